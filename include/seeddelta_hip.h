@@ -1,0 +1,159 @@
+/*
+ * seeddelta_hip.h — C ABI of libseeddelta_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary for the SeedDelta FFN hot path of frudas24/llama.cpp.
+ * Everything crossing it is plain C: raw pointers, sizes, ggml type codes. No torch
+ * types, no C++ types, no exceptions. Every entry point returns 0 on success or a
+ * negative sdh_status; sdh_last_error() gives the text for the calling thread.
+ *
+ * What the reference binds here (reference paths relative to /root/reference):
+ *   - the four custom-op callbacks of src/llama-seeddelta.cpp (:582 coo, :714 block,
+ *     :1014 base+coo, :1178 base+block) — replaced by sdh_forward();
+ *   - the payload struct llama_seeddelta_weight (src/llama-seeddelta.h:12-25) — mirrored
+ *     by sdh_weight_desc, validated with the rules of src/llama-context.cpp:145-268;
+ *   - the builder's candidate-evaluation loop (tools/seeddelta-build/sd_build.cpp:463-800,
+ *     sd_eval.cpp, sd_ffn_proxy.cpp) — replaced by the sdh_scan_* calls.
+ *
+ * The host-side C++ translation unit that forwards the reference's ggml custom ops to
+ * this ABI lives in llama.cpp_amd/shim/llama-seeddelta-hip.cpp; INTEGRATION.md shows the
+ * two-line change a maintainer makes to use it.
+ */
+#ifndef SEEDDELTA_HIP_H
+#define SEEDDELTA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDH_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------------------ */
+typedef enum sdh_status {
+    SDH_OK              =  0,
+    SDH_ERR_INVALID     = -1,  /* bad argument / payload rejected by validation          */
+    SDH_ERR_NO_DEVICE   = -2,  /* no HIP device, or sdh_init() not called                 */
+    SDH_ERR_HIP         = -3,  /* a HIP runtime call failed (text in sdh_last_error)      */
+    SDH_ERR_UNSUPPORTED = -4,  /* valid payload, but a shape/type this build cannot run   */
+    SDH_ERR_TOO_LARGE   = -5   /* exceeds a stated static limit (no-alloc entry points)   */
+} sdh_status;
+
+/* ---- element types: numerically identical to enum ggml_type
+ *      (ggml/include/ggml.h:385-411) so a shim can pass tensor->type through unchanged.  */
+typedef enum sdh_type {
+    SDH_TYPE_F32  = 0,   /* GGML_TYPE_F32  */
+    SDH_TYPE_F16  = 1,   /* GGML_TYPE_F16  */
+    SDH_TYPE_Q8_0 = 8,   /* GGML_TYPE_Q8_0 (dense weights for the scan only) */
+    SDH_TYPE_I16  = 25,  /* GGML_TYPE_I16  */
+    SDH_TYPE_I32  = 26   /* GGML_TYPE_I32  */
+} sdh_type;
+
+/* A borrowed view of one ggml tensor: the fields of struct ggml_tensor the reference op
+ * reads (data, type, ne[], nb[]; ggml/include/ggml.h:640-676). data == NULL means "tensor
+ * absent" (the reference passes nullptr for optional tensors). Host memory. */
+typedef struct sdh_tensor {
+    const void * data;
+    int32_t      type;     /* sdh_type */
+    int32_t      n_dims;   /* ggml_n_dims() of the tensor */
+    int64_t      ne[4];    /* elements per dimension, ne[0] fastest */
+    int64_t      nb[4];    /* stride in bytes per dimension */
+} sdh_tensor;
+
+/* Mirror of struct llama_seeddelta_weight (src/llama-seeddelta.h:12-25), plus the dims of
+ * the dense weight it replaces (w->ne[0] = n_in, w->ne[1] = n_out). */
+typedef struct sdh_weight_desc {
+    int64_t    n_in;
+    int64_t    n_out;
+    sdh_tensor d_idx;       /* [K, n_out]        I16/I32 */
+    sdh_tensor d_val;       /* [K, n_out]        F16/F32 */
+    sdh_tensor b_idx;       /* [nb, n_out]       I16/I32 */
+    sdh_tensor b_val;       /* [block,nb,n_out]  F16/F32 */
+    sdh_tensor row_scale;   /* [n_out]           F16/F32, optional */
+    sdh_tensor base_d1;     /* [L, B]            F16/F32, optional (presence selects the base ops) */
+    sdh_tensor base_d2;     /* [L, B]            F16/F32, optional */
+    sdh_tensor base_d3;     /* [L, B]            F16/F32, optional */
+    sdh_tensor base_perm1;  /* [L, B]            I16/I32, optional */
+    sdh_tensor base_perm2;  /* [L, B]            I16/I32, optional */
+} sdh_weight_desc;
+
+typedef struct sdh_weight sdh_weight;   /* opaque: device-resident payload */
+
+/* Which of the reference's four ops a handle dispatches to (src/llama-graph.cpp:681-703:
+ * block payload wins over COO; base variant iff base_d1). */
+typedef enum sdh_op_kind {
+    SDH_OP_COO        = 0,  /* llama_seeddelta_coo_op        src/llama-seeddelta.cpp:582  */
+    SDH_OP_BLOCK      = 1,  /* llama_seeddelta_block_op      :714  */
+    SDH_OP_BASE_COO   = 2,  /* llama_seeddelta_base_op       :1014 */
+    SDH_OP_BASE_BLOCK = 3   /* llama_seeddelta_base_block_op :1178 */
+} sdh_op_kind;
+
+/* ---- forward flags ------------------------------------------------------------------ */
+#define SDH_FWD_DEVICE_IO     0x0  /* x and y are device pointers; async on `stream`          */
+#define SDH_FWD_HOST_IO       0x1  /* x and y are host pointers; copies in/out and waits       */
+#define SDH_FWD_ZERO_NONFINITE 0x2 /* non-finite outputs are written as 0.0f (the reference's
+                                      behaviour when the dense weight is stripped,
+                                      src/llama-seeddelta.cpp:373-380); without this flag they
+                                      are left as computed so the caller can repair them       */
+#define SDH_FWD_EXACT_ORDER   0x4  /* verification mode: accumulate every output in the
+                                      reference's sequential order (one lane per output) so the
+                                      result is bit-identical to the CPU op. Slow.             */
+#define SDH_FWD_W0_MFMA       0x8  /* prefill: evaluate the base as W0 tiles regenerated in LDS
+                                      and contracted on MFMA instead of the FWHT form          */
+
+/* ---- library / device ----------------------------------------------------------------
+ * sdh_init: bind the calling process to HIP device `device` and create the library's
+ * stream and scratch. Idempotent per device. Replaces nothing in the reference (its op is
+ * CPU-only); a shim calls it lazily from the first custom-op callback. */
+int          sdh_init(int device);
+int          sdh_abi_version(void);
+const char * sdh_last_error(void);
+int          sdh_device_synchronize(void);
+
+/* ---- weights -------------------------------------------------------------------------
+ * sdh_weight_create: validate a payload exactly as try_add_seeddelta does
+ * (src/llama-context.cpp:145-268: dims, types, L pow2, L >= min(n_in,n_out),
+ * B >= ceil(max(n_in,n_out)/L)), upload it once, precompute what the kernels need.
+ * Rejected sub-payloads degrade the same way the reference does (a bad COO pair is
+ * dropped, a bad row_scale is ignored, a bad base drops all base tensors); if nothing
+ * usable remains the call fails with SDH_ERR_INVALID. The host tensors are not referenced
+ * after the call returns. */
+int  sdh_weight_create(const sdh_weight_desc * desc, sdh_weight ** out);
+void sdh_weight_destroy(sdh_weight * w);
+int  sdh_weight_op_kind(const sdh_weight * w);            /* sdh_op_kind, or <0 */
+/* bytes of the payload as stored by the GGUF (the "algorithmic bytes" of SURVEY §8d,
+ * without the T*4*(n_in+n_out) activation term). */
+int64_t sdh_weight_payload_bytes(const sdh_weight * w);
+
+/* sdh_forward — replaces the body of the reference's custom-op callback for this payload:
+ *   y[o + t*ldy] = row_scale[o] * ( W0(x[:,t])[o] + sum_r val[r,o] * x[idx[r,o] + t*ldx] )
+ * x: F32 [n_in, n_tokens] with column stride ldx (elements); y: F32 [n_out, n_tokens] with
+ * column stride ldy. `stream` is a hipStream_t (NULL = the library's own stream).
+ * Semantics follow src/llama-seeddelta.cpp: invalid indices skipped (:693, :929-936),
+ * out-of-range perm entries read element 0 (:524-527), scale applied only if != 1 (:645),
+ * tall/wide base split on n_out >= n_in (:1073). */
+int sdh_forward(sdh_weight * w,
+                const float * x, int64_t ldx, int64_t n_tokens,
+                float * y, int64_t ldy,
+                int flags, void * stream);
+
+/* Number of non-finite outputs produced by the most recent sdh_forward on this handle
+ * (the reference's llama_seeddelta_nan_count, src/llama-seeddelta.cpp:77,382, per call).
+ * Waits for that forward to finish. */
+int64_t sdh_nonfinite_count(sdh_weight * w);
+
+/* Regenerate a tile of the dense base W0 (bit-exact integer XOR indexing into the per-block
+ * table G_b = FWHT(d2_b)): out[(o-o0) + (i-i0)*(o1-o0)] = W0[o,i] for o in [o0,o1), i in [i0,i1).
+ * `out` is a device or host pointer according to `flags` (SDH_FWD_HOST_IO). Used by the
+ * parity tests and by the MFMA prefill path. Follows the W0 definition implied by
+ * apply_base_block (src/llama-seeddelta.cpp:497-574) and used explicitly by the builder
+ * (tools/seeddelta-build/sd_eval.cpp:506,528,714-716). Only valid for depth-2 payloads
+ * without base_perm2 and with a bijective perm1 (what the builder writes). */
+int sdh_w0_tile(sdh_weight * w, int64_t o0, int64_t o1, int64_t i0, int64_t i1,
+                float * out, int flags, void * stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEEDDELTA_HIP_H */
