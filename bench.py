@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py — SeedDelta FFN decode throughput on MI355X (BASELINE.json metric, config 3).
+
+A "step" is one pass of the hot path over one batch of synthetic input: one token (T=1) through the
+SeedDelta op of one FFN tensor — by default Mistral-7B ``blk.23.ffn_down`` (14336 -> 4096), block32
+K=1536 (nb=48), base L=4096 B=4, row_scale: 13,189,120 algorithmic bytes per step.
+Inputs are resident in HBM when the timed region starts. To keep the 256 MB Infinity Cache from
+serving the payload, the loop rotates over ``--payloads`` (default 32 => 420 MB) distinct payloads and
+activations.
+
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the FFN path does not shard — one model
+fits one GPU — so ranks run independent replicas ("replicas only", weak scaling), no data-path
+collective; the reported value is all ranks' steps / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 with the throughput, a ``roofline`` object for the dominant kernel
+(payload-streaming residual kernel; duration from HIP events recorded by the library on the launch
+stream) and a ``cpu_baseline`` object (the reference's own translation unit from oracle/_ref when that
+prebuilt .so is present, else the oracle port; rank 0, N=1 only; bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 achievable)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8192)
+    ap.add_argument("--warmup", type=int, default=512)
+    ap.add_argument("--workload", default="cfg3_mistral_down_block32_k1536")
+    ap.add_argument("--payloads", type=int, default=32, help="distinct payloads rotated per loop (cache honesty)")
+    ap.add_argument("--tokens", type=int, default=1, help="tokens per step (1 = decode)")
+    ap.add_argument("--launch", choices=["graph", "eager"], default="graph")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(workload: str, tokens: int, budget_s: float):
+    """Reference CPU path on this host's cores, bounded sample. kind = 'reference' when the prebuilt
+    oracle/_ref/libsdref.so (the reference's own TU) is present, else 'port' (oracle/sd_oracle.c)."""
+    import oracle_py as O
+    from llama_cpp_amd.payload import config_payload, make_x
+    p = config_payload(workload, seed=1234)
+    x = make_x(p.n_in, tokens, seed=1)
+    use_ref = O.ref_available()
+    if not use_ref:
+        O.oracle_lib()
+    cores = min(16, os.cpu_count() or 1)       # the GPU box gives a 16-core share per GPU
+    y = np.empty((tokens, p.n_out), dtype=np.float32)
+    O.forward(p, x, nth=cores, use_ref=use_ref, out=y)      # warm
+    n, t0 = 0, time.perf_counter()
+    while True:
+        O.forward(p, x, nth=cores, use_ref=use_ref, out=y)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 2000:
+            break
+    note = ""
+    if tokens == 1 and not p.is_tall:
+        note = "; wide base path splits tokens across threads, so at T=1 one thread does all the work (src/llama-seeddelta.cpp:1129-1131)"
+    return {
+        "value": n * tokens / el, "unit": "tok/s", "cores": cores,
+        "kind": "reference" if use_ref else "port",
+        "sample": f"{n} evaluations of {workload} at T={tokens} in {el:.1f}s, {cores} threads{note}",
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+    import llama_cpp_amd  # noqa: F401
+    from llama_cpp_amd import seeddelta
+    from llama_cpp_amd.payload import config_payload
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    seeddelta.init(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    T = args.tokens
+    NP = max(1, args.payloads)
+    weights, xs, ys = [], [], []
+    alg_bytes = None
+    for i in range(NP):
+        p = config_payload(args.workload, seed=1234 + i)
+        w = seeddelta.SeedDeltaWeight(p)
+        weights.append(w)
+        alg_bytes = p.algorithmic_bytes(T)
+        g = torch.Generator(device="cpu").manual_seed(1 + i)
+        xs.append(torch.randn((T, p.n_in), generator=g, dtype=torch.float32).to(dev))
+        ys.append(torch.empty((T, p.n_out), dtype=torch.float32, device=dev))
+        n_in, n_out = p.n_in, p.n_out
+        del p
+    torch.cuda.synchronize()
+
+    def run_rotation(stream_ptr):
+        for i in range(NP):
+            weights[i].forward_device(xs[i].data_ptr(), n_in, T, ys[i].data_ptr(), n_out, stream=stream_ptr)
+
+    steps = max(NP, (args.steps // NP) * NP)
+    warm = max(NP, (args.warmup // NP) * NP)
+    cur = torch.cuda.current_stream()
+
+    graph = None
+    if args.launch == "graph":
+        run_rotation(cur.cuda_stream)           # allocate workspaces outside capture
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            run_rotation(torch.cuda.current_stream().cuda_stream)
+
+    def loop(n_steps):
+        if graph is not None:
+            for _ in range(n_steps // NP):
+                graph.replay()
+        else:
+            sp = cur.cuda_stream
+            for _ in range(n_steps // NP):
+                run_rotation(sp)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    loop(warm)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loop(steps)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # roofline leg: the same steps, eager, with the library bracketing the dominant kernel of every
+    # forward with hipEvents on the launch stream
+    roof = None
+    if not args.no_roofline and rank == 0:
+        seeddelta.profile_enable(True)
+        sp = cur.cuda_stream
+        n_prof = min(steps, 4096)
+        for _ in range(max(1, n_prof // NP)):
+            run_rotation(sp)
+        torch.cuda.synchronize()
+        ms, n = seeddelta.profile_read()
+        seeddelta.profile_enable(False)
+        if n > 0:
+            dur_s = ms / 1e3 / n
+            achieved = alg_bytes / dur_s / 1e9
+            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "kernel": "delta_rows_kernel", "avg_kernel_us": dur_s * 1e6, "launches": n,
+                    "algorithmic_bytes_per_launch": alg_bytes}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.workload, T, args.cpu_seconds)
+
+    if rank == 0:
+        value = world * steps * T / elapsed
+        line = {
+            "metric": "SeedDelta FFN decode tok/s (Mistral-7B)", "value": value, "unit": "tok/s",
+            "n_gpus": world, "steps": steps, "warmup": warm,
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "tokens_per_step": T, "n_in": n_in, "n_out": n_out,
+                       "distinct_payloads": NP, "launch": args.launch,
+                       "parallelism": "replicas only" if world > 1 else "single GPU"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

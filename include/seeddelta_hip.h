@@ -153,6 +153,15 @@ int64_t sdh_nonfinite_count(sdh_weight * w);
 int sdh_w0_tile(sdh_weight * w, int64_t o0, int64_t o1, int64_t i0, int64_t i1,
                 float * out, int flags, void * stream);
 
+/* ---- measurement hooks (no counterpart in the reference; used by bench.py) -------------------
+ * sdh_profile_enable(1): from now on every sdh_forward brackets its dominant kernel (the
+ * residual/epilogue kernel that streams the payload) with a pair of hipEvents recorded on the
+ * stream the kernel is launched on. sdh_profile_read waits for the recorded events, returns the
+ * summed elapsed milliseconds and the number of bracketed launches since the last read, and
+ * resets both. sdh_profile_enable(0) stops recording. Not for use under graph capture. */
+int sdh_profile_enable(int on);
+int sdh_profile_read(double * total_ms, int64_t * launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,531 @@
+// sdh_api.hip — the C ABI of include/seeddelta_hip.h: device set-up, payload validation and
+// upload, forward dispatch. Host code only (kernels live in sdh_base.hip / sdh_delta.hip).
+#include "sdh_internal.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+namespace sdh {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char * fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+LibState & lib() {
+    static LibState s;
+    return s;
+}
+
+static std::mutex g_mu;
+
+// ---- host-side tensor helpers ---------------------------------------------------------------
+static inline bool present(const sdh_tensor & t) { return t.data != nullptr; }
+
+static float half_to_float(uint16_t h) {
+    const uint32_t sign = ((uint32_t) h & 0x8000u) << 16;
+    const uint32_t e = (h >> 10) & 0x1Fu;
+    uint32_t m = h & 0x3FFu;
+    uint32_t bits;
+    if (e == 0x1Fu)      bits = sign | 0x7F800000u | (m << 13);
+    else if (e != 0)     bits = sign | ((e + 112u) << 23) | (m << 13);
+    else if (m == 0)     bits = sign;
+    else {
+        uint32_t ee = 113u;
+        while ((m & 0x400u) == 0) { m <<= 1; --ee; }
+        bits = sign | (ee << 23) | ((m & 0x3FFu) << 13);
+    }
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+
+static inline size_t type_size(int type) {
+    switch (type) {
+        case SDH_TYPE_F32: case SDH_TYPE_I32: return 4;
+        case SDH_TYPE_F16: case SDH_TYPE_I16: return 2;
+        default: return 0;
+    }
+}
+
+static inline const uint8_t * elem_ptr(const sdh_tensor & t, int64_t i0, int64_t i1, int64_t i2) {
+    return (const uint8_t *) t.data + i0 * t.nb[0] + i1 * t.nb[1] + i2 * t.nb[2];
+}
+
+// copy a (possibly strided) tensor into a contiguous byte vector, keeping its element type
+static std::vector<uint8_t> pack_raw(const sdh_tensor & t) {
+    const size_t es = type_size(t.type);
+    const int64_t n0 = t.ne[0], n1 = t.ne[1], n2 = t.ne[2];
+    std::vector<uint8_t> out((size_t) (n0 * n1 * n2) * es);
+    uint8_t * dst = out.data();
+    const bool row_contig = (size_t) t.nb[0] == es;
+    for (int64_t i2 = 0; i2 < n2; ++i2)
+        for (int64_t i1 = 0; i1 < n1; ++i1) {
+            if (row_contig) {
+                memcpy(dst, elem_ptr(t, 0, i1, i2), (size_t) n0 * es);
+                dst += (size_t) n0 * es;
+            } else {
+                for (int64_t i0 = 0; i0 < n0; ++i0) { memcpy(dst, elem_ptr(t, i0, i1, i2), es); dst += es; }
+            }
+        }
+    return out;
+}
+
+static std::vector<float> pack_f32(const sdh_tensor & t) {     // F16/F32 -> F32, exact
+    const int64_t n0 = t.ne[0], n1 = t.ne[1];
+    std::vector<float> out((size_t) (n0 * n1));
+    for (int64_t i1 = 0; i1 < n1; ++i1)
+        for (int64_t i0 = 0; i0 < n0; ++i0) {
+            const uint8_t * p = elem_ptr(t, i0, i1, 0);
+            float f;
+            if (t.type == SDH_TYPE_F16) { uint16_t h; memcpy(&h, p, 2); f = half_to_float(h); }
+            else memcpy(&f, p, 4);
+            out[(size_t) (i1 * n0 + i0)] = f;
+        }
+    return out;
+}
+
+static std::vector<int32_t> pack_i32(const sdh_tensor & t) {   // I16/I32 -> I32
+    const int64_t n0 = t.ne[0], n1 = t.ne[1];
+    std::vector<int32_t> out((size_t) (n0 * n1));
+    for (int64_t i1 = 0; i1 < n1; ++i1)
+        for (int64_t i0 = 0; i0 < n0; ++i0) {
+            const uint8_t * p = elem_ptr(t, i0, i1, 0);
+            int32_t v;
+            if (t.type == SDH_TYPE_I16) { int16_t s; memcpy(&s, p, 2); v = s; }
+            else memcpy(&v, p, 4);
+            out[(size_t) (i1 * n0 + i0)] = v;
+        }
+    return out;
+}
+
+static void host_fwht(float * a, int64_t n) {      // reference stage order (:484-493)
+    for (int64_t len = 1; len < n; len <<= 1)
+        for (int64_t i = 0; i < n; i += (len << 1))
+            for (int64_t j = 0; j < len; ++j) {
+                const float u = a[i + j], v = a[i + j + len];
+                a[i + j] = u + v;
+                a[i + j + len] = u - v;
+            }
+}
+
+template <typename T>
+static int upload(const std::vector<T> & h, T ** d) {
+    *d = nullptr;
+    if (h.empty()) return SDH_OK;
+    SDH_HIP_CHECK(hipMalloc((void **) d, h.size() * sizeof(T)));
+    SDH_HIP_CHECK(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return SDH_OK;
+}
+
+static void free_weight(DeviceWeight * w) {
+    if (!w) return;
+    (void) hipFree(w->idx); (void) hipFree(w->val); (void) hipFree(w->rs);
+    (void) hipFree(w->d1); (void) hipFree(w->d2); (void) hipFree(w->d3); (void) hipFree(w->p1); (void) hipFree(w->p2);
+    (void) hipFree(w->G); (void) hipFree(w->inv); (void) hipFree(w->nf_ring); (void) hipFree(w->ws);
+    delete w;
+}
+
+static int ensure_ws(DeviceWeight * w, size_t bytes) {
+    if (w->ws_bytes >= bytes) return SDH_OK;
+    if (w->ws) { SDH_HIP_CHECK(hipFree(w->ws)); w->ws = nullptr; w->ws_bytes = 0; }
+    SDH_HIP_CHECK(hipMalloc((void **) &w->ws, bytes));
+    w->ws_bytes = bytes;
+    return SDH_OK;
+}
+
+// drain recorded event pairs into the running totals (waits for the last one)
+static int prof_flush(LibState & s) {
+    for (int i = 0; i < s.prof_used; ++i) {
+        SDH_HIP_CHECK(hipEventSynchronize(s.prof_ev[2 * i + 1]));
+        float ms = 0.0f;
+        SDH_HIP_CHECK(hipEventElapsedTime(&ms, s.prof_ev[2 * i], s.prof_ev[2 * i + 1]));
+        s.prof_ms += (double) ms;
+        s.prof_n += 1;
+    }
+    s.prof_used = 0;
+    return SDH_OK;
+}
+
+} // namespace sdh
+
+using namespace sdh;
+
+// ================================================================================================
+extern "C" {
+
+int sdh_abi_version(void) { return SDH_ABI_VERSION; }
+
+const char * sdh_last_error(void) { return g_last_error.c_str(); }
+
+int sdh_init(int device) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    LibState & s = lib();
+    if (s.inited && s.device == device) return SDH_OK;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        set_error("no HIP device visible");
+        return SDH_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) {
+        set_error("device %d out of range (%d visible)", device, n);
+        return SDH_ERR_INVALID;
+    }
+    SDH_HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    SDH_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (!s.stream) SDH_HIP_CHECK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    s.num_cu = prop.multiProcessorCount;
+    s.device = device;
+    s.inited = true;
+    return SDH_OK;
+}
+
+int sdh_device_synchronize(void) {
+    if (!lib().inited) { set_error("sdh_init not called"); return SDH_ERR_NO_DEVICE; }
+    SDH_HIP_CHECK(hipDeviceSynchronize());
+    return SDH_OK;
+}
+
+// Validation follows try_add_seeddelta (src/llama-context.cpp:145-268).
+int sdh_weight_create(const sdh_weight_desc * desc, sdh_weight ** out) {
+    if (!desc || !out) { set_error("null argument"); return SDH_ERR_INVALID; }
+    *out = nullptr;
+    if (!lib().inited) { set_error("sdh_init not called"); return SDH_ERR_NO_DEVICE; }
+    const int64_t n_in = desc->n_in, n_out = desc->n_out;
+    if (n_in <= 0 || n_out <= 0 || n_in > INT32_MAX / 2 || n_out > INT32_MAX / 2) {
+        set_error("invalid dims n_in=%lld n_out=%lld", (long long) n_in, (long long) n_out);
+        return SDH_ERR_INVALID;
+    }
+
+    sdh_tensor d_idx = desc->d_idx, d_val = desc->d_val, b_idx = desc->b_idx, b_val = desc->b_val;
+    sdh_tensor rs = desc->row_scale;
+    sdh_tensor d1 = desc->base_d1, d2 = desc->base_d2, d3 = desc->base_d3;
+    sdh_tensor p1 = desc->base_perm1, p2 = desc->base_perm2;
+    auto drop = [](sdh_tensor & t) { t.data = nullptr; };
+    auto is_idx = [](int t) { return t == SDH_TYPE_I16 || t == SDH_TYPE_I32; };
+    auto is_flt = [](int t) { return t == SDH_TYPE_F16 || t == SDH_TYPE_F32; };
+
+    bool have_coo = present(d_idx) && present(d_val);
+    bool have_block = present(b_idx) && present(b_val);
+    if (have_coo) {                                                      // :162-177
+        if (d_idx.n_dims != 2 || d_val.n_dims != 2 || !is_idx(d_idx.type) || !is_flt(d_val.type) ||
+            d_idx.ne[0] != d_val.ne[0] || d_idx.ne[1] != d_val.ne[1] || d_idx.ne[1] != n_out) {
+            have_coo = false;
+        }
+    }
+    if (have_block) {                                                    // :179-194
+        if (b_idx.n_dims != 2 || b_val.n_dims != 3 || !is_idx(b_idx.type) || !is_flt(b_val.type) ||
+            b_val.ne[1] != b_idx.ne[0] || b_val.ne[2] != b_idx.ne[1] || b_idx.ne[1] != n_out) {
+            have_block = false;
+        }
+    }
+    if (!have_coo && !have_block) {
+        set_error("payload has no valid COO or block residual");
+        return SDH_ERR_INVALID;
+    }
+    if (present(rs)) {                                                   // :206-213
+        if (rs.n_dims != 1 || !is_flt(rs.type) || rs.ne[0] != n_out) drop(rs);
+    }
+    const bool any_base = present(d1) || present(d2) || present(d3) || present(p1) || present(p2);
+    if (any_base) {                                                      // :218-268
+        bool ok = present(d1) && d1.n_dims == 2 && is_flt(d1.type);
+        if (ok) {
+            const int64_t L = d1.ne[0], B = d1.ne[1];
+            const bool pow2 = L > 0 && (L & (L - 1)) == 0;
+            const int64_t need_L = n_in < n_out ? n_in : n_out;
+            const int64_t need_B = ((n_in > n_out ? n_in : n_out) + L - 1) / L;
+            if (!pow2 || L < need_L || B < need_B) ok = false;
+        }
+        if (!ok) { drop(d1); drop(d2); drop(d3); drop(p1); drop(p2); }
+        auto same = [&](sdh_tensor & t, bool perm) {
+            if (!present(t) || !present(d1)) return;
+            if (t.n_dims != 2 || t.ne[0] != d1.ne[0] || t.ne[1] != d1.ne[1] ||
+                (perm ? !is_idx(t.type) : !is_flt(t.type))) drop(t);
+        };
+        same(d2, false); same(d3, false); same(p1, true); same(p2, true);
+    }
+    const bool have_base = present(d1);
+
+    DeviceWeight * w = new DeviceWeight();
+    w->device = lib().device;
+    w->n_in = n_in; w->n_out = n_out;
+    w->tall = n_out >= n_in;                                             // src/llama-seeddelta.cpp:1073
+    // dispatch priority of src/llama-graph.cpp:681-703
+    if (have_block) w->kind = have_base ? SDH_OP_BASE_BLOCK : SDH_OP_BLOCK;
+    else            w->kind = have_base ? SDH_OP_BASE_COO : SDH_OP_COO;
+
+    int rc = SDH_OK;
+    auto fail = [&](int code) { free_weight(w); return code; };
+
+    if (have_block) {
+        w->nb = b_idx.ne[0]; w->block = b_val.ne[0];
+        w->idx_type = b_idx.type; w->val_type = b_val.type;
+        if (w->nb * w->block > INT32_MAX / 4) { set_error("row too long"); return fail(SDH_ERR_UNSUPPORTED); }
+        std::vector<uint8_t> hi = pack_raw(b_idx), hv = pack_raw(b_val);
+        w->payload_bytes += (int64_t) hi.size() + (int64_t) hv.size();
+        if ((rc = upload(hi, (uint8_t **) &w->idx)) != SDH_OK) return fail(rc);
+        if ((rc = upload(hv, (uint8_t **) &w->val)) != SDH_OK) return fail(rc);
+    } else {
+        w->K = d_idx.ne[0];
+        w->idx_type = d_idx.type; w->val_type = d_val.type;
+        if (w->K > INT32_MAX / 4) { set_error("row too long"); return fail(SDH_ERR_UNSUPPORTED); }
+        std::vector<uint8_t> hi = pack_raw(d_idx), hv = pack_raw(d_val);
+        w->payload_bytes += (int64_t) hi.size() + (int64_t) hv.size();
+        if ((rc = upload(hi, (uint8_t **) &w->idx)) != SDH_OK) return fail(rc);
+        if ((rc = upload(hv, (uint8_t **) &w->val)) != SDH_OK) return fail(rc);
+    }
+    if (present(rs)) {
+        sdh_tensor r2 = rs; r2.ne[1] = 1;
+        std::vector<float> h = pack_f32(r2);
+        w->payload_bytes += (int64_t) n_out * (int64_t) type_size(rs.type);
+        if ((rc = upload(h, &w->rs)) != SDH_OK) return fail(rc);
+    }
+    if (have_base) {
+        const int64_t L = d1.ne[0], B = d1.ne[1];
+        w->L = L; w->B = B;
+        w->logL = 0; while ((1LL << w->logL) < L) ++w->logL;
+        const size_t n = (size_t) (L * B);
+        std::vector<float> h1 = pack_f32(d1), h2, h3;
+        w->payload_bytes += (int64_t) n * (int64_t) type_size(d1.type);
+        if ((rc = upload(h1, &w->d1)) != SDH_OK) return fail(rc);
+        if (present(d2)) {
+            h2 = pack_f32(d2);
+            w->payload_bytes += (int64_t) n * (int64_t) type_size(d2.type);
+            if ((rc = upload(h2, &w->d2)) != SDH_OK) return fail(rc);
+        }
+        if (present(d3)) {
+            h3 = pack_f32(d3);
+            w->payload_bytes += (int64_t) n * (int64_t) type_size(d3.type);
+            if ((rc = upload(h3, &w->d3)) != SDH_OK) return fail(rc);
+        }
+        std::vector<int32_t> hp1, hp2;
+        auto clamp_perm = [&](std::vector<int32_t> & p) {          // out of range -> 0 (:524-527)
+            for (auto & s : p) if (s < 0 || s >= (int32_t) L) s = 0;
+        };
+        if (present(p1)) {
+            hp1 = pack_i32(p1); clamp_perm(hp1);
+            w->payload_bytes += (int64_t) n * (int64_t) type_size(p1.type);
+            if ((rc = upload(hp1, &w->p1)) != SDH_OK) return fail(rc);
+        }
+        if (present(p2)) {
+            hp2 = pack_i32(p2); clamp_perm(hp2);
+            w->payload_bytes += (int64_t) n * (int64_t) type_size(p2.type);
+            if ((rc = upload(hp2, &w->p2)) != SDH_OK) return fail(rc);
+        }
+        // closed-form tables: G_b = FWHT(d2_b) (d2 absent => all-ones), inv_b = perm1_b^-1
+        std::vector<float> G(n);
+        std::vector<int32_t> inv(n, -1);
+        bool bijective = true;
+        for (int64_t b = 0; b < B; ++b) {
+            for (int64_t i = 0; i < L; ++i) G[(size_t) (b * L + i)] = h2.empty() ? 1.0f : h2[(size_t) (b * L + i)];
+            host_fwht(G.data() + b * L, L);
+            for (int64_t i = 0; i < L; ++i) {
+                const int32_t src = hp1.empty() ? (int32_t) i : hp1[(size_t) (b * L + i)];
+                if (inv[(size_t) (b * L + src)] != -1) bijective = false;
+                inv[(size_t) (b * L + src)] = (int32_t) i;
+            }
+        }
+        if (!bijective) for (auto & v : inv) if (v < 0) v = 0;
+        w->w0_closed_form = bijective && present(d2) && !present(p2);
+        if ((rc = upload(G, &w->G)) != SDH_OK) return fail(rc);
+        if ((rc = upload(inv, &w->inv)) != SDH_OK) return fail(rc);
+    }
+    {
+        hipError_t e = hipMalloc((void **) &w->nf_ring, DeviceWeight::NF_SLOTS * sizeof(int));
+        if (e == hipSuccess) e = hipMemset(w->nf_ring, 0, DeviceWeight::NF_SLOTS * sizeof(int));
+        if (e != hipSuccess) { set_error("nf ring alloc failed: %s", hipGetErrorString(e)); return fail(SDH_ERR_HIP); }
+    }
+    *out = reinterpret_cast<sdh_weight *>(w);
+    return SDH_OK;
+}
+
+void sdh_weight_destroy(sdh_weight * h) {
+    if (!h) return;
+    (void) hipDeviceSynchronize();
+    free_weight(reinterpret_cast<DeviceWeight *>(h));
+}
+
+int sdh_weight_op_kind(const sdh_weight * h) {
+    if (!h) { set_error("null weight"); return SDH_ERR_INVALID; }
+    return reinterpret_cast<const DeviceWeight *>(h)->kind;
+}
+
+int64_t sdh_weight_payload_bytes(const sdh_weight * h) {
+    if (!h) { set_error("null weight"); return SDH_ERR_INVALID; }
+    return reinterpret_cast<const DeviceWeight *>(h)->payload_bytes;
+}
+
+int sdh_forward(sdh_weight * h, const float * x, int64_t ldx, int64_t n_tokens,
+                float * y, int64_t ldy, int flags, void * stream) {
+    if (!h || !x || !y) { set_error("null argument"); return SDH_ERR_INVALID; }
+    if (!lib().inited) { set_error("sdh_init not called"); return SDH_ERR_NO_DEVICE; }
+    DeviceWeight * w = reinterpret_cast<DeviceWeight *>(h);
+    if (n_tokens < 0 || ldx < w->n_in || ldy < w->n_out) {
+        set_error("bad shape: T=%lld ldx=%lld (n_in=%lld) ldy=%lld (n_out=%lld)", (long long) n_tokens,
+                  (long long) ldx, (long long) w->n_in, (long long) ldy, (long long) w->n_out);
+        return SDH_ERR_INVALID;
+    }
+    if (n_tokens == 0) return SDH_OK;
+    hipStream_t s = stream ? (hipStream_t) stream : lib().stream;
+    const bool host_io = (flags & SDH_FWD_HOST_IO) != 0;
+    const bool has_base = (w->kind == SDH_OP_BASE_COO || w->kind == SDH_OP_BASE_BLOCK);
+
+    const float * dx = x;
+    float * dy = y;
+    int64_t dldx = ldx, dldy = ldy;
+    if (host_io) {
+        LibState & L = lib();
+        const size_t xb = (size_t) n_tokens * (size_t) w->n_in * 4, yb = (size_t) n_tokens * (size_t) w->n_out * 4;
+        if (L.hx_bytes < xb) {
+            if (L.hx) SDH_HIP_CHECK(hipFree(L.hx));
+            L.hx = nullptr; L.hx_bytes = 0;
+            SDH_HIP_CHECK(hipMalloc((void **) &L.hx, xb)); L.hx_bytes = xb;
+        }
+        if (L.hy_bytes < yb) {
+            if (L.hy) SDH_HIP_CHECK(hipFree(L.hy));
+            L.hy = nullptr; L.hy_bytes = 0;
+            SDH_HIP_CHECK(hipMalloc((void **) &L.hy, yb)); L.hy_bytes = yb;
+        }
+        SDH_HIP_CHECK(hipMemcpy2DAsync(L.hx, (size_t) w->n_in * 4, x, (size_t) ldx * 4, (size_t) w->n_in * 4,
+                                       (size_t) n_tokens, hipMemcpyHostToDevice, s));
+        dx = L.hx; dy = L.hy; dldx = w->n_in; dldy = w->n_out;
+    }
+
+    // per-call non-finite counter: ring slot, the second half of the ring is re-zeroed while the
+    // first half is in use (one small memset every NF_SLOTS/2 calls, none on the other calls)
+    constexpr int NS = DeviceWeight::NF_SLOTS;
+    const int slot = (int) (w->seq % NS);
+    if (w->seq > 0 && slot % (NS / 2) == 0) {
+        SDH_HIP_CHECK(hipMemsetAsync(w->nf_ring + slot, 0, (NS / 2) * sizeof(int), s));
+    }
+
+    // token chunking bounds the base-term workspace
+    int64_t chunk = n_tokens;
+    if (has_base) {
+        const size_t per_tok = (size_t) w->B * (size_t) w->L * 4;
+        const size_t cap = (size_t) 512 << 20;
+        if (per_tok * (size_t) chunk > cap) chunk = (int64_t) (cap / per_tok);
+        if (chunk < 1) chunk = 1;
+        int rc = ensure_ws(w, per_tok * (size_t) chunk);
+        if (rc != SDH_OK) return rc;
+    }
+    for (int64_t t0 = 0; t0 < n_tokens; t0 += chunk) {
+        const int64_t tc = (n_tokens - t0 < chunk) ? (n_tokens - t0) : chunk;
+        const float * xc = dx + t0 * dldx;
+        if (has_base) {
+            int rc = launch_base_apply(*w, xc, dldx, tc, w->ws, s);
+            if (rc != SDH_OK) return rc;
+        }
+        DeltaLaunch a{};
+        a.x = xc; a.ldx = dldx; a.T = tc;
+        a.y = dy + t0 * dldy; a.ldy = dldy;
+        a.v = has_base ? w->ws : nullptr;
+        a.nf_counter = w->nf_ring + slot;
+        a.zero_nonfinite = (flags & SDH_FWD_ZERO_NONFINITE) != 0;
+        a.exact_order = (flags & SDH_FWD_EXACT_ORDER) != 0;
+        LibState & ls = lib();
+        int pair = -1;
+        if (ls.prof_on) {
+            if (ls.prof_used == LibState::PROF_PAIRS) { int rcf = prof_flush(ls); if (rcf != SDH_OK) return rcf; }
+            pair = ls.prof_used;
+            SDH_HIP_CHECK(hipEventRecord(ls.prof_ev[2 * pair], s));
+        }
+        int rc = launch_delta(*w, a, s);
+        if (rc != SDH_OK) return rc;
+        if (pair >= 0) {
+            SDH_HIP_CHECK(hipEventRecord(ls.prof_ev[2 * pair + 1], s));
+            ls.prof_used = pair + 1;
+        }
+    }
+    w->seq++;
+    w->last_stream = s;
+
+    if (host_io) {
+        SDH_HIP_CHECK(hipMemcpy2DAsync(y, (size_t) ldy * 4, dy, (size_t) w->n_out * 4, (size_t) w->n_out * 4,
+                                       (size_t) n_tokens, hipMemcpyDeviceToHost, s));
+        SDH_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    return SDH_OK;
+}
+
+int64_t sdh_nonfinite_count(sdh_weight * h) {
+    if (!h) { set_error("null weight"); return SDH_ERR_INVALID; }
+    DeviceWeight * w = reinterpret_cast<DeviceWeight *>(h);
+    if (w->seq == 0) return 0;
+    const int slot = (int) ((w->seq - 1) % DeviceWeight::NF_SLOTS);
+    int v = 0;
+    if (hipStreamSynchronize(w->last_stream) != hipSuccess ||
+        hipMemcpy(&v, w->nf_ring + slot, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) {
+        set_error("reading non-finite counter failed");
+        return SDH_ERR_HIP;
+    }
+    return v;
+}
+
+int sdh_profile_enable(int on) {
+    LibState & s = lib();
+    if (!s.inited) { set_error("sdh_init not called"); return SDH_ERR_NO_DEVICE; }
+    if (on && !s.prof_ev) {
+        s.prof_ev = new hipEvent_t[2 * LibState::PROF_PAIRS];
+        for (int i = 0; i < 2 * LibState::PROF_PAIRS; ++i) SDH_HIP_CHECK(hipEventCreate(&s.prof_ev[i]));
+    }
+    if (!on && s.prof_on) { int rc = prof_flush(s); if (rc != SDH_OK) return rc; }
+    s.prof_on = on != 0;
+    return SDH_OK;
+}
+
+int sdh_profile_read(double * total_ms, int64_t * launches) {
+    LibState & s = lib();
+    if (!s.inited) { set_error("sdh_init not called"); return SDH_ERR_NO_DEVICE; }
+    int rc = prof_flush(s);
+    if (rc != SDH_OK) return rc;
+    if (total_ms) *total_ms = s.prof_ms;
+    if (launches) *launches = s.prof_n;
+    s.prof_ms = 0.0;
+    s.prof_n = 0;
+    return SDH_OK;
+}
+
+int sdh_w0_tile(sdh_weight * h, int64_t o0, int64_t o1, int64_t i0, int64_t i1,
+                float * out, int flags, void * stream) {
+    if (!h || !out) { set_error("null argument"); return SDH_ERR_INVALID; }
+    DeviceWeight * w = reinterpret_cast<DeviceWeight *>(h);
+    if (!w->d1) { set_error("payload has no base"); return SDH_ERR_INVALID; }
+    if (!w->w0_closed_form) {
+        set_error("closed-form W0 needs depth 2, no perm2 and a bijective perm1");
+        return SDH_ERR_UNSUPPORTED;
+    }
+    if (o0 < 0 || o1 > w->n_out || i0 < 0 || i1 > w->n_in || o0 > o1 || i0 > i1) {
+        set_error("tile out of range");
+        return SDH_ERR_INVALID;
+    }
+    hipStream_t s = stream ? (hipStream_t) stream : lib().stream;
+    const size_t bytes = (size_t) (o1 - o0) * (size_t) (i1 - i0) * 4;
+    if (bytes == 0) return SDH_OK;
+    if (flags & SDH_FWD_HOST_IO) {
+        float * d = nullptr;
+        SDH_HIP_CHECK(hipMalloc((void **) &d, bytes));
+        int rc = launch_w0_tile(*w, o0, o1, i0, i1, d, s);
+        if (rc == SDH_OK) {
+            hipError_t e = hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) { set_error("w0 tile copy failed: %s", hipGetErrorString(e)); rc = SDH_ERR_HIP; }
+        }
+        (void) hipFree(d);
+        return rc;
+    }
+    return launch_w0_tile(*w, o0, o1, i0, i1, out, s);
+}
+
+} // extern "C"

@@ -1,0 +1,149 @@
+// sdh_base.hip — the SeedDelta base term on gfx950.
+//
+//   v_b = D3 * H * [D2 * [P2] * H] * P1 * D1 * x_b          (one length-L block b, one token)
+//
+// Follows apply_base_block of the reference (src/llama-seeddelta.cpp:497-574). H is the
+// unnormalised fast Walsh-Hadamard transform in the reference's stage order (len = 1,2,4,...,
+// butterfly (u+v, u-v), :484-493). A butterfly stage touches every element exactly once, so
+// running its L/2 butterflies in parallel yields the same fp32 bits as the sequential loop:
+// the base term computed here is bit-identical to the CPU op.
+//
+// Also: the closed-form dense W0 tile generator (integer XOR indexing into G_b = FWHT(d2_b)).
+#include "sdh_internal.h"
+
+namespace sdh {
+
+// One workgroup per (base block b, token t). LDS holds two L-float buffers (ping for the
+// transform, pong for the permutation gather).
+template <int THREADS>
+__global__ __launch_bounds__(THREADS)
+void base_apply_kernel(const float * __restrict__ x, int64_t ldx, int n_in, int L, int B, int tall,
+                       const float * __restrict__ d1, const float * __restrict__ d2,
+                       const float * __restrict__ d3, const int * __restrict__ p1,
+                       const int * __restrict__ p2, float * __restrict__ v) {
+    extern __shared__ float sm[];
+    float * y   = sm;
+    float * tmp = sm + L;
+    const int b = blockIdx.x;
+    const int64_t t = blockIdx.y;
+    const int tid = threadIdx.x;
+    const float * xt = x + t * ldx;
+    const int in0 = tall ? 0 : b * L;            // tall: x padded to L; wide: chunk b (:1091-1096, :1136-1145)
+    const int64_t pb = (int64_t) b * L;
+
+    // y = D1 * x
+    for (int i = tid; i < L; i += THREADS) {
+        const int src = in0 + i;
+        const float xv = (src < n_in) ? xt[src] : 0.0f;
+        y[i] = xv * d1[pb + i];
+    }
+    __syncthreads();
+
+    // y = P1 * y  (gather: tmp[i] = y[perm[i]]; out-of-range entries were mapped to 0 at upload)
+    if (p1) {
+        for (int i = tid; i < L; i += THREADS) tmp[i] = y[p1[pb + i]];
+        __syncthreads();
+        float * s = y; y = tmp; tmp = s;
+    }
+
+    auto fwht = [&](float * a) {
+        for (int len = 1; len < L; len <<= 1) {
+            for (int k = tid; k < (L >> 1); k += THREADS) {
+                const int i = ((k & ~(len - 1)) << 1) | (k & (len - 1));
+                const float u = a[i];
+                const float w = a[i + len];
+                a[i]       = u + w;
+                a[i + len] = u - w;
+            }
+            __syncthreads();
+        }
+    };
+
+    fwht(y);
+
+    float * out = v + ((size_t) t * B + b) * (size_t) L;
+    if (!d2 && !p2) {                            // depth 1 (:537-544)
+        for (int i = tid; i < L; i += THREADS) out[i] = d3 ? y[i] * d3[pb + i] : y[i];
+        return;
+    }
+    if (d2) {
+        for (int i = tid; i < L; i += THREADS) y[i] *= d2[pb + i];
+        __syncthreads();
+    }
+    if (p2) {
+        for (int i = tid; i < L; i += THREADS) tmp[i] = y[p2[pb + i]];
+        __syncthreads();
+        float * s = y; y = tmp; tmp = s;
+    }
+    fwht(y);
+    for (int i = tid; i < L; i += THREADS) out[i] = d3 ? y[i] * d3[pb + i] : y[i];
+}
+
+int launch_base_apply(const DeviceWeight & w, const float * x, int64_t ldx, int64_t T,
+                      float * v, hipStream_t s) {
+    const int L = (int) w.L;
+    const size_t lds = (size_t) 2 * L * sizeof(float);
+    if (lds > 160 * 1024) {
+        set_error("base block length L=%d needs %zu B of LDS (max 163840)", L, lds);
+        return SDH_ERR_UNSUPPORTED;
+    }
+    if (T <= 0) return SDH_OK;
+    dim3 grid((unsigned) w.B, (unsigned) T);
+    if (L >= 2048) {
+        constexpr int TH = 1024;
+        static bool attr_set = false;
+        if (!attr_set) {
+            SDH_HIP_CHECK(hipFuncSetAttribute((const void *) base_apply_kernel<TH>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(base_apply_kernel<TH>, grid, dim3(TH), lds, s, x, ldx, (int) w.n_in, L, (int) w.B,
+                           w.tall ? 1 : 0, w.d1, w.d2, w.d3, w.p1, w.p2, v);
+    } else {
+        constexpr int TH = 256;
+        hipLaunchKernelGGL(base_apply_kernel<TH>, grid, dim3(TH), lds, s, x, ldx, (int) w.n_in, L, (int) w.B,
+                           w.tall ? 1 : 0, w.d1, w.d2, w.d3, w.p1, w.p2, v);
+    }
+    SDH_HIP_CHECK(hipGetLastError());
+    return SDH_OK;
+}
+
+// ---- closed-form W0 tile ------------------------------------------------------------------------
+// tall: W0[o,i] = d3[p,b] * G_b[(p ^ inv_b[i]) & (L-1)] * d1[i,b],  b=o/L, p=o-bL
+// wide: W0[o,i] = d3[o,b] * G_b[(o ^ inv_b[q]) & (L-1)] * d1[q,b],  b=i/L, q=i-bL
+// Two separately rounded fp32 multiplies, (d3*G)*d1, so the tile is bit-identical to the oracle.
+__global__ void w0_tile_kernel(const float * __restrict__ d1, const float * __restrict__ d3,
+                               const float * __restrict__ G, const int * __restrict__ inv,
+                               int L, int tall, int64_t o0, int64_t o1, int64_t i0, int64_t i1,
+                               float * __restrict__ out) {
+#pragma clang fp contract(off)
+    const int64_t no = o1 - o0;
+    const int64_t n = no * (i1 - i0);
+    for (int64_t e = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; e < n;
+         e += (int64_t) gridDim.x * blockDim.x) {
+        const int64_t o = o0 + e % no;
+        const int64_t i = i0 + e / no;
+        int64_t b, p, q;
+        if (tall) { b = o / L; p = o - b * L; q = i; }
+        else      { b = i / L; q = i - b * L; p = o; }
+        const float g  = G[b * L + ((p ^ (int64_t) inv[b * L + q]) & (L - 1))];
+        const float s3 = d3 ? d3[b * L + p] : 1.0f;
+        const float tt = s3 * g;
+        out[e] = tt * d1[b * L + q];
+    }
+}
+
+int launch_w0_tile(const DeviceWeight & w, int64_t o0, int64_t o1, int64_t i0, int64_t i1,
+                   float * out_dev, hipStream_t s) {
+    const int64_t n = (o1 - o0) * (i1 - i0);
+    if (n <= 0) return SDH_OK;
+    const int threads = 256;
+    int64_t blocks = (n + threads - 1) / threads;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(w0_tile_kernel, dim3((unsigned) blocks), dim3(threads), 0, s,
+                       w.d1, w.d3, w.G, w.inv, (int) w.L, w.tall ? 1 : 0, o0, o1, i0, i1, out_dev);
+    SDH_HIP_CHECK(hipGetLastError());
+    return SDH_OK;
+}
+
+} // namespace sdh

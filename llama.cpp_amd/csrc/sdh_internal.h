@@ -1,0 +1,100 @@
+// sdh_internal.h — private declarations shared by the translation units of libseeddelta_hip.so.
+// gfx950 (MI355X) only. Nothing here crosses the C ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/seeddelta_hip.h"
+
+namespace sdh {
+
+// ---- error plumbing ----------------------------------------------------------------------
+void set_error(const char * fmt, ...);
+#define SDH_HIP_CHECK(expr)                                                                  \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            sdh::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return SDH_ERR_HIP;                                                              \
+        }                                                                                    \
+    } while (0)
+
+// ---- device-resident payload ---------------------------------------------------------------
+// All tensors are repacked contiguous at upload; element types of idx/val are kept as stored
+// in the GGUF (they are the HBM stream), small per-row / per-base-block vectors are widened
+// exactly (f16 -> f32, i16 -> i32, out-of-range perm entries -> 0 as the reference reads them).
+struct DeviceWeight {
+    int     device = 0;
+    int     kind = 0;            // sdh_op_kind
+    int64_t n_in = 0, n_out = 0;
+    // residual
+    int     idx_type = 0;        // SDH_TYPE_I16 / I32
+    int     val_type = 0;        // SDH_TYPE_F16 / F32
+    int64_t K = 0;               // COO: entries per row
+    int64_t nb = 0, block = 0;   // block scheme: blocks per row, block length
+    void *  idx = nullptr;       // [n_out][K] or [n_out][nb]
+    void *  val = nullptr;       // [n_out][K] or [n_out][nb][block]
+    float * rs = nullptr;        // [n_out] or null
+    // base
+    int64_t L = 0, B = 0;
+    int     logL = 0;
+    bool    tall = false;
+    float * d1 = nullptr;        // [B][L]
+    float * d2 = nullptr;        // [B][L] or null
+    float * d3 = nullptr;        // [B][L] or null
+    int *   p1 = nullptr;        // [B][L] or null
+    int *   p2 = nullptr;        // [B][L] or null
+    float * G = nullptr;         // [B][L]  FWHT(d2_b) in the reference butterfly order
+    int *   inv = nullptr;       // [B][L]  perm1_b^-1
+    bool    w0_closed_form = false;   // depth 2, no perm2, perm1 bijective
+    // accounting
+    int64_t payload_bytes = 0;   // as stored in the GGUF
+    // non-finite accounting: ring of per-call counters (no per-call memset on the hot path)
+    static constexpr int NF_SLOTS = 256;
+    int *    nf_ring = nullptr;  // device, NF_SLOTS ints
+    uint64_t seq = 0;            // forwards issued
+    hipStream_t last_stream = nullptr;
+    // workspace for the base term v[T_chunk][B][L]
+    float * ws = nullptr;
+    size_t  ws_bytes = 0;
+};
+
+struct LibState {
+    bool        inited = false;
+    int         device = -1;
+    hipStream_t stream = nullptr;
+    int         num_cu = 256;
+    // staging for host-IO forwards
+    float * hx = nullptr; size_t hx_bytes = 0;
+    float * hy = nullptr; size_t hy_bytes = 0;
+    // measurement hooks (sdh_profile_*): event pairs around the dominant kernel
+    bool   prof_on = false;
+    static constexpr int PROF_PAIRS = 4096;
+    hipEvent_t * prof_ev = nullptr;     // 2*PROF_PAIRS events, created on first enable
+    int     prof_used = 0;              // pairs recorded and not yet read
+    double  prof_ms = 0.0;              // accumulated from flushed pairs
+    int64_t prof_n = 0;
+};
+LibState & lib();
+
+// ---- kernel launchers (sdh_base.hip / sdh_delta.hip) -------------------------------------------
+// v[t][b][i] = (D3 H [D2 [P2] H] P1 D1 x_chunk)(i) for t in [0,T), b in [0,B)
+int launch_base_apply(const DeviceWeight & w, const float * x, int64_t ldx, int64_t T,
+                      float * v, hipStream_t s);
+
+struct DeltaLaunch {
+    const float * x; int64_t ldx; int64_t T;
+    float * y; int64_t ldy;
+    const float * v;        // base term scratch [T][B][L] or null
+    int * nf_counter;       // device counter for this call
+    bool zero_nonfinite;
+    bool exact_order;
+};
+int launch_delta(const DeviceWeight & w, const DeltaLaunch & a, hipStream_t s);
+
+int launch_w0_tile(const DeviceWeight & w, int64_t o0, int64_t o1, int64_t i0, int64_t i1,
+                   float * out_dev, hipStream_t s);
+
+} // namespace sdh

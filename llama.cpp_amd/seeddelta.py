@@ -1,0 +1,256 @@
+"""ctypes binding of libseeddelta_hip.so (include/seeddelta_hip.h) — the host-side mirror of the
+reference's SeedDelta operator interface.
+
+The reference exposes four graph-node constructors (``src/llama-seeddelta.h:41-84``):
+``llama_seeddelta_mul_mat``, ``_block``, ``_base``, ``_base_block``. The functions of the same name
+here take the same arguments (numpy arrays instead of ggml tensors) and run the op on the MI355X
+through the C ABI. ``SeedDeltaWeight`` is the upload-once handle (``struct llama_seeddelta_weight``,
+``src/llama-seeddelta.h:12-25``); ``SeedDeltaContext`` mirrors ``llama_seeddelta_context`` (:27-38):
+a map from a dense-weight key to its payload, with ``find`` / ``mul_mat`` dispatch as in
+``llm_graph_context::build_lora_mm`` (``src/llama-graph.cpp:679-715``).
+
+There is no CPU fallback: if the HIP library or a GPU is missing every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from .payload import Payload
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libseeddelta_hip.so")
+
+SDH_TYPE = {np.dtype(np.float32): 0, np.dtype(np.float16): 1, np.dtype(np.int16): 25, np.dtype(np.int32): 26}
+
+FWD_DEVICE_IO, FWD_HOST_IO, FWD_ZERO_NONFINITE, FWD_EXACT_ORDER, FWD_W0_MFMA = 0x0, 0x1, 0x2, 0x4, 0x8
+
+# every symbol include/seeddelta_hip.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "sdh_init", "sdh_abi_version", "sdh_last_error", "sdh_device_synchronize",
+    "sdh_weight_create", "sdh_weight_destroy", "sdh_weight_op_kind", "sdh_weight_payload_bytes",
+    "sdh_forward", "sdh_nonfinite_count", "sdh_w0_tile",
+    "sdh_profile_enable", "sdh_profile_read",
+]
+
+
+class SdhTensor(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("type", C.c_int32), ("n_dims", C.c_int32),
+                ("ne", C.c_int64 * 4), ("nb", C.c_int64 * 4)]
+
+
+class SdhWeightDesc(C.Structure):
+    _fields_ = [("n_in", C.c_int64), ("n_out", C.c_int64)] + [(n, SdhTensor) for n in (
+        "d_idx", "d_val", "b_idx", "b_val", "row_scale",
+        "base_d1", "base_d2", "base_d3", "base_perm1", "base_perm2")]
+
+
+class SeedDeltaError(RuntimeError):
+    pass
+
+
+def tensor_of(arr: Optional[np.ndarray]) -> SdhTensor:
+    """View a numpy array as a ggml-style tensor (ne[0] = fastest numpy axis)."""
+    t = SdhTensor()
+    if arr is None:
+        return t
+    if arr.dtype not in SDH_TYPE:
+        raise SeedDeltaError(f"unsupported dtype {arr.dtype}")
+    t.data = arr.ctypes.data
+    t.type = SDH_TYPE[arr.dtype]
+    shape, strides = arr.shape[::-1], arr.strides[::-1]
+    t.n_dims = len(shape)
+    ne, nb = [1, 1, 1, 1], [0, 0, 0, 0]
+    for i in range(len(shape)):
+        ne[i], nb[i] = shape[i], strides[i]
+    for i in range(len(shape), 4):
+        nb[i] = nb[i - 1] * ne[i - 1]
+    t.ne[:], t.nb[:] = ne, nb
+    return t
+
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH):
+    """dlopen the HIP library. Raises if it is not built — there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise SeedDeltaError(f"{path} not built: run `make -C llama.cpp_amd/csrc` (or __graft_entry__.build())")
+    lib = C.CDLL(path)
+    lib.sdh_init.argtypes = [C.c_int]
+    lib.sdh_abi_version.restype = C.c_int
+    lib.sdh_last_error.restype = C.c_char_p
+    lib.sdh_weight_create.argtypes = [C.POINTER(SdhWeightDesc), C.POINTER(C.c_void_p)]
+    lib.sdh_weight_destroy.argtypes = [C.c_void_p]
+    lib.sdh_weight_destroy.restype = None
+    lib.sdh_weight_op_kind.argtypes = [C.c_void_p]
+    lib.sdh_weight_payload_bytes.argtypes = [C.c_void_p]
+    lib.sdh_weight_payload_bytes.restype = C.c_int64
+    lib.sdh_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
+                                C.c_int, C.c_void_p]
+    lib.sdh_nonfinite_count.argtypes = [C.c_void_p]
+    lib.sdh_nonfinite_count.restype = C.c_int64
+    lib.sdh_w0_tile.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
+                                C.c_int, C.c_void_p]
+    lib.sdh_profile_enable.argtypes = [C.c_int]
+    lib.sdh_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = load_library().sdh_last_error().decode(errors="replace")
+        raise SeedDeltaError(f"{what} failed ({rc}): {msg}")
+
+
+_inited_device = None
+
+
+def init(device: int = 0):
+    global _inited_device
+    lib = load_library()
+    _check(lib.sdh_init(device), "sdh_init")
+    _inited_device = device
+
+
+def profile_enable(on: bool):
+    _check(load_library().sdh_profile_enable(1 if on else 0), "sdh_profile_enable")
+
+
+def profile_read():
+    """-> (total_ms, launches) of the dominant kernel since the last read (HIP events)."""
+    ms, n = C.c_double(0.0), C.c_int64(0)
+    _check(load_library().sdh_profile_read(C.byref(ms), C.byref(n)), "sdh_profile_read")
+    return ms.value, n.value
+
+
+class SeedDeltaWeight:
+    """Device-resident payload of one FFN weight (upload once, evaluate many times)."""
+
+    def __init__(self, payload: Payload):
+        if _inited_device is None:
+            init(0)
+        lib = load_library()
+        d = SdhWeightDesc()
+        d.n_in, d.n_out = payload.n_in, payload.n_out
+        # keep references so the host arrays outlive the create call
+        self._keep = payload
+        for name in ("d_idx", "d_val", "b_idx", "b_val", "row_scale",
+                     "base_d1", "base_d2", "base_d3", "base_perm1", "base_perm2"):
+            setattr(d, name, tensor_of(getattr(payload, name)))
+        h = C.c_void_p()
+        _check(lib.sdh_weight_create(C.byref(d), C.byref(h)), "sdh_weight_create")
+        self._h = h
+        self.n_in, self.n_out = payload.n_in, payload.n_out
+        self.kind = lib.sdh_weight_op_kind(h)
+        self.payload_bytes = lib.sdh_weight_payload_bytes(h)
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().sdh_weight_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- host buffers (what the ggml custom-op callback sees) ---------------------------------
+    def forward_host(self, x: np.ndarray, flags: int = 0) -> np.ndarray:
+        """x (T, n_in) float32 host -> y (T, n_out) float32 host."""
+        assert x.dtype == np.float32 and x.ndim == 2 and x.shape[1] == self.n_in
+        assert x.strides[1] == 4 and x.strides[0] % 4 == 0
+        T = x.shape[0]
+        y = np.empty((T, self.n_out), dtype=np.float32)
+        rc = load_library().sdh_forward(self._h, x.ctypes.data, x.strides[0] // 4, T,
+                                        y.ctypes.data, self.n_out, flags | FWD_HOST_IO, None)
+        _check(rc, "sdh_forward")
+        return y
+
+    # -- device buffers (raw pointers; torch is only the allocator) ---------------------------
+    def forward_device(self, x_ptr: int, ldx: int, T: int, y_ptr: int, ldy: int,
+                       flags: int = 0, stream: int = 0):
+        rc = load_library().sdh_forward(self._h, x_ptr, ldx, T, y_ptr, ldy, flags & ~FWD_HOST_IO,
+                                        C.c_void_p(stream) if stream else None)
+        _check(rc, "sdh_forward")
+
+    def nonfinite_count(self) -> int:
+        n = load_library().sdh_nonfinite_count(self._h)
+        if n < 0:
+            _check(int(n), "sdh_nonfinite_count")
+        return int(n)
+
+    def w0_tile(self, o0: int, o1: int, i0: int, i1: int) -> np.ndarray:
+        """Dense W0[o0:o1, i0:i1] regenerated on the device; returned as (o1-o0, i1-i0)."""
+        out = np.empty((i1 - i0, o1 - o0), dtype=np.float32)   # device layout: o fastest
+        rc = load_library().sdh_w0_tile(self._h, o0, o1, i0, i1, out.ctypes.data, FWD_HOST_IO, None)
+        _check(rc, "sdh_w0_tile")
+        return np.ascontiguousarray(out.T)
+
+
+# ---- the reference's four constructors, same argument order (src/llama-seeddelta.h:41-84) ----
+def llama_seeddelta_mul_mat(x, w_ref, d_idx, d_val, row_scale, flags: int = 0):
+    n_in, n_out = x.shape[1], d_idx.shape[0]
+    w = SeedDeltaWeight(Payload(n_in, n_out, d_idx=d_idx, d_val=d_val, row_scale=row_scale, w_ref=w_ref))
+    return w.forward_host(x, flags)
+
+
+def llama_seeddelta_mul_mat_block(x, w_ref, b_idx, b_val, row_scale, flags: int = 0):
+    n_in, n_out = x.shape[1], b_idx.shape[0]
+    w = SeedDeltaWeight(Payload(n_in, n_out, b_idx=b_idx, b_val=b_val, row_scale=row_scale, w_ref=w_ref))
+    return w.forward_host(x, flags)
+
+
+def llama_seeddelta_mul_mat_base(x, w_ref, base_d1, base_d2, base_d3, base_perm1, base_perm2,
+                                 d_idx, d_val, row_scale, flags: int = 0):
+    n_in, n_out = x.shape[1], d_idx.shape[0]
+    w = SeedDeltaWeight(Payload(n_in, n_out, d_idx=d_idx, d_val=d_val, row_scale=row_scale,
+                                base_d1=base_d1, base_d2=base_d2, base_d3=base_d3,
+                                base_perm1=base_perm1, base_perm2=base_perm2, w_ref=w_ref))
+    return w.forward_host(x, flags)
+
+
+def llama_seeddelta_mul_mat_base_block(x, w_ref, base_d1, base_d2, base_d3, base_perm1, base_perm2,
+                                       b_idx, b_val, row_scale, flags: int = 0):
+    n_in, n_out = x.shape[1], b_idx.shape[0]
+    w = SeedDeltaWeight(Payload(n_in, n_out, b_idx=b_idx, b_val=b_val, row_scale=row_scale,
+                                base_d1=base_d1, base_d2=base_d2, base_d3=base_d3,
+                                base_perm1=base_perm1, base_perm2=base_perm2, w_ref=w_ref))
+    return w.forward_host(x, flags)
+
+
+class SeedDeltaContext:
+    """Mirror of ``llama_seeddelta_context`` (src/llama-seeddelta.h:27-38): dense-weight key ->
+    device payload, filled with the acceptance rules of ``try_add_seeddelta``
+    (src/llama-context.cpp:145-286; enforced inside sdh_weight_create)."""
+
+    def __init__(self, enabled: bool = True, gap_tol: float = 0.02):
+        self.enabled = enabled
+        self.gap_tol = gap_tol          # stored and never read, as in the reference
+        self.weights: dict = {}
+
+    def try_add(self, key, payload: Payload) -> bool:
+        try:
+            self.weights[key] = SeedDeltaWeight(payload)
+            return True
+        except SeedDeltaError:
+            return False               # reference: LLAMA_LOG_WARN + keep the dense path
+
+    def find(self, key) -> Optional[SeedDeltaWeight]:
+        return self.weights.get(key)
+
+    def mul_mat(self, key, x: np.ndarray) -> Optional[np.ndarray]:
+        """build_lora_mm's SeedDelta branch: None means 'use the dense matmul'."""
+        if not self.enabled:
+            return None
+        w = self.find(key)
+        return None if w is None else w.forward_host(x)

@@ -97,6 +97,16 @@ static inline int32_t rd_i(const sdo_tensor * t, const uint8_t * base, int64_t i
 
 static inline int present(const sdo_tensor * t) { return t && t->data != NULL; }
 
+/* ggml_n_dims (ggml/src/ggml.c): trailing dimensions of extent 1 do not count, so a single-token
+ * x [n_in, 1] is 1-D. The reference's dense fallback therefore refuses to run at T = 1 and the
+ * NaN guard writes 0.0 there (src/llama-seeddelta.cpp:323-325) — restated as is. */
+static inline int ggml_like_n_dims(const sdo_tensor * t) {
+    for (int i = 3; i >= 1; --i) {
+        if (t->ne[i] > 1) return i + 1;
+    }
+    return 1;
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* NaN guard + dense fallback (:294-392)                                                  */
 /* ------------------------------------------------------------------------------------ */
@@ -126,7 +136,7 @@ void sdo_dequant_row_q8_0(const void * row, float * y, int64_t k) {
 
 /* one row of the dense weight as fp32 (llama_seeddelta_read_weight_col_f32, :234-292) */
 static int read_weight_row(const sdo_tensor * w, int64_t col, float * out) {
-    if (!present(w) || w->n_dims != 2) return 0;
+    if (!present(w) || ggml_like_n_dims(w) != 2) return 0;
     const int64_t n_in = w->ne[0], n_out = w->ne[1];
     if (n_in <= 0 || col < 0 || col >= n_out) return 0;
     const uint8_t * base = (const uint8_t *) w->data + col * w->nb[1];
@@ -152,7 +162,7 @@ static int read_weight_row(const sdo_tensor * w, int64_t col, float * out) {
 /* llama_seeddelta_dense_fallback (:294-361): y = sum_i w[i,o]*x[i,t] accumulated in double */
 static int dense_fallback(const sdo_tensor * w, const sdo_tensor * x, int64_t o, int64_t t, float * y_out) {
     if (!present(w) || !present(x)) return 0;
-    if (x->n_dims < 2 || w->n_dims != 2) return 0;
+    if (ggml_like_n_dims(x) < 2 || ggml_like_n_dims(w) != 2) return 0;
     const int64_t n_in = x->ne[0];
     if (w->ne[0] != n_in) return 0;
     if (o < 0 || o >= w->ne[1]) return 0;

@@ -1,0 +1,84 @@
+"""CPU checks of the drop-in boundary: the library loads without a GPU and exports every symbol
+include/seeddelta_hip.h declares; struct layouts match the header; host-side dispatch logic."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from llama_cpp_amd import seeddelta
+from llama_cpp_amd.payload import (OP_BASE_BLOCK, OP_BASE_COO, OP_BLOCK, OP_COO, base_dims, config_payload,
+                                   make_payload)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "seeddelta_hip.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sdh_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_what_python_binds():
+    assert declared_symbols() == sorted(seeddelta.ABI_SYMBOLS)
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    assert os.path.exists(seeddelta.LIB_PATH), "libseeddelta_hip.so not built (run __graft_entry__.build())"
+    lib = C.CDLL(seeddelta.LIB_PATH)
+    for sym in declared_symbols():
+        assert hasattr(lib, sym), f"{sym} declared in include/seeddelta_hip.h but not exported"
+    lib.sdh_abi_version.restype = C.c_int
+    assert lib.sdh_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    # sdh_tensor: void*, int32, int32, int64[4], int64[4]
+    assert C.sizeof(seeddelta.SdhTensor) == 8 + 4 + 4 + 32 + 32
+    assert C.sizeof(seeddelta.SdhWeightDesc) == 16 + 10 * C.sizeof(seeddelta.SdhTensor)
+
+
+def test_tensor_view_follows_ggml_axis_order():
+    a = np.zeros((5, 3, 16), dtype=np.float16)        # ggml [16, 3, 5]
+    t = seeddelta.tensor_of(a)
+    assert list(t.ne) == [16, 3, 5, 1] and list(t.nb)[:3] == [2, 32, 96] and t.type == 1 and t.n_dims == 3
+    assert seeddelta.tensor_of(None).data is None
+
+
+def test_dispatch_priority_matches_build_lora_mm():
+    # src/llama-graph.cpp:681-703: block wins over COO, base iff base_d1
+    p = make_payload(64, 128, scheme="coo", K=8)
+    assert p.kind == OP_COO
+    q = make_payload(64, 128, scheme="block", K=16, block=16, base=True)
+    assert q.kind == OP_BASE_BLOCK
+    q.d_idx, q.d_val = p.d_idx, p.d_val
+    assert q.kind == OP_BASE_BLOCK
+    q.b_idx = None
+    assert q.kind == OP_BASE_COO
+    q.base_d1 = None
+    assert q.kind == OP_COO
+    assert make_payload(64, 128, scheme="block", K=16).kind == OP_BLOCK
+
+
+def test_base_dims_and_algorithmic_bytes_of_named_configs():
+    assert base_dims(14336, 4096) == (4096, 4)      # Mistral-7B
+    assert base_dims(2560, 10240) == (4096, 3)      # Gemma-3 4B
+    assert base_dims(1152, 6912) == (2048, 4)       # Gemma-3 1B
+    # cfg3 = 13,189,120 B per token per tensor
+    p = config_payload("cfg3_mistral_down_block32_k1536")
+    assert p.algorithmic_bytes(1) == 13_189_120
+    # cfg2 Gemma-4B gate COO K=128 + base: 5,412,864 B/token
+    assert config_payload("cfg2_gemma4b_gate_coo_k128").algorithmic_bytes(1) == 5_412_864
+
+
+def test_no_silent_fallback_without_gpu():
+    """Without a GPU the product path must fail loudly, not fall back to a CPU computation."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(seeddelta.SeedDeltaError):
+        seeddelta.init(0)
+    with pytest.raises(seeddelta.SeedDeltaError):
+        seeddelta.SeedDeltaWeight(make_payload(64, 64))
