@@ -132,6 +132,7 @@ static void free_weight(DeviceWeight * w) {
     if (!w) return;
     (void) hipFree(w->idx); (void) hipFree(w->val); (void) hipFree(w->rs);
     (void) hipFree(w->d1); (void) hipFree(w->d2); (void) hipFree(w->d3); (void) hipFree(w->p1); (void) hipFree(w->p2);
+    (void) hipFree(w->pack_dev);
     (void) hipFree(w->G); (void) hipFree(w->inv); (void) hipFree(w->nf_ring); (void) hipFree(w->ws);
     delete w;
 }
@@ -340,6 +341,59 @@ int sdh_weight_create(const sdh_weight_desc * desc, sdh_weight ** out) {
         w->w0_closed_form = bijective && present(d2) && !present(p2);
         if ((rc = upload(G, &w->G)) != SDH_OK) return fail(rc);
         if ((rc = upload(inv, &w->inv)) != SDH_OK) return fail(rc);
+
+        // packed hot-path slab: per base block [perm1][d2][d1][d3][perm2], 16-bit when the GGUF
+        // stores F16 / I16 (what the builder writes), else widened to 32-bit. d1 / d3 that are all
+        // ones (what the builder writes) are elided.
+        auto all_ones = [](const std::vector<float> & v) {
+            for (float f : v) if (f != 1.0f) return false;
+            return true;
+        };
+        const bool keep_d1 = !all_ones(h1);
+        const bool keep_d3 = present(d3) && !all_ones(h3);
+        bool narrow = L <= 32768 && (!keep_d1 || d1.type == SDH_TYPE_F16) &&
+                      (!present(d2) || d2.type == SDH_TYPE_F16) && (!keep_d3 || d3.type == SDH_TYPE_F16) &&
+                      (!present(p1) || p1.type == SDH_TYPE_I16) && (!present(p2) || p2.type == SDH_TYPE_I16);
+        const size_t es = narrow ? 2 : 4;
+        BasePackDesc & pd = w->pack;
+        pd.wide32 = narrow ? 0 : 1;
+        int off = 0;
+        auto region = [&](bool on) { int o = -1; if (on) { o = off; off += (int) (((size_t) L * es + 15) / 16 * 16); } return o; };
+        pd.off_p1 = region(present(p1));
+        pd.off_d2 = region(present(d2));
+        pd.off_d1 = region(keep_d1);
+        pd.off_d3 = region(keep_d3);
+        pd.off_p2 = region(present(p2));
+        pd.blk_stride = off;
+        if (off > 0) {
+            std::vector<uint8_t> slab((size_t) off * (size_t) B, 0);
+            auto put_f = [&](int o, const sdh_tensor & src, const std::vector<float> & f32) {
+                if (o < 0) return;
+                for (int64_t b = 0; b < B; ++b) {
+                    uint8_t * dst = slab.data() + (size_t) b * off + o;
+                    if (narrow) { for (int64_t i = 0; i < L; ++i) memcpy(dst + 2 * i, elem_ptr(src, i, b, 0), 2); }
+                    else        { memcpy(dst, f32.data() + b * L, (size_t) L * 4); }
+                }
+            };
+            auto put_i = [&](int o, const std::vector<int32_t> & i32) {     // already clamped to [0, L)
+                if (o < 0) return;
+                for (int64_t b = 0; b < B; ++b) {
+                    uint8_t * dst = slab.data() + (size_t) b * off + o;
+                    for (int64_t i = 0; i < L; ++i) {
+                        const int32_t v = i32[(size_t) (b * L + i)];
+                        if (narrow) { const uint16_t u = (uint16_t) v; memcpy(dst + 2 * i, &u, 2); }
+                        else memcpy(dst + 4 * i, &v, 4);
+                    }
+                }
+            };
+            put_i(pd.off_p1, hp1);
+            put_f(pd.off_d2, d2, h2);
+            put_f(pd.off_d1, d1, h1);
+            put_f(pd.off_d3, d3, h3);
+            put_i(pd.off_p2, hp2);
+            if ((rc = upload(slab, &w->pack_dev)) != SDH_OK) return fail(rc);
+            pd.pack = w->pack_dev;
+        }
     }
     {
         hipError_t e = hipMalloc((void **) &w->nf_ring, DeviceWeight::NF_SLOTS * sizeof(int));

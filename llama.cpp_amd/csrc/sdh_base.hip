@@ -1,26 +1,37 @@
-// sdh_base.hip — the SeedDelta base term on gfx950.
+// sdh_base.hip — the SeedDelta base term on gfx950: stand-alone kernels (prefill / generic path).
 //
 //   v_b = D3 * H * [D2 * [P2] * H] * P1 * D1 * x_b          (one length-L block b, one token)
 //
 // Follows apply_base_block of the reference (src/llama-seeddelta.cpp:497-574). H is the
 // unnormalised fast Walsh-Hadamard transform in the reference's stage order (len = 1,2,4,...,
 // butterfly (u+v, u-v), :484-493). A butterfly stage touches every element exactly once, so
-// running its L/2 butterflies in parallel yields the same fp32 bits as the sequential loop:
-// the base term computed here is bit-identical to the CPU op.
+// running its L/2 butterflies in parallel yields the same fp32 bits as the sequential loop as
+// long as the STAGE ORDER is kept: the base term computed here is bit-identical to the CPU op.
+//
+//   base_apply_kernel<LOG_E, P32>   L = 256 * 2^LOG_E in {1024, 2048, 4096, 8192}: the register /
+//                                   LDS-transpose transform of sdh_base_dev.h, parameters read from
+//                                   the packed 16-bit slab (one contiguous region per block).
+//   base_apply_lds_kernel           any other power-of-two L that fits LDS; one barrier per stage.
 //
 // Also: the closed-form dense W0 tile generator (integer XOR indexing into G_b = FWHT(d2_b)).
 #include "sdh_internal.h"
+#include "sdh_base_dev.h"
+
+// Every multiply and add in this file must round separately (the reference TU is built without FMA
+// contraction): a fused x*d1 + ... in the first butterfly stage would change the bits.
+#pragma clang fp contract(off)
 
 namespace sdh {
 
-// One workgroup per (base block b, token t). LDS holds two L-float buffers (ping for the
-// transform, pong for the permutation gather).
+// ---------------------------------------------------------------------------------------------
+// generic LDS kernel (small or unusual L)
+// ---------------------------------------------------------------------------------------------
 template <int THREADS>
 __global__ __launch_bounds__(THREADS)
-void base_apply_kernel(const float * __restrict__ x, int64_t ldx, int n_in, int L, int B, int tall,
-                       const float * __restrict__ d1, const float * __restrict__ d2,
-                       const float * __restrict__ d3, const int * __restrict__ p1,
-                       const int * __restrict__ p2, float * __restrict__ v) {
+void base_apply_lds_kernel(const float * __restrict__ x, int64_t ldx, int n_in, int L, int B, int tall,
+                           const float * __restrict__ d1, const float * __restrict__ d2,
+                           const float * __restrict__ d3, const int * __restrict__ p1,
+                           const int * __restrict__ p2, float * __restrict__ v) {
     extern __shared__ float sm[];
     float * y   = sm;
     float * tmp = sm + L;
@@ -31,21 +42,17 @@ void base_apply_kernel(const float * __restrict__ x, int64_t ldx, int n_in, int 
     const int in0 = tall ? 0 : b * L;            // tall: x padded to L; wide: chunk b (:1091-1096, :1136-1145)
     const int64_t pb = (int64_t) b * L;
 
-    // y = D1 * x
-    for (int i = tid; i < L; i += THREADS) {
+    for (int i = tid; i < L; i += THREADS) {     // y = D1 * x
         const int src = in0 + i;
         const float xv = (src < n_in) ? xt[src] : 0.0f;
         y[i] = xv * d1[pb + i];
     }
     __syncthreads();
-
-    // y = P1 * y  (gather: tmp[i] = y[perm[i]]; out-of-range entries were mapped to 0 at upload)
-    if (p1) {
+    if (p1) {                                    // y = P1 * y (gather; out-of-range mapped to 0 at upload)
         for (int i = tid; i < L; i += THREADS) tmp[i] = y[p1[pb + i]];
         __syncthreads();
         float * s = y; y = tmp; tmp = s;
     }
-
     auto fwht = [&](float * a) {
         for (int len = 1; len < L; len <<= 1) {
             for (int k = tid; k < (L >> 1); k += THREADS) {
@@ -58,9 +65,7 @@ void base_apply_kernel(const float * __restrict__ x, int64_t ldx, int n_in, int 
             __syncthreads();
         }
     };
-
     fwht(y);
-
     float * out = v + ((size_t) t * B + b) * (size_t) L;
     if (!d2 && !p2) {                            // depth 1 (:537-544)
         for (int i = tid; i < L; i += THREADS) out[i] = d3 ? y[i] * d3[pb + i] : y[i];
@@ -79,30 +84,70 @@ void base_apply_kernel(const float * __restrict__ x, int64_t ldx, int n_in, int 
     for (int i = tid; i < L; i += THREADS) out[i] = d3 ? y[i] * d3[pb + i] : y[i];
 }
 
+// ---------------------------------------------------------------------------------------------
+// register / LDS-transpose kernel: one workgroup per (base block, token)
+// ---------------------------------------------------------------------------------------------
+template <int LOG_E, bool P32>
+__global__ __launch_bounds__(256)
+void base_apply_kernel(const float * __restrict__ x, int64_t ldx, int n_in, int B, int tall, int x_vec_ok,
+                       const BasePackDesc pd, float * __restrict__ v) {
+    constexpr int L = BaseLay<LOG_E>::L;
+    __shared__ __align__(16) float lds[2 * L];
+    const int b = blockIdx.x;
+    const int64_t t = blockIdx.y;
+    SDH_STAMP(0);
+    float * out = v + ((size_t) t * B + b) * (size_t) L;
+    base_transform<LOG_E, P32>(x + t * ldx, n_in, tall ? 0 : b * L, x_vec_ok != 0, pd, b, lds, threadIdx.x,
+                               [&](int i, float val) { out[i] = val; });
+    SDH_STAMP(9);
+}
+
+template <int LOG_E>
+static void launch_reg(const DeviceWeight & w, const float * x, int64_t ldx, int64_t T, float * v, hipStream_t s) {
+    dim3 grid((unsigned) w.B, (unsigned) T);
+    const int x_vec_ok = (((uintptr_t) x % 16) == 0 && (ldx % 4) == 0) ? 1 : 0;
+    if (w.pack.wide32) {
+        hipLaunchKernelGGL((base_apply_kernel<LOG_E, true>), grid, dim3(256), 0, s,
+                           x, ldx, (int) w.n_in, (int) w.B, w.tall ? 1 : 0, x_vec_ok, w.pack, v);
+    } else {
+        hipLaunchKernelGGL((base_apply_kernel<LOG_E, false>), grid, dim3(256), 0, s,
+                           x, ldx, (int) w.n_in, (int) w.B, w.tall ? 1 : 0, x_vec_ok, w.pack, v);
+    }
+}
+
 int launch_base_apply(const DeviceWeight & w, const float * x, int64_t ldx, int64_t T,
                       float * v, hipStream_t s) {
     const int L = (int) w.L;
-    const size_t lds = (size_t) 2 * L * sizeof(float);
-    if (lds > 160 * 1024) {
-        set_error("base block length L=%d needs %zu B of LDS (max 163840)", L, lds);
-        return SDH_ERR_UNSUPPORTED;
-    }
     if (T <= 0) return SDH_OK;
-    dim3 grid((unsigned) w.B, (unsigned) T);
-    if (L >= 2048) {
-        constexpr int TH = 1024;
-        static bool attr_set = false;
-        if (!attr_set) {
-            SDH_HIP_CHECK(hipFuncSetAttribute((const void *) base_apply_kernel<TH>,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
+    if (T > 65535) { set_error("base: token chunk %lld exceeds grid limit", (long long) T); return SDH_ERR_UNSUPPORTED; }
+    switch (L) {
+        case 1024: launch_reg<2>(w, x, ldx, T, v, s); break;
+        case 2048: launch_reg<3>(w, x, ldx, T, v, s); break;
+        case 4096: launch_reg<4>(w, x, ldx, T, v, s); break;
+        case 8192: launch_reg<5>(w, x, ldx, T, v, s); break;
+        default: {
+            const size_t lds = (size_t) 2 * L * sizeof(float);
+            if (lds > 160 * 1024) {
+                set_error("base block length L=%d needs %zu B of LDS (max 163840)", L, lds);
+                return SDH_ERR_UNSUPPORTED;
+            }
+            dim3 grid((unsigned) w.B, (unsigned) T);
+            if (L >= 2048) {
+                constexpr int TH = 1024;
+                static bool attr_set = false;
+                if (!attr_set) {
+                    SDH_HIP_CHECK(hipFuncSetAttribute((const void *) base_apply_lds_kernel<TH>,
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    attr_set = true;
+                }
+                hipLaunchKernelGGL(base_apply_lds_kernel<TH>, grid, dim3(TH), lds, s, x, ldx, (int) w.n_in, L,
+                                   (int) w.B, w.tall ? 1 : 0, w.d1, w.d2, w.d3, w.p1, w.p2, v);
+            } else {
+                constexpr int TH = 256;
+                hipLaunchKernelGGL(base_apply_lds_kernel<TH>, grid, dim3(TH), lds, s, x, ldx, (int) w.n_in, L,
+                                   (int) w.B, w.tall ? 1 : 0, w.d1, w.d2, w.d3, w.p1, w.p2, v);
+            }
         }
-        hipLaunchKernelGGL(base_apply_kernel<TH>, grid, dim3(TH), lds, s, x, ldx, (int) w.n_in, L, (int) w.B,
-                           w.tall ? 1 : 0, w.d1, w.d2, w.d3, w.p1, w.p2, v);
-    } else {
-        constexpr int TH = 256;
-        hipLaunchKernelGGL(base_apply_kernel<TH>, grid, dim3(TH), lds, s, x, ldx, (int) w.n_in, L, (int) w.B,
-                           w.tall ? 1 : 0, w.d1, w.d2, w.d3, w.p1, w.p2, v);
     }
     SDH_HIP_CHECK(hipGetLastError());
     return SDH_OK;
@@ -116,7 +161,6 @@ __global__ void w0_tile_kernel(const float * __restrict__ d1, const float * __re
                                const float * __restrict__ G, const int * __restrict__ inv,
                                int L, int tall, int64_t o0, int64_t o1, int64_t i0, int64_t i1,
                                float * __restrict__ out) {
-#pragma clang fp contract(off)
     const int64_t no = o1 - o0;
     const int64_t n = no * (i1 - i0);
     for (int64_t e = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; e < n;

@@ -1,0 +1,219 @@
+// sdh_base_dev.h — device code of the SeedDelta base transform, shared by the stand-alone base
+// kernel (sdh_base.hip) and the fused decode kernel (sdh_decode.hip).
+//
+//   v_b = D3 * H * [D2 * [P2] * H] * P1 * D1 * x_b      (reference: src/llama-seeddelta.cpp:497-574)
+//
+// One workgroup of 256 threads transforms one block of L = 256 * E elements (E = 2^LOG_E per
+// thread). The FWHT runs entirely in registers: the index bits are processed LOG_E at a time, and
+// between groups the block is transposed through LDS into the layout that makes the next LOG_E
+// bits register-resident. The STAGE ORDER is the reference's (bit 0 first), every butterfly is
+// (u+v, u-v) with u the element whose bit is clear, and multiplies / adds are never contracted,
+// so the result is bit-identical to the CPU op.
+//
+// Layout j: the register index r supplies index bits [s_j, s_j + LOG_E), s_j = min(j*LOG_E, N-LOG_E);
+// the thread id supplies the other N - LOG_E = 8 bits (low part below s_j, high part above).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "sdh_internal.h"      // BasePackDesc
+
+// Diagnostic stamps (tools/base_diag.hip builds with SDH_DIAG_STAMPS; the product build compiles
+// them away). Thread 0 of each workgroup records the 100 MHz real-time counter.
+#ifdef SDH_DIAG_STAMPS
+__device__ unsigned long long * sdh_diag_buf;
+#define SDH_STAMP(k)                                                                              \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        if (threadIdx.x == 0)                                                                     \
+            sdh_diag_buf[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+    } while (0)
+#else
+#define SDH_STAMP(k) do { } while (0)
+#endif
+
+namespace sdh {
+
+template <int LOG_E>
+struct BaseLay {
+    static constexpr int E  = 1 << LOG_E;
+    static constexpr int TB = 8;                     // thread-id bits (256 threads)
+    static constexpr int N  = LOG_E + TB;
+    static constexpr int L  = 1 << N;
+    static constexpr int J  = (N + LOG_E - 1) / LOG_E;
+    static constexpr int THREADS = 256;
+    static __host__ __device__ constexpr int shift(int j) { return (j * LOG_E <= N - LOG_E) ? j * LOG_E : N - LOG_E; }
+    static __device__ __forceinline__ int idx(int j, int tid, int r) {
+        const int s = shift(j);
+        return (tid & ((1 << s) - 1)) | (r << s) | ((tid >> s) << (s + LOG_E));
+    }
+};
+
+template <int LOG_E, int JJ>
+__device__ __forceinline__ void base_stages(float (&y)[1 << LOG_E]) {
+#pragma clang fp contract(off)
+    using Ly = BaseLay<LOG_E>;
+    constexpr int E = Ly::E;
+    constexpr int b0 = JJ * LOG_E;
+    constexpr int b1 = (b0 + LOG_E < Ly::N) ? b0 + LOG_E : Ly::N;
+#pragma unroll
+    for (int bit = b0; bit < b1; ++bit) {
+        const int rb = 1 << (bit - Ly::shift(JJ));
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            if ((r & rb) == 0) {
+                const float u = y[r], w = y[r | rb];
+                y[r] = u + w;
+                y[r | rb] = u - w;
+            }
+        }
+    }
+}
+
+template <int LOG_E, int JJ>
+__device__ __forceinline__ void base_lds_write(float * lds, const float (&y)[1 << LOG_E], int tid) {
+    using Ly = BaseLay<LOG_E>;
+    constexpr int E = Ly::E;
+    if constexpr (Ly::shift(JJ) == 0 && E >= 4) {
+#pragma unroll
+        for (int k = 0; k < E; k += 4)
+            *reinterpret_cast<float4 *>(lds + E * tid + k) = make_float4(y[k], y[k + 1], y[k + 2], y[k + 3]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < E; ++r) lds[Ly::idx(JJ, tid, r)] = y[r];
+    }
+}
+
+template <int LOG_E, int JJ>
+__device__ __forceinline__ void base_lds_read(float (&y)[1 << LOG_E], const float * lds, int tid) {
+    using Ly = BaseLay<LOG_E>;
+    constexpr int E = Ly::E;
+    if constexpr (Ly::shift(JJ) == 0 && E >= 4) {
+#pragma unroll
+        for (int k = 0; k < E; k += 4) {
+            const float4 q = *reinterpret_cast<const float4 *>(lds + E * tid + k);
+            y[k] = q.x; y[k + 1] = q.y; y[k + 2] = q.z; y[k + 3] = q.w;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < E; ++r) y[r] = lds[Ly::idx(JJ, tid, r)];
+    }
+}
+
+// Full FWHT of the block held in layout 0; leaves it in layout J-1. The transposes alternate
+// between the two LDS buffers, transition JJ using lds0 when (JJ + PAR) is odd, so that a buffer
+// is never rewritten before a barrier has separated it from its last readers.
+template <int LOG_E, int PAR, int JJ = 0>
+__device__ __forceinline__ void base_fwht(float (&y)[1 << LOG_E], float * lds0, float * lds1, int tid) {
+    using Ly = BaseLay<LOG_E>;
+    base_stages<LOG_E, JJ>(y);
+    if constexpr (JJ + 1 < Ly::J) {
+        float * buf = ((JJ + PAR) & 1) ? lds0 : lds1;
+        base_lds_write<LOG_E, JJ>(buf, y, tid);
+        __syncthreads();
+        base_lds_read<LOG_E, JJ + 1>(y, buf, tid);
+        base_fwht<LOG_E, PAR, JJ + 1>(y, lds0, lds1, tid);
+    }
+}
+
+template <bool P32>
+__device__ __forceinline__ float base_param_f(const uint8_t * p, int i) {
+    if constexpr (P32) return reinterpret_cast<const float *>(p)[i];
+    else return __half2float(__ushort_as_half(reinterpret_cast<const uint16_t *>(p)[i]));
+}
+template <bool P32>
+__device__ __forceinline__ int base_param_i(const uint8_t * p, int i) {
+    if constexpr (P32) return reinterpret_cast<const int *>(p)[i];
+    else return (int) reinterpret_cast<const uint16_t *>(p)[i];      // perms are clamped to [0,L) at upload
+}
+
+// Transform one block. xt: the token's activation column; in0: first input element of the block
+// (0 for tall weights); the block reads x[in0 .. in0+L) zero-padded past n_in. lds: 2*L floats.
+// emit(i, value) receives every output element (i in [0,L)), coalesced across the workgroup.
+template <int LOG_E, bool P32, typename Emit>
+__device__ __forceinline__ void base_transform(const float * __restrict__ xt, int n_in, int in0, bool x_vec_ok,
+                                               const BasePackDesc & pd, int b, float * lds, int tid, Emit && emit) {
+#pragma clang fp contract(off)
+    using Ly = BaseLay<LOG_E>;
+    constexpr int E = Ly::E, L = Ly::L, JL = Ly::J - 1;
+    float * lds0 = lds;
+    float * lds1 = lds + L;
+    const uint8_t * pk = pd.pack + (size_t) b * pd.blk_stride;
+    const bool has_p1 = pd.off_p1 >= 0, has_d2 = pd.off_d2 >= 0, has_d1 = pd.off_d1 >= 0,
+               has_d3 = pd.off_d3 >= 0, has_p2 = pd.off_p2 >= 0;
+
+    // ---- every global load is issued before the first use -------------------------------------
+    float y[E], s2[E], s3[E];
+    int g1[E];
+    const int src0 = in0 + E * tid;
+    if (x_vec_ok && src0 + E <= n_in) {
+#pragma unroll
+        for (int k = 0; k < E; k += 4) {
+            const float4 q = *reinterpret_cast<const float4 *>(xt + src0 + k);
+            y[k] = q.x; y[k + 1] = q.y; y[k + 2] = q.z; y[k + 3] = q.w;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < E; ++r) y[r] = (src0 + r < n_in) ? xt[src0 + r] : 0.0f;
+    }
+    if (has_p1) {
+#pragma unroll
+        for (int r = 0; r < E; ++r) g1[r] = base_param_i<P32>(pk + pd.off_p1, E * tid + r);
+    }
+    if (has_d2) {
+#pragma unroll
+        for (int r = 0; r < E; ++r) s2[r] = base_param_f<P32>(pk + pd.off_d2, Ly::idx(JL, tid, r));
+    }
+    if (has_d3) {
+#pragma unroll
+        for (int r = 0; r < E; ++r) s3[r] = base_param_f<P32>(pk + pd.off_d3, Ly::idx(JL, tid, r));
+    }
+    if (has_d1) {                                            // elided when all ones (x * 1.0f == x exactly)
+#pragma unroll
+        for (int r = 0; r < E; ++r) y[r] = y[r] * base_param_f<P32>(pk + pd.off_d1, E * tid + r);
+    }
+    SDH_STAMP(1);
+    // ---- P1 (gather) ----------------------------------------------------------------------------
+    if (has_p1) {
+        base_lds_write<LOG_E, 0>(lds0, y, tid);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < E; ++r) y[r] = lds0[g1[r]];
+    }
+    SDH_STAMP(2);
+    // ---- H ----------------------------------------------------------------------------------------
+    base_fwht<LOG_E, 0>(y, lds0, lds1, tid);                 // y now in layout JL
+    SDH_STAMP(3);
+    if (!has_d2 && !has_p2) {                                // depth 1 (:537-544)
+#pragma unroll
+        for (int r = 0; r < E; ++r) emit(Ly::idx(JL, tid, r), has_d3 ? y[r] * s3[r] : y[r]);
+        return;
+    }
+    if (has_d2) {
+#pragma unroll
+        for (int r = 0; r < E; ++r) y[r] = y[r] * s2[r];
+    }
+    // ---- back to layout 0, through the optional second permutation ------------------------------
+    // The first FWHT's last transpose used lds0 when J is odd, lds1 when J is even; the other
+    // buffer's readers are already behind a barrier, so it takes the way back. The second FWHT
+    // then starts on the buffer that is not being read here (PAR = J & 1).
+    float * back = (Ly::J & 1) ? lds1 : lds0;
+    base_lds_write<LOG_E, JL>(back, y, tid);
+    __syncthreads();
+    if (has_p2) {
+#pragma unroll
+        for (int r = 0; r < E; ++r) y[r] = back[base_param_i<P32>(pk + pd.off_p2, E * tid + r)];
+    } else {
+        base_lds_read<LOG_E, 0>(y, back, tid);
+    }
+    SDH_STAMP(4);
+    base_fwht<LOG_E, (Ly::J & 1)>(y, lds0, lds1, tid);
+    SDH_STAMP(5);
+#pragma unroll
+    for (int r = 0; r < E; ++r) emit(Ly::idx(JL, tid, r), has_d3 ? y[r] * s3[r] : y[r]);
+}
+
+} // namespace sdh

@@ -41,6 +41,8 @@ struct DeltaParams {
     int G;                  // lanes per row
     int zero_nf;
     int x_vec_ok;           // x columns are 16-byte aligned
+    int block_shift;        // log2(block) if a power of two, else -1
+    int n_blk_in;           // ceil(n_in / block): block ids below this start inside x
 };
 
 __device__ __forceinline__ float h2f(uint16_t h) {
@@ -98,17 +100,23 @@ __device__ __forceinline__ void finish(const DeltaParams & p, int o, int64_t t, 
     p.y[o + t * p.ldy] = out;
 }
 
-constexpr int UNROLL = 4;
-
-template <typename IDX_T, typename VAL_T, bool BLOCK>
+// Fast path. STEPS = number of 8-element steps each lane owns (compile time, so that every
+// payload / index / activation load of the row is issued before the first use: one HBM round
+// trip for the payload and the indices, one L2 round trip for the gathered activations).
+// STEPS == 0 selects a runtime loop over chunks of 4 steps for very long rows.
+// Everything is branch-free: out-of-range steps and skipped blocks load from a clamped (valid)
+// address and their partial sum is discarded by a select, so hipcc keeps all loads in flight.
+// Requires Ktot % 8 == 0, (block % 8 == 0 and n_in % 8 == 0 for the block scheme) and 16-byte
+// aligned x columns; other shapes take delta_rows_scalar_kernel.
+template <typename IDX_T, typename VAL_T, bool BLOCK, int STEPS>
 __global__ __launch_bounds__(256)
 void delta_rows_kernel(const DeltaParams p) {
+    constexpr int NS = STEPS > 0 ? STEPS : 4;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int G = p.G;
-    const int rows_per_wave = 64 / G;
     const int l = lane & (G - 1);
-    const int o = ((int) blockIdx.y * 4 + wave) * rows_per_wave + (lane / G);
+    const int o = ((int) blockIdx.y * 4 + wave) * (64 / G) + (lane / G);
     const int64_t t = blockIdx.x;
     const bool row_ok = o < p.n_out;
     const int orow = row_ok ? o : 0;
@@ -117,69 +125,108 @@ void delta_rows_kernel(const DeltaParams p) {
     const VAL_T * vrow = reinterpret_cast<const VAL_T *>(p.val) + (size_t) orow * p.Ktot;
     const IDX_T * irow = reinterpret_cast<const IDX_T *>(p.idx) + (size_t) orow * (BLOCK ? p.nb : p.Ktot);
 
-    float acc = 0.0f;
-    for (int base = 0; base < p.Ktot; base += G * 8 * UNROLL) {
-        Vec8<VAL_T> vv[UNROLL];
-        bool ok[UNROLL];
-        int e0[UNROLL];
+    // epilogue operands, requested first so they are home long before the reduction ends
+    float scale = 1.0f, vb[8];
+    const bool leader = row_ok && l == 0;
+    const int nbase = p.v ? (p.tall ? 1 : p.B) : 0;
+    if (leader) {
+        if (p.rs) scale = p.rs[o];
+        const float * vt = p.v + (size_t) t * p.B * p.L;
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            e0[u] = base + (u * G + l) * 8;
-            ok[u] = row_ok && e0[u] < p.Ktot;
-            if (ok[u]) vv[u].load(vrow + e0[u]);
+        for (int b = 0; b < 8; ++b) vb[b] = (b < nbase) ? vt[(size_t) b * p.L + o] : 0.0f;
+    }
+
+    float acc = 0.0f;
+    const int chunk = G * 8 * NS;
+    for (int base = 0; base < (STEPS > 0 ? 1 : p.Ktot); base += chunk) {
+        Vec8<VAL_T> vv[NS];
+        bool ok[NS];
+        int e0[NS];
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const int e = base + (u * G + l) * 8;
+            ok[u] = row_ok & (e < p.Ktot);
+            e0[u] = ok[u] ? e : 0;
         }
         if constexpr (BLOCK) {
-            int in0[UNROLL];
+            int blk[NS], off[NS];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                in0[u] = -1;
-                if (ok[u]) {
-                    const int bi  = e0[u] / p.block;
-                    const int blk = idx_to_i32<IDX_T>(irow[bi]);
-                    const int64_t s = (int64_t) blk * p.block;
-                    if (blk >= 0 && s < p.n_in) in0[u] = (int) s + (e0[u] - bi * p.block);
-                }
+            for (int u = 0; u < NS; ++u) {       // block indices first: they head the dependent chain
+                const int bi = e0[u] >> p.block_shift;            // block is a power of two on this path
+                off[u] = e0[u] & (p.block - 1);
+                blk[u] = idx_to_i32<IDX_T>(irow[bi]);
             }
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                if (in0[u] < 0) continue;
-                if (p.x_vec_ok && in0[u] + 8 <= p.n_in) {
-                    const float4 xa = *reinterpret_cast<const float4 *>(xt + in0[u]);
-                    const float4 xb = *reinterpret_cast<const float4 *>(xt + in0[u] + 4);
-                    acc += val_to_f32<VAL_T>(vv[u].get(0)) * xa.x;
-                    acc += val_to_f32<VAL_T>(vv[u].get(1)) * xa.y;
-                    acc += val_to_f32<VAL_T>(vv[u].get(2)) * xa.z;
-                    acc += val_to_f32<VAL_T>(vv[u].get(3)) * xa.w;
-                    acc += val_to_f32<VAL_T>(vv[u].get(4)) * xb.x;
-                    acc += val_to_f32<VAL_T>(vv[u].get(5)) * xb.y;
-                    acc += val_to_f32<VAL_T>(vv[u].get(6)) * xb.z;
-                    acc += val_to_f32<VAL_T>(vv[u].get(7)) * xb.w;
-                } else {
+            for (int u = 0; u < NS; ++u) vv[u].load(vrow + e0[u]);
+            float4 xa[NS], xb[NS];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        if (in0[u] + j < p.n_in) acc += val_to_f32<VAL_T>(vv[u].get(j)) * xt[in0[u] + j];
-                    }
-                }
+            for (int u = 0; u < NS; ++u) {
+                // valid iff 0 <= blk and blk*block < n_in  <=>  (unsigned) blk < ceil(n_in / block)
+                // and the last block is clipped to n_in: with n_in % 8 == 0 an 8-run is all in or all out
+                const int raw = (blk[u] << p.block_shift) + off[u];
+                ok[u] = ok[u] & ((unsigned) blk[u] < (unsigned) p.n_blk_in) & (raw < p.n_in);
+                const int in0 = ok[u] ? raw : 0;
+                xa[u] = *reinterpret_cast<const float4 *>(xt + in0);
+                xb[u] = *reinterpret_cast<const float4 *>(xt + in0 + 4);
+            }
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                float ps = val_to_f32<VAL_T>(vv[u].get(0)) * xa[u].x;
+                ps += val_to_f32<VAL_T>(vv[u].get(1)) * xa[u].y;
+                ps += val_to_f32<VAL_T>(vv[u].get(2)) * xa[u].z;
+                ps += val_to_f32<VAL_T>(vv[u].get(3)) * xa[u].w;
+                ps += val_to_f32<VAL_T>(vv[u].get(4)) * xb[u].x;
+                ps += val_to_f32<VAL_T>(vv[u].get(5)) * xb[u].y;
+                ps += val_to_f32<VAL_T>(vv[u].get(6)) * xb[u].z;
+                ps += val_to_f32<VAL_T>(vv[u].get(7)) * xb[u].w;
+                acc += ok[u] ? ps : 0.0f;
             }
         } else {
-            Vec8<IDX_T> ii[UNROLL];
+            Vec8<IDX_T> ii[NS];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                if (ok[u]) ii[u].load(irow + e0[u]);
-            }
+            for (int u = 0; u < NS; ++u) ii[u].load(irow + e0[u]);
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                if (!ok[u]) continue;
+            for (int u = 0; u < NS; ++u) vv[u].load(vrow + e0[u]);
+            float xs[NS][8];
+            bool okj[NS][8];
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int i = idx_to_i32<IDX_T>(ii[u].get(j));
-                    if (i >= 0 && i < p.n_in) acc += val_to_f32<VAL_T>(vv[u].get(j)) * xt[i];
+                    okj[u][j] = ok[u] & ((unsigned) i < (unsigned) p.n_in);
+                    xs[u][j] = xt[okj[u][j] ? i : 0];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float pr = val_to_f32<VAL_T>(vv[u].get(j)) * xs[u][j];
+                    acc += okj[u][j] ? pr : 0.0f;
                 }
             }
         }
     }
     for (int m = G >> 1; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
-    if (row_ok && l == 0) finish(p, o, t, base_term(p, o, t) + acc);
+    if (leader) {
+        float yh = 0.0f;
+        if (p.v) {
+            if (p.tall) yh = vb[0];
+            else {
+#pragma unroll
+                for (int b = 0; b < 8; ++b) if (b < nbase) yh += vb[b];
+                for (int b = 8; b < nbase; ++b) yh += p.v[((size_t) t * p.B + b) * p.L + o];
+            }
+        }
+        const float y = yh + acc;
+        float out = (scale != 1.0f) ? (y * scale) : y;
+        if (!isfinite(out)) {
+            atomicAdd(p.nf, 1);
+            if (p.zero_nf) out = 0.0f;
+        }
+        p.y[o + t * p.ldy] = out;
+    }
 }
 
 // Scalar-load variant for payloads whose rows are not 16-byte multiples (K % 8 != 0, odd block
@@ -263,11 +310,12 @@ static int launch_typed(const DeviceWeight & w, const DeltaLaunch & a, DeltaPara
         SDH_HIP_CHECK(hipGetLastError());
         return SDH_OK;
     }
-    // lanes per row: enough that every lane has at most UNROLL 8-element steps, at least 1
-    const bool vec_ok = (p.Ktot % 8 == 0) && (!BLOCK || (p.block % 8 == 0));
-    const int per_lane = vec_ok ? 8 : 1;
+    // vector path: 8 payload elements (16 B of f16) per lane per step
+    const bool vec_ok = (p.Ktot % 8 == 0) && p.x_vec_ok &&
+                        (!BLOCK || (p.block % 8 == 0 && p.block_shift >= 0 && p.n_in % 8 == 0));
     int G = 1;
-    while (G < 64 && G * per_lane * (vec_ok ? 1 : 4) < p.Ktot) G <<= 1;
+    if (vec_ok) { while (G < 64 && G * 8 < p.Ktot) G <<= 1; }
+    else        { while (G < 64 && G * 4 < p.Ktot) G <<= 1; }
     p.G = G;
     const int rows_per_block = 4 * (64 / G);
     const unsigned gy = (unsigned) ((p.n_out + rows_per_block - 1) / rows_per_block);
@@ -277,7 +325,14 @@ static int launch_typed(const DeviceWeight & w, const DeltaLaunch & a, DeltaPara
     }
     dim3 grid((unsigned) a.T, gy);
     if (vec_ok) {
-        hipLaunchKernelGGL((delta_rows_kernel<IDX_T, VAL_T, BLOCK>), grid, dim3(256), 0, s, p);
+        const int steps = (p.Ktot + G * 8 - 1) / (G * 8);
+        switch (steps) {
+            case 1:  hipLaunchKernelGGL((delta_rows_kernel<IDX_T, VAL_T, BLOCK, 1>), grid, dim3(256), 0, s, p); break;
+            case 2:  hipLaunchKernelGGL((delta_rows_kernel<IDX_T, VAL_T, BLOCK, 2>), grid, dim3(256), 0, s, p); break;
+            case 3:  hipLaunchKernelGGL((delta_rows_kernel<IDX_T, VAL_T, BLOCK, 3>), grid, dim3(256), 0, s, p); break;
+            case 4:  hipLaunchKernelGGL((delta_rows_kernel<IDX_T, VAL_T, BLOCK, 4>), grid, dim3(256), 0, s, p); break;
+            default: hipLaunchKernelGGL((delta_rows_kernel<IDX_T, VAL_T, BLOCK, 0>), grid, dim3(256), 0, s, p); break;
+        }
     } else {
         hipLaunchKernelGGL((delta_rows_scalar_kernel<IDX_T, VAL_T, BLOCK>), grid, dim3(256), 0, s, p);
     }
@@ -298,6 +353,9 @@ int launch_delta(const DeviceWeight & w, const DeltaLaunch & a, hipStream_t s) {
     p.L = (int) w.L; p.B = (int) w.B; p.tall = w.tall ? 1 : 0;
     p.zero_nf = a.zero_nonfinite ? 1 : 0;
     p.x_vec_ok = (((uintptr_t) a.x % 16) == 0 && (a.ldx % 4) == 0) ? 1 : 0;
+    p.n_blk_in = is_block ? (int) ((w.n_in + w.block - 1) / w.block) : 0;
+    p.block_shift = -1;
+    if (is_block && w.block > 0 && (w.block & (w.block - 1)) == 0) { int sft = 0; while ((1LL << sft) < w.block) ++sft; p.block_shift = sft; }
 
     const bool i16 = w.idx_type == SDH_TYPE_I16;
     const bool f16 = w.val_type == SDH_TYPE_F16;

@@ -21,6 +21,17 @@ void set_error(const char * fmt, ...);
         }                                                                                    \
     } while (0)
 
+// Where the per-block base parameters live inside the packed parameter slab that the hot-path
+// kernels read (bytes from the start of the block's slab; -1 = tensor absent, or all ones and
+// elided because x * 1.0f == x exactly). One contiguous region per base block: a cold block
+// costs one page walk and one HBM round trip.
+struct BasePackDesc {
+    const uint8_t * pack = nullptr;   // device
+    int blk_stride = 0;               // bytes per base block
+    int off_p1 = -1, off_d2 = -1, off_d1 = -1, off_d3 = -1, off_p2 = -1;
+    int wide32 = 0;                   // 1: f32 / i32 parameters, 0: f16 / i16 (as the builder writes them)
+};
+
 // ---- device-resident payload ---------------------------------------------------------------
 // All tensors are repacked contiguous at upload; element types of idx/val are kept as stored
 // in the GGUF (they are the HBM stream), small per-row / per-base-block vectors are widened
@@ -49,6 +60,8 @@ struct DeviceWeight {
     float * G = nullptr;         // [B][L]  FWHT(d2_b) in the reference butterfly order
     int *   inv = nullptr;       // [B][L]  perm1_b^-1
     bool    w0_closed_form = false;   // depth 2, no perm2, perm1 bijective
+    uint8_t *    pack_dev = nullptr;  // packed 16/32-bit base parameters (hot path)
+    BasePackDesc pack;
     // accounting
     int64_t payload_bytes = 0;   // as stored in the GGUF
     // non-finite accounting: ring of per-call counters (no per-call memset on the hot path)

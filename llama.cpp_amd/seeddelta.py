@@ -82,6 +82,13 @@ def load_library(path: str = LIB_PATH):
         return _lib
     if not os.path.exists(path):
         raise SeedDeltaError(f"{path} not built: run `make -C llama.cpp_amd/csrc` (or __graft_entry__.build())")
+    try:
+        # torch ships its own libamdhip64/libhsa-runtime64. If this library (linked against
+        # libamdhip64.so.7) is loaded first, the process ends up with two HIP runtimes and torch
+        # then reports "No HIP GPUs are available". Loading torch first makes both share one.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     lib.sdh_init.argtypes = [C.c_int]
     lib.sdh_abi_version.restype = C.c_int
