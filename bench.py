@@ -45,7 +45,10 @@ def parse_args():
     ap.add_argument("--workload", default="cfg3_mistral_down_block32_k1536")
     ap.add_argument("--payloads", type=int, default=32, help="distinct payloads rotated per loop (cache honesty)")
     ap.add_argument("--tokens", type=int, default=1, help="tokens per step (1 = decode)")
-    ap.add_argument("--launch", choices=["graph", "eager"], default="graph")
+    ap.add_argument("--launch", choices=["graph", "eager"], default="eager",
+                    help="eager: one fused launch per step (the fused decode kernel is not capturable: its "
+                         "hand-off epoch is a launch argument); graph: hipGraph replay of the two-launch path")
+    ap.add_argument("--no-fuse", action="store_true", help="force the two-launch path (A/B)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -116,9 +119,13 @@ def main():
         del p
     torch.cuda.synchronize()
 
+    fwd_flags = seeddelta.FWD_NO_FUSE if (args.no_fuse or args.launch == "graph") else 0
+    fused = (T == 1 and args.launch == "eager" and not args.no_fuse)
+
     def run_rotation(stream_ptr):
         for i in range(NP):
-            weights[i].forward_device(xs[i].data_ptr(), n_in, T, ys[i].data_ptr(), n_out, stream=stream_ptr)
+            weights[i].forward_device(xs[i].data_ptr(), n_in, T, ys[i].data_ptr(), n_out, flags=fwd_flags,
+                                      stream=stream_ptr)
 
     steps = max(NP, (args.steps // NP) * NP)
     warm = max(NP, (args.warmup // NP) * NP)
@@ -179,7 +186,9 @@ def main():
             achieved = alg_bytes / dur_s / 1e9
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                    "kernel": "delta_rows_kernel", "avg_kernel_us": dur_s * 1e6, "launches": n,
+                    "kernel": "decode_fused_kernel (base + residual in one launch)" if fused else
+                              "delta_rows_kernel (residual; the base kernel runs before it)",
+                    "avg_kernel_us": dur_s * 1e6, "launches": n,
                     "algorithmic_bytes_per_launch": alg_bytes}
 
     cpu = None

@@ -132,7 +132,7 @@ static void free_weight(DeviceWeight * w) {
     if (!w) return;
     (void) hipFree(w->idx); (void) hipFree(w->val); (void) hipFree(w->rs);
     (void) hipFree(w->d1); (void) hipFree(w->d2); (void) hipFree(w->d3); (void) hipFree(w->p1); (void) hipFree(w->p2);
-    (void) hipFree(w->pack_dev);
+    (void) hipFree(w->pack_dev); (void) hipFree(w->handoff);
     (void) hipFree(w->G); (void) hipFree(w->inv); (void) hipFree(w->nf_ring); (void) hipFree(w->ws);
     delete w;
 }
@@ -394,6 +394,14 @@ int sdh_weight_create(const sdh_weight_desc * desc, sdh_weight ** out) {
             if ((rc = upload(slab, &w->pack_dev)) != SDH_OK) return fail(rc);
             pd.pack = w->pack_dev;
         }
+        // hand-off buffer of the fused decode kernel: [B][L] granules {value, epoch} (tag 0 = never
+        // written; epochs start at 1)
+        {
+            const size_t gb = (size_t) L * (size_t) B * sizeof(unsigned long long);
+            hipError_t e = hipMalloc((void **) &w->handoff, gb);
+            if (e == hipSuccess) e = hipMemset(w->handoff, 0, gb);
+            if (e != hipSuccess) { set_error("hand-off alloc failed: %s", hipGetErrorString(e)); return fail(SDH_ERR_HIP); }
+        }
     }
     {
         hipError_t e = hipMalloc((void **) &w->nf_ring, DeviceWeight::NF_SLOTS * sizeof(int));
@@ -464,43 +472,67 @@ int sdh_forward(sdh_weight * h, const float * x, int64_t ldx, int64_t n_tokens,
         SDH_HIP_CHECK(hipMemsetAsync(w->nf_ring + slot, 0, (NS / 2) * sizeof(int), s));
     }
 
-    // token chunking bounds the base-term workspace
+    // token chunking bounds the base-term workspace of the two-kernel path
     int64_t chunk = n_tokens;
+    const size_t per_tok = has_base ? (size_t) w->B * (size_t) w->L * 4 : 0;
     if (has_base) {
-        const size_t per_tok = (size_t) w->B * (size_t) w->L * 4;
         const size_t cap = (size_t) 512 << 20;
         if (per_tok * (size_t) chunk > cap) chunk = (int64_t) (cap / per_tok);
         if (chunk < 1) chunk = 1;
-        int rc = ensure_ws(w, per_tok * (size_t) chunk);
-        if (rc != SDH_OK) return rc;
     }
+    LibState & ls = lib();
     for (int64_t t0 = 0; t0 < n_tokens; t0 += chunk) {
         const int64_t tc = (n_tokens - t0 < chunk) ? (n_tokens - t0) : chunk;
         const float * xc = dx + t0 * dldx;
-        if (has_base) {
-            int rc = launch_base_apply(*w, xc, dldx, tc, w->ws, s);
-            if (rc != SDH_OK) return rc;
-        }
         DeltaLaunch a{};
         a.x = xc; a.ldx = dldx; a.T = tc;
         a.y = dy + t0 * dldy; a.ldy = dldy;
-        a.v = has_base ? w->ws : nullptr;
+        a.v = nullptr;
         a.nf_counter = w->nf_ring + slot;
         a.zero_nonfinite = (flags & SDH_FWD_ZERO_NONFINITE) != 0;
         a.exact_order = (flags & SDH_FWD_EXACT_ORDER) != 0;
-        LibState & ls = lib();
-        int pair = -1;
-        if (ls.prof_on) {
+
+        auto prof_begin = [&](int & pair) -> int {
+            pair = -1;
+            if (!ls.prof_on) return SDH_OK;
             if (ls.prof_used == LibState::PROF_PAIRS) { int rcf = prof_flush(ls); if (rcf != SDH_OK) return rcf; }
             pair = ls.prof_used;
             SDH_HIP_CHECK(hipEventRecord(ls.prof_ev[2 * pair], s));
-        }
-        int rc = launch_delta(*w, a, s);
-        if (rc != SDH_OK) return rc;
-        if (pair >= 0) {
+            return SDH_OK;
+        };
+        auto prof_end = [&](int pair) -> int {
+            if (pair < 0) return SDH_OK;
             SDH_HIP_CHECK(hipEventRecord(ls.prof_ev[2 * pair + 1], s));
             ls.prof_used = pair + 1;
+            return SDH_OK;
+        };
+
+        // batch-1 decode with a base: one fused launch when the payload qualifies
+        if (has_base && tc == 1 && !(flags & SDH_FWD_NO_FUSE)) {
+            int pair, rc = prof_begin(pair);
+            if (rc != SDH_OK) return rc;
+            rc = launch_decode_fused(*w, a, s);
+            if (rc < 0) return rc;
+            if (rc == SDH_OK) {
+                rc = prof_end(pair);
+                if (rc != SDH_OK) return rc;
+                continue;
+            }
+            // rc == 1: not applicable; the opening event is simply re-recorded below
         }
+        if (has_base) {
+            int rc = ensure_ws(w, per_tok * (size_t) chunk);
+            if (rc != SDH_OK) return rc;
+            rc = launch_base_apply(*w, xc, dldx, tc, w->ws, s);
+            if (rc != SDH_OK) return rc;
+            a.v = w->ws;
+        }
+        int pair, rc = prof_begin(pair);
+        if (rc != SDH_OK) return rc;
+        rc = launch_delta(*w, a, s);
+        if (rc != SDH_OK) return rc;
+        rc = prof_end(pair);
+        if (rc != SDH_OK) return rc;
     }
     w->seq++;
     w->last_stream = s;

@@ -106,16 +106,19 @@ __device__ __forceinline__ void base_lds_read(float (&y)[1 << LOG_E], const floa
 // Full FWHT of the block held in layout 0; leaves it in layout J-1. The transposes alternate
 // between the two LDS buffers, transition JJ using lds0 when (JJ + PAR) is odd, so that a buffer
 // is never rewritten before a barrier has separated it from its last readers.
-template <int LOG_E, int PAR, int JJ = 0>
+// With ONE_BUF (lds0 == lds1, half the LDS: the fused decode kernel needs the occupancy) every
+// rewrite is preceded by a barrier of its own instead.
+template <int LOG_E, int PAR, bool ONE_BUF, int JJ = 0>
 __device__ __forceinline__ void base_fwht(float (&y)[1 << LOG_E], float * lds0, float * lds1, int tid) {
     using Ly = BaseLay<LOG_E>;
     base_stages<LOG_E, JJ>(y);
     if constexpr (JJ + 1 < Ly::J) {
         float * buf = ((JJ + PAR) & 1) ? lds0 : lds1;
+        if constexpr (ONE_BUF) __syncthreads();
         base_lds_write<LOG_E, JJ>(buf, y, tid);
         __syncthreads();
         base_lds_read<LOG_E, JJ + 1>(y, buf, tid);
-        base_fwht<LOG_E, PAR, JJ + 1>(y, lds0, lds1, tid);
+        base_fwht<LOG_E, PAR, ONE_BUF, JJ + 1>(y, lds0, lds1, tid);
     }
 }
 
@@ -131,22 +134,25 @@ __device__ __forceinline__ int base_param_i(const uint8_t * p, int i) {
 }
 
 // Transform one block. xt: the token's activation column; in0: first input element of the block
-// (0 for tall weights); the block reads x[in0 .. in0+L) zero-padded past n_in. lds: 2*L floats.
-// emit(i, value) receives every output element (i in [0,L)), coalesced across the workgroup.
-template <int LOG_E, bool P32, typename Emit>
+// (0 for tall weights); the block reads x[in0 .. in0+L) zero-padded past n_in. lds: 2*L floats
+// (ONE_BUF: L floats, at the price of one more barrier per transpose).
+// On return y[r] holds output element BaseLay::idx(J-1, tid, r) (the last layout: consecutive
+// threads hold consecutive elements, so a plain store per register is coalesced).
+template <int LOG_E, bool P32, bool ONE_BUF>
 __device__ __forceinline__ void base_transform(const float * __restrict__ xt, int n_in, int in0, bool x_vec_ok,
-                                               const BasePackDesc & pd, int b, float * lds, int tid, Emit && emit) {
+                                               const BasePackDesc & pd, int b, float * lds, int tid,
+                                               float (&y)[1 << LOG_E]) {
 #pragma clang fp contract(off)
     using Ly = BaseLay<LOG_E>;
     constexpr int E = Ly::E, L = Ly::L, JL = Ly::J - 1;
     float * lds0 = lds;
-    float * lds1 = lds + L;
+    float * lds1 = ONE_BUF ? lds : lds + L;
     const uint8_t * pk = pd.pack + (size_t) b * pd.blk_stride;
     const bool has_p1 = pd.off_p1 >= 0, has_d2 = pd.off_d2 >= 0, has_d1 = pd.off_d1 >= 0,
                has_d3 = pd.off_d3 >= 0, has_p2 = pd.off_p2 >= 0;
 
     // ---- every global load is issued before the first use -------------------------------------
-    float y[E], s2[E], s3[E];
+    float s2[E], s3[E];
     int g1[E];
     const int src0 = in0 + E * tid;
     if (x_vec_ok && src0 + E <= n_in) {
@@ -185,11 +191,13 @@ __device__ __forceinline__ void base_transform(const float * __restrict__ xt, in
     }
     SDH_STAMP(2);
     // ---- H ----------------------------------------------------------------------------------------
-    base_fwht<LOG_E, 0>(y, lds0, lds1, tid);                 // y now in layout JL
+    base_fwht<LOG_E, 0, ONE_BUF>(y, lds0, lds1, tid);        // y now in layout JL
     SDH_STAMP(3);
     if (!has_d2 && !has_p2) {                                // depth 1 (:537-544)
+        if (has_d3) {
 #pragma unroll
-        for (int r = 0; r < E; ++r) emit(Ly::idx(JL, tid, r), has_d3 ? y[r] * s3[r] : y[r]);
+            for (int r = 0; r < E; ++r) y[r] = y[r] * s3[r];
+        }
         return;
     }
     if (has_d2) {
@@ -201,6 +209,7 @@ __device__ __forceinline__ void base_transform(const float * __restrict__ xt, in
     // buffer's readers are already behind a barrier, so it takes the way back. The second FWHT
     // then starts on the buffer that is not being read here (PAR = J & 1).
     float * back = (Ly::J & 1) ? lds1 : lds0;
+    if constexpr (ONE_BUF) __syncthreads();
     base_lds_write<LOG_E, JL>(back, y, tid);
     __syncthreads();
     if (has_p2) {
@@ -210,10 +219,24 @@ __device__ __forceinline__ void base_transform(const float * __restrict__ xt, in
         base_lds_read<LOG_E, 0>(y, back, tid);
     }
     SDH_STAMP(4);
-    base_fwht<LOG_E, (Ly::J & 1)>(y, lds0, lds1, tid);
+    base_fwht<LOG_E, (Ly::J & 1), ONE_BUF>(y, lds0, lds1, tid);
     SDH_STAMP(5);
+    if (has_d3) {
 #pragma unroll
-    for (int r = 0; r < E; ++r) emit(Ly::idx(JL, tid, r), has_d3 ? y[r] * s3[r] : y[r]);
+        for (int r = 0; r < E; ++r) y[r] = y[r] * s3[r];
+    }
+}
+
+// Re-order a finished block from the last layout to layout 0 (E consecutive elements per thread,
+// thread t holding [E*t, E*t+E)) through a single LDS buffer that may still be in use: a barrier
+// first, then write, barrier, read.
+template <int LOG_E>
+__device__ __forceinline__ void base_to_layout0(float (&y)[1 << LOG_E], float * lds, int tid) {
+    using Ly = BaseLay<LOG_E>;
+    __syncthreads();
+    base_lds_write<LOG_E, Ly::J - 1>(lds, y, tid);
+    __syncthreads();
+    base_lds_read<LOG_E, 0>(y, lds, tid);
 }
 
 } // namespace sdh

@@ -1,0 +1,241 @@
+// sdh_decode.hip — batch-1 decode of a SeedDelta weight WITH a base, as ONE launch.
+//
+// At T = 1 the op is latency-bound: the payload (cfg3: 13 MB) streams in ~4 us, the base transform
+// (2 FWHTs per block behind a cold parameter fetch) takes ~5 us on its own, and a dependent kernel
+// boundary costs another ~1.5-2.5 us. Running the two as separate launches serialises them. Here
+// the first B workgroups of the grid compute the base blocks while all the others stream the
+// residual; a residual wave picks up the base term of its row at the very end.
+//
+// Hand-off (cdna_hip_programming.md Guideline 16, form R2 "the data IS the flag"): the base
+// workgroups publish every output element as a naturally aligned 8-byte {value, epoch} granule
+// written by ONE agent-scope (sc1, write-through) store; a consumer lane reads the granules of its
+// row with agent-scope (sc1) 8-byte
+// loads and accepts them only when the tag equals this launch's epoch. A granule is written by one
+// store and read by one load, so no flag, fence or ordering between different addresses is
+// involved, nothing depends on workgroup placement or dispatch order, and the 4096 polling lanes
+// touch 4096 different addresses (a single shared flag word measured 3 us slower: every poll of the
+// launch lands on one line). The epoch is a host counter bumped per launch, so granules of earlier
+// launches are never accepted (which is also why this path is not used under stream capture: a
+// replayed launch would replay its epoch).
+//
+// Safety: the consumers spin, so every workgroup of the grid must be resident together. The host
+// only takes this path when grid <= occupancy x CUs, and verifies that once per kernel with a
+// census launch (every workgroup checks in and waits, bounded, for all the others) — on gfx950 the
+// occupancy API can over-report by one workgroup per CU. All spins are bounded by the real-time
+// counter; a consumer that gives up writes NaN, which the non-finite counter reports.
+#include "sdh_internal.h"
+#include "sdh_base_dev.h"
+#include "sdh_delta_dev.h"
+
+namespace sdh {
+
+constexpr unsigned long long SPIN_TICKS = 50000;      // 100 MHz ticks = 500 us
+#ifndef SDH_POLL_SLEEP
+#define SDH_POLL_SLEEP 4                              // s_sleep units of 64 clocks between polls
+#endif
+#ifndef SDH_BASE_PRIO
+#define SDH_BASE_PRIO 3
+#endif
+
+struct FusedArgs {
+    unsigned long long * vg;      // [B][L] granules {value, epoch}
+    unsigned   epoch;
+    int        census;            // 1: census launch (no computation)
+    unsigned * census_ctr;        // [0] arrivals, [1] failures
+};
+
+template <bool BLOCK, int STEPS, int LOG_E>
+__global__ __launch_bounds__(256)
+void decode_fused_kernel(const DeltaParams p, const BasePackDesc pd, const FusedArgs fa) {
+    constexpr int L = BaseLay<LOG_E>::L;
+    constexpr int E = BaseLay<LOG_E>::E;
+    __shared__ __align__(16) float lds[L];             // one transpose buffer: occupancy over barriers
+
+    if (fa.census) {                                   // residency self-test, see header comment
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(&fa.census_ctr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            bool all = false;
+            while (__builtin_amdgcn_s_memrealtime() - t0 < 2 * SPIN_TICKS) {
+                if (__hip_atomic_load(&fa.census_ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= gridDim.x) { all = true; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (!all) __hip_atomic_fetch_add(&fa.census_ctr[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+
+    if ((int) blockIdx.x < p.B) {
+        // ---- base role: one block of the base transform, published write-through + flag --------
+        const int b = blockIdx.x;
+        const int tid = threadIdx.x;
+        __builtin_amdgcn_s_setprio(SDH_BASE_PRIO);     // the base blocks are the critical path of the launch
+        float y[E];
+        base_transform<LOG_E, false, true>(p.x, p.n_in, p.tall ? 0 : b * L, p.x_vec_ok != 0, pd, b, lds, tid, y);
+        // Publish as {value, epoch} granules, one agent-scope (sc1, write-through) 8-byte store each,
+        // straight from the last layout (consecutive lanes write consecutive granules). Measured
+        // alternatives, all slower end to end on the cfg3 shape: two granules per 16-byte sc1 store
+        // after an LDS re-order (+5 us: the stores collide with the pollers of the same lines), plain
+        // f32 values + one flag per block (+2.5 us: 4096 pollers on one line).
+        unsigned long long * out = fa.vg + (size_t) b * L;
+        const unsigned long long tag = (unsigned long long) fa.epoch << 32;
+#pragma unroll
+        for (int r = 0; r < E; ++r)
+            __hip_atomic_store(out + BaseLay<LOG_E>::idx(BaseLay<LOG_E>::J - 1, tid, r),
+                               tag | (unsigned long long) __float_as_uint(y[r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        SDH_STAMP(6);
+        return;
+    }
+
+    // ---- residual role ------------------------------------------------------------------------
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int G = p.G;
+    const int l = lane & (G - 1);
+    const int o = (((int) blockIdx.x - p.B) * 4 + wave) * (64 / G) + (lane / G);
+    const bool row_ok = o < p.n_out;
+    const int orow = row_ok ? o : 0;
+    const bool leader = row_ok && l == 0;
+    float scale = 1.0f;
+    if (leader && p.rs) scale = p.rs[o];
+
+    SDH_STAMP(10);
+    float acc = delta_row_partial<uint16_t, uint16_t, BLOCK, STEPS>(p, p.x, orow, row_ok, l, G);
+    acc = group_reduce(acc, G);
+    SDH_STAMP(11);
+
+    if (leader) {
+        // base term: tall v_b[o - bL] with b = o / L (buffer index b*L + (o - b*L) == o);
+        // wide sum_b v_b[o], accumulated from 0.0f in block order
+        const int nbase = p.tall ? 1 : p.B;             // host guarantees nbase <= 8
+        const unsigned long long * gp = fa.vg + o;
+        float vals[8];
+        bool ok = false;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        do {
+            ok = true;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                vals[b] = 0.0f;
+                if (b < nbase) {                         // wave-uniform
+                    const unsigned long long g = __hip_atomic_load(gp + (size_t) b * L, __ATOMIC_RELAXED,
+                                                                   __HIP_MEMORY_SCOPE_AGENT);
+                    ok = ok & ((unsigned) (g >> 32) == fa.epoch);
+                    vals[b] = __uint_as_float((unsigned) g);
+                }
+            }
+            if (ok) break;
+            __builtin_amdgcn_s_sleep(SDH_POLL_SLEEP);
+        } while (__builtin_amdgcn_s_memrealtime() - t0 < SPIN_TICKS);
+        SDH_STAMP(12);
+        float yh;
+        if (p.tall) yh = vals[0];
+        else {
+            yh = 0.0f;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) if (b < nbase) yh += vals[b];
+        }
+        float y = yh + acc;
+        if (!ok) y = __uint_as_float(0x7FC00000u);       // base never arrived: surface it as a NaN
+        store_output(p, o, 0, y, scale);
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------
+struct FusedKernelInfo {
+    int occ = -1;                 // resident workgroups per CU (occupancy API)
+    unsigned census_ok_grid = 0;  // largest grid the census has confirmed
+    bool census_failed = false;
+};
+
+template <bool BLOCK, int STEPS, int LOG_E>
+static FusedKernelInfo & kernel_info() {
+    static FusedKernelInfo info;
+    return info;
+}
+
+template <bool BLOCK, int STEPS, int LOG_E>
+static int launch_inst(const DeltaParams & p, const BasePackDesc & pd, FusedArgs fa, unsigned grid, hipStream_t s) {
+    FusedKernelInfo & ki = kernel_info<BLOCK, STEPS, LOG_E>();
+    LibState & ls = lib();
+    if (ki.occ < 0) {
+        int occ = 0;
+        SDH_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, decode_fused_kernel<BLOCK, STEPS, LOG_E>, 256, 0));
+        ki.occ = occ;
+    }
+    static const bool dbg = getenv("SDH_DEBUG") != nullptr;
+    if (ki.census_failed || (long long) grid > (long long) ki.occ * ls.num_cu) {   // not all resident: caller falls back
+        if (dbg) fprintf(stderr, "[sdh] fused decode declined: grid=%u occ=%d cus=%d census_failed=%d\n", grid, ki.occ, ls.num_cu, (int) ki.census_failed);
+        return 1;
+    }
+    if (grid > ki.census_ok_grid) {
+        // one-time residency census for this kernel at this grid size
+        if (!ls.census_ctr) {
+            SDH_HIP_CHECK(hipMalloc((void **) &ls.census_ctr, 16));
+        }
+        SDH_HIP_CHECK(hipMemsetAsync(ls.census_ctr, 0, 16, s));
+        FusedArgs ca = fa;
+        ca.census = 1;
+        ca.census_ctr = ls.census_ctr;
+        hipLaunchKernelGGL((decode_fused_kernel<BLOCK, STEPS, LOG_E>), dim3(grid), dim3(256), 0, s, p, pd, ca);
+        SDH_HIP_CHECK(hipGetLastError());
+        unsigned h[2] = {0, 0};
+        SDH_HIP_CHECK(hipMemcpyAsync(h, ls.census_ctr, sizeof(h), hipMemcpyDeviceToHost, s));
+        SDH_HIP_CHECK(hipStreamSynchronize(s));
+        if (dbg) fprintf(stderr, "[sdh] fused decode census: grid=%u arrived=%u failures=%u\n", grid, h[0], h[1]);
+        if (h[0] != grid || h[1] != 0) { ki.census_failed = true; return 1; }
+        ki.census_ok_grid = grid;
+    }
+    fa.census = 0;
+    fa.census_ctr = nullptr;
+    hipLaunchKernelGGL((decode_fused_kernel<BLOCK, STEPS, LOG_E>), dim3(grid), dim3(256), 0, s, p, pd, fa);
+    SDH_HIP_CHECK(hipGetLastError());
+    return SDH_OK;
+}
+
+template <bool BLOCK, int LOG_E>
+static int launch_steps(int steps, const DeltaParams & p, const BasePackDesc & pd, const FusedArgs & fa, unsigned grid, hipStream_t s) {
+    switch (steps) {
+        case 1: return launch_inst<BLOCK, 1, LOG_E>(p, pd, fa, grid, s);
+        case 2: return launch_inst<BLOCK, 2, LOG_E>(p, pd, fa, grid, s);
+        case 3: return launch_inst<BLOCK, 3, LOG_E>(p, pd, fa, grid, s);
+        case 4: return launch_inst<BLOCK, 4, LOG_E>(p, pd, fa, grid, s);
+        default: return 1;
+    }
+}
+
+// Returns SDH_OK if the fused kernel was launched, 1 if this payload / call does not qualify (the
+// caller then runs the two-kernel path), <0 on error.
+int launch_decode_fused(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s) {
+    const bool is_block = (w.kind == SDH_OP_BASE_BLOCK);
+    static const bool dbg = getenv("SDH_DEBUG") != nullptr;
+#define SDH_DECLINE(why) do { if (dbg) fprintf(stderr, "[sdh] fused decode declined: %s\n", why); return 1; } while (0)
+    if (a.T != 1 || a.exact_order) return 1;
+    if (w.kind != SDH_OP_BASE_BLOCK && w.kind != SDH_OP_BASE_COO) return 1;
+    if (w.idx_type != SDH_TYPE_I16 || w.val_type != SDH_TYPE_F16) SDH_DECLINE("payload is not I16/F16");
+    if (w.pack.wide32 || !w.handoff) SDH_DECLINE("base parameters are 32-bit");
+    if (!(w.L == 1024 || w.L == 2048 || w.L == 4096)) SDH_DECLINE("L not in {1024,2048,4096}");
+    if (!w.tall && w.B > 8) SDH_DECLINE("more than 8 base blocks per output");
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) SDH_DECLINE("stream is capturing");
+
+    DeltaParams p = make_delta_params(w, a);
+    int G = 1, steps = 0;
+    if (!delta_vector_shape(p, is_block, &G, &steps) || steps < 1 || steps > 4) SDH_DECLINE("row shape needs the scalar or looped kernel");
+#undef SDH_DECLINE
+    p.G = G;
+    const int rows_per_block = 4 * (64 / G);
+    const unsigned grid = (unsigned) w.B + (unsigned) ((p.n_out + rows_per_block - 1) / rows_per_block);
+
+    if (++w.epoch == 0) w.epoch = 1;
+    FusedArgs fa{};
+    fa.vg = reinterpret_cast<unsigned long long *>(w.handoff);
+    fa.epoch = w.epoch;
+    switch (w.L) {
+        case 1024: return is_block ? launch_steps<true, 2>(steps, p, w.pack, fa, grid, s) : launch_steps<false, 2>(steps, p, w.pack, fa, grid, s);
+        case 2048: return is_block ? launch_steps<true, 3>(steps, p, w.pack, fa, grid, s) : launch_steps<false, 3>(steps, p, w.pack, fa, grid, s);
+        default:   return is_block ? launch_steps<true, 4>(steps, p, w.pack, fa, grid, s) : launch_steps<false, 4>(steps, p, w.pack, fa, grid, s);
+    }
+}
+
+} // namespace sdh

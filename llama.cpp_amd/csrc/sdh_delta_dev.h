@@ -1,0 +1,185 @@
+// sdh_delta_dev.h — device code of the sparse residual Δ·x shared by the stand-alone residual
+// kernels (sdh_delta.hip) and the fused decode kernel (sdh_decode.hip).
+//
+//   COO  : sum_r val[r,o] * x[idx[r,o]]                      idx<0 or idx>=n_in skipped (:693)
+//   block: sum_bi sum_j bval[j,bi,o] * x[bidx[bi,o]*block+j] blk<0 or blk*block>=n_in skipped,
+//                                                            last block clipped to n_in (:929-936)
+// (reference: src/llama-seeddelta.cpp)
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "sdh_internal.h"
+
+namespace sdh {
+
+struct DeltaParams {
+    const void *  idx;
+    const void *  val;
+    const float * rs;
+    const float * x;
+    float *       y;
+    const float * v;        // base scratch [T][B][L] or null
+    int *         nf;       // non-finite counter
+    int64_t ldx, ldy;
+    int n_in, n_out;
+    int Ktot;               // COO: K ; block: nb*block
+    int nb, block;          // block scheme only
+    int L, B, tall;
+    int G;                  // lanes per row
+    int zero_nf;
+    int x_vec_ok;           // x columns are 16-byte aligned
+    int block_shift;        // log2(block) if a power of two, else -1
+    int n_blk_in;           // ceil(n_in / block): block ids below this start inside x
+};
+
+// host: fill the parameter block for one launch (sdh_delta.hip)
+DeltaParams make_delta_params(const DeviceWeight & w, const DeltaLaunch & a);
+// host: lanes per row and 8-element steps per lane for the vector path; returns false if the
+// payload needs the scalar kernel
+bool delta_vector_shape(const DeltaParams & p, bool is_block, int * G, int * steps);
+
+__device__ __forceinline__ float h2f(uint16_t h) {
+    return __half2float(__ushort_as_half(h));
+}
+
+template <typename T> struct Vec8;     // 8 consecutive payload elements
+template <> struct Vec8<uint16_t> {    // f16 values or i16 indices: one 16-byte load
+    uint4 q;
+    __device__ __forceinline__ void load(const uint16_t * p) { q = *reinterpret_cast<const uint4 *>(p); }
+    __device__ __forceinline__ uint16_t get(int j) const {
+        const uint32_t w = (j < 2) ? q.x : (j < 4) ? q.y : (j < 6) ? q.z : q.w;
+        return (uint16_t) ((j & 1) ? (w >> 16) : (w & 0xFFFFu));
+    }
+};
+template <> struct Vec8<uint32_t> {    // f32 values or i32 indices: two 16-byte loads
+    uint4 a, b;
+    __device__ __forceinline__ void load(const uint32_t * p) {
+        a = *reinterpret_cast<const uint4 *>(p);
+        b = *reinterpret_cast<const uint4 *>(p + 4);
+    }
+    __device__ __forceinline__ uint32_t get(int j) const {
+        switch (j) {
+            case 0: return a.x; case 1: return a.y; case 2: return a.z; case 3: return a.w;
+            case 4: return b.x; case 5: return b.y; case 6: return b.z; default: return b.w;
+        }
+    }
+};
+
+template <typename VAL_T> __device__ __forceinline__ float val_to_f32(VAL_T raw);
+template <> __device__ __forceinline__ float val_to_f32<uint16_t>(uint16_t raw) { return h2f(raw); }
+template <> __device__ __forceinline__ float val_to_f32<uint32_t>(uint32_t raw) { return __uint_as_float(raw); }
+
+template <typename IDX_T> __device__ __forceinline__ int idx_to_i32(IDX_T raw);
+template <> __device__ __forceinline__ int idx_to_i32<uint16_t>(uint16_t raw) { return (int) (int16_t) raw; }
+template <> __device__ __forceinline__ int idx_to_i32<uint32_t>(uint32_t raw) { return (int) raw; }
+
+// One lane's share of one row's dot product on the vector path. STEPS = number of 8-element
+// steps each lane owns (compile time, so that every payload / index / activation load of the row
+// is issued before the first use: one HBM round trip for the payload and the indices, one L2
+// round trip for the gathered activations). STEPS == 0 selects a runtime loop over chunks of 4
+// steps for very long rows. Everything is branch-free: out-of-range steps and skipped blocks load
+// from a clamped (valid) address and their partial sum is discarded by a select, so hipcc keeps
+// all loads in flight. Requires Ktot % 8 == 0, (block a power of two >= 8 and n_in % 8 == 0 for
+// the block scheme) and 16-byte aligned x columns.
+template <typename IDX_T, typename VAL_T, bool BLOCK, int STEPS>
+__device__ __forceinline__ float delta_row_partial(const DeltaParams & p, const float * __restrict__ xt,
+                                                   int orow, bool row_ok, int l, int G) {
+    constexpr int NS = STEPS > 0 ? STEPS : 4;
+    const VAL_T * vrow = reinterpret_cast<const VAL_T *>(p.val) + (size_t) orow * p.Ktot;
+    const IDX_T * irow = reinterpret_cast<const IDX_T *>(p.idx) + (size_t) orow * (BLOCK ? p.nb : p.Ktot);
+    float acc = 0.0f;
+    const int chunk = G * 8 * NS;
+    for (int base = 0; base < (STEPS > 0 ? 1 : p.Ktot); base += chunk) {
+        Vec8<VAL_T> vv[NS];
+        bool ok[NS];
+        int e0[NS];
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const int e = base + (u * G + l) * 8;
+            ok[u] = row_ok & (e < p.Ktot);
+            e0[u] = ok[u] ? e : 0;
+        }
+        if constexpr (BLOCK) {
+            int blk[NS], off[NS];
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {       // block indices first: they head the dependent chain
+                const int bi = e0[u] >> p.block_shift;
+                off[u] = e0[u] & (p.block - 1);
+                blk[u] = idx_to_i32<IDX_T>(irow[bi]);
+            }
+#pragma unroll
+            for (int u = 0; u < NS; ++u) vv[u].load(vrow + e0[u]);
+            float4 xa[NS], xb[NS];
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                // valid iff 0 <= blk and blk*block < n_in  <=>  (unsigned) blk < ceil(n_in / block);
+                // the last block is clipped to n_in: with n_in % 8 == 0 an 8-run is all in or all out
+                const int raw = (blk[u] << p.block_shift) + off[u];
+                ok[u] = ok[u] & ((unsigned) blk[u] < (unsigned) p.n_blk_in) & (raw < p.n_in);
+                const int in0 = ok[u] ? raw : 0;
+                xa[u] = *reinterpret_cast<const float4 *>(xt + in0);
+                xb[u] = *reinterpret_cast<const float4 *>(xt + in0 + 4);
+            }
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                float ps = val_to_f32<VAL_T>(vv[u].get(0)) * xa[u].x;
+                ps += val_to_f32<VAL_T>(vv[u].get(1)) * xa[u].y;
+                ps += val_to_f32<VAL_T>(vv[u].get(2)) * xa[u].z;
+                ps += val_to_f32<VAL_T>(vv[u].get(3)) * xa[u].w;
+                ps += val_to_f32<VAL_T>(vv[u].get(4)) * xb[u].x;
+                ps += val_to_f32<VAL_T>(vv[u].get(5)) * xb[u].y;
+                ps += val_to_f32<VAL_T>(vv[u].get(6)) * xb[u].z;
+                ps += val_to_f32<VAL_T>(vv[u].get(7)) * xb[u].w;
+                acc += ok[u] ? ps : 0.0f;
+            }
+        } else {
+            Vec8<IDX_T> ii[NS];
+#pragma unroll
+            for (int u = 0; u < NS; ++u) ii[u].load(irow + e0[u]);
+#pragma unroll
+            for (int u = 0; u < NS; ++u) vv[u].load(vrow + e0[u]);
+            float xs[NS][8];
+            bool okj[NS][8];
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int i = idx_to_i32<IDX_T>(ii[u].get(j));
+                    okj[u][j] = ok[u] & ((unsigned) i < (unsigned) p.n_in);
+                    xs[u][j] = xt[okj[u][j] ? i : 0];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float pr = val_to_f32<VAL_T>(vv[u].get(j)) * xs[u][j];
+                    acc += okj[u][j] ? pr : 0.0f;
+                }
+            }
+        }
+    }
+    return acc;
+}
+
+// reduce over the G lanes that own a row (G a power of two, groups aligned); every lane of the
+// group ends with the sum
+__device__ __forceinline__ float group_reduce(float acc, int G) {
+    for (int m = G >> 1; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    return acc;
+}
+
+// scale (only if != 1, :645), count / optionally zero non-finite outputs (:363-392), store
+__device__ __forceinline__ void store_output(const DeltaParams & p, int o, int64_t t, float y, float scale) {
+    float out = (scale != 1.0f) ? (y * scale) : y;
+    if (!isfinite(out)) {
+        atomicAdd(p.nf, 1);
+        if (p.zero_nf) out = 0.0f;
+    }
+    p.y[o + t * p.ldy] = out;
+}
+
+} // namespace sdh

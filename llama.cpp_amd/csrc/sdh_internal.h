@@ -62,6 +62,10 @@ struct DeviceWeight {
     bool    w0_closed_form = false;   // depth 2, no perm2, perm1 bijective
     uint8_t *    pack_dev = nullptr;  // packed 16/32-bit base parameters (hot path)
     BasePackDesc pack;
+    // fused decode hand-off: [B][L] granules {value, epoch};
+    // epoch bumped per fused launch
+    uint8_t * handoff = nullptr;
+    unsigned epoch = 0;
     // accounting
     int64_t payload_bytes = 0;   // as stored in the GGUF
     // non-finite accounting: ring of per-call counters (no per-call memset on the hot path)
@@ -82,6 +86,7 @@ struct LibState {
     // staging for host-IO forwards
     float * hx = nullptr; size_t hx_bytes = 0;
     float * hy = nullptr; size_t hy_bytes = 0;
+    unsigned * census_ctr = nullptr;    // residency census of the fused decode kernel (sdh_decode.hip)
     // measurement hooks (sdh_profile_*): event pairs around the dominant kernel
     bool   prof_on = false;
     static constexpr int PROF_PAIRS = 4096;
@@ -106,6 +111,10 @@ struct DeltaLaunch {
     bool exact_order;
 };
 int launch_delta(const DeviceWeight & w, const DeltaLaunch & a, hipStream_t s);
+
+// Batch-1 decode with a base as ONE launch (sdh_decode.hip). Returns SDH_OK if launched, 1 if the
+// payload / call does not qualify (caller runs base + delta kernels instead), <0 on error.
+int launch_decode_fused(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s);
 
 int launch_w0_tile(const DeviceWeight & w, int64_t o0, int64_t o1, int64_t i0, int64_t i1,
                    float * out_dev, hipStream_t s);

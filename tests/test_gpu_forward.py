@@ -226,6 +226,38 @@ def test_full_size_config_properties(hip, cfg):
     assert np.array_equal(bits(yb), bits(O.forward(q, x[:1])))
 
 
+@pytest.mark.parametrize("cfg", ["cfg3_mistral_down_block32_k1536", "cfg2_gemma4b_gate_coo_k128",
+                                 "cfg4_mistral_gate_block16_k128", "cfg4_mistral_down_coo_k128",
+                                 "cfg1_gemma1b_gate_block16_k64", "cfg1_gemma1b_down_block16_k128"])
+def test_fused_decode_matches_two_launch_path(hip, cfg):
+    """Batch-1 decode with a base runs as one fused launch (base workgroups hand their output to the
+    residual waves through epoch-tagged granules). Same arithmetic, so it must be bit-identical to the
+    two-launch path, call after call with changing inputs (a stale granule would show up here)."""
+    p = config_payload(cfg)
+    w = hip.SeedDeltaWeight(p)
+    xs = make_x(p.n_in, 6, seed=21)
+    for i in range(6):
+        x = xs[i:i + 1]
+        y_fused = w.forward_host(x)
+        y_two = w.forward_host(x, hip.FWD_NO_FUSE)
+        assert np.array_equal(bits(y_fused), bits(y_two)), f"{cfg} call {i}"
+        assert w.nonfinite_count() == 0
+    check_fast(p, xs[5:6], y_fused, O.forward(p, xs[5:6], nth=8))
+    # many back-to-back launches without host synchronisation in between (device I/O)
+    torch = pytest.importorskip("torch")
+    xd = torch.from_numpy(xs).cuda()
+    yd = torch.zeros((6, p.n_out), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    sp = torch.cuda.current_stream().cuda_stream
+    for rep in range(50):
+        for i in range(6):
+            w.forward_device(xd[i].data_ptr(), p.n_in, 1, yd[i].data_ptr(), p.n_out, stream=sp)
+    torch.cuda.synchronize()
+    y_all = yd.cpu().numpy()
+    for i in range(6):
+        assert np.array_equal(bits(y_all[i:i + 1]), bits(w.forward_host(xs[i:i + 1], hip.FWD_NO_FUSE)))
+
+
 def test_device_io_path_matches_host_io(hip):
     torch = pytest.importorskip("torch")
     p = make_payload(1024, 512, scheme="block", K=64, block=32, base=True, seed=8)

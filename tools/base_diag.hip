@@ -5,6 +5,7 @@
 #include "../llama.cpp_amd/csrc/sdh_api.hip"
 #include "../llama.cpp_amd/csrc/sdh_base.hip"
 #include "../llama.cpp_amd/csrc/sdh_delta.hip"
+#include "../llama.cpp_amd/csrc/sdh_decode.hip"
 
 #include <algorithm>
 #include <cstdio>
@@ -63,7 +64,7 @@ int main() {
     for (int it = 0; it < ITERS; ++it) {
         const int p = it % NPAY;
         if (p == 0) CK(hipMemsetAsync(flush, it, FL, s));
-        if (sdh_forward(ws[p], xs[p], NIN, 1, y, NOUT, 0, s) != 0) { fprintf(stderr, "fwd: %s\n", sdh_last_error()); return 1; }
+        if (sdh_forward(ws[p], xs[p], NIN, 1, y, NOUT, SDH_FWD_NO_FUSE, s) != 0) { fprintf(stderr, "fwd: %s\n", sdh_last_error()); return 1; }
         CK(hipStreamSynchronize(s));
         CK(hipMemcpy(hdv, dbg, sizeof(hdv), hipMemcpyDeviceToHost));
         if (it < 32) continue;

@@ -185,5 +185,9 @@ int main(int argc, char ** argv) {
     printf("  stream read              : %7.2f  (%.0f GB/s)\n", t_stream, mb * 1e6 / t_stream / 1e3);
     printf("  stream + dependent gather: %7.2f  (%.0f GB/s)\n", t_gather, mb * 1e6 / t_gather / 1e3);
     printf("  sdh_forward (%s)   : %7.2f  (%.0f GB/s algorithmic)\n", with_base ? "base+block" : "block only", t_fwd, 13.189e6 / t_fwd / 1e3);
+    if (with_base) {
+        float t_nf = time_loop(s, iters, [&](int i) { int p = i % NPAY; sdh_forward(ws[p], xs[p], NIN, 1, ys[p], ROWS, SDH_FWD_NO_FUSE, s); });
+        printf("  sdh_forward two launches   : %7.2f  (%.0f GB/s algorithmic)\n", t_nf, 13.189e6 / t_nf / 1e3);
+    }
     return 0;
 }
