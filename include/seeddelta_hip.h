@@ -163,6 +163,12 @@ int sdh_w0_tile(sdh_weight * w, int64_t o0, int64_t o1, int64_t i0, int64_t i1,
  * resets both. sdh_profile_enable(0) stops recording. Not for use under graph capture. */
 int sdh_profile_enable(int on);
 int sdh_profile_read(double * total_ms, int64_t * launches);
+/* Span form, free of per-launch overhead: sdh_profile_span_begin records one hipEvent on `stream`;
+ * sdh_profile_span_end records a second one, waits for it, and returns the elapsed milliseconds
+ * and the number of sdh_forward calls issued in between. For an op that is one kernel per call
+ * (the fused decode launch) elapsed / launches is that kernel's back-to-back launch period. */
+int sdh_profile_span_begin(void * stream);
+int sdh_profile_span_end(void * stream, double * elapsed_ms, int64_t * forwards);
 
 #ifdef __cplusplus
 }

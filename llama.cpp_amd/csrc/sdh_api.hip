@@ -536,6 +536,7 @@ int sdh_forward(sdh_weight * h, const float * x, int64_t ldx, int64_t n_tokens,
     }
     w->seq++;
     w->last_stream = s;
+    ls.span_forwards++;
 
     if (host_io) {
         SDH_HIP_CHECK(hipMemcpy2DAsync(y, (size_t) ldy * 4, dy, (size_t) w->n_out * 4, (size_t) w->n_out * 4,
@@ -568,6 +569,30 @@ int sdh_profile_enable(int on) {
     }
     if (!on && s.prof_on) { int rc = prof_flush(s); if (rc != SDH_OK) return rc; }
     s.prof_on = on != 0;
+    return SDH_OK;
+}
+
+int sdh_profile_span_begin(void * stream) {
+    LibState & s = lib();
+    if (!s.inited) { set_error("sdh_init not called"); return SDH_ERR_NO_DEVICE; }
+    if (!s.span_ev[0]) {
+        SDH_HIP_CHECK(hipEventCreate(&s.span_ev[0]));
+        SDH_HIP_CHECK(hipEventCreate(&s.span_ev[1]));
+    }
+    s.span_forwards = 0;
+    SDH_HIP_CHECK(hipEventRecord(s.span_ev[0], stream ? (hipStream_t) stream : s.stream));
+    return SDH_OK;
+}
+
+int sdh_profile_span_end(void * stream, double * elapsed_ms, int64_t * forwards) {
+    LibState & s = lib();
+    if (!s.inited || !s.span_ev[0]) { set_error("sdh_profile_span_begin not called"); return SDH_ERR_INVALID; }
+    SDH_HIP_CHECK(hipEventRecord(s.span_ev[1], stream ? (hipStream_t) stream : s.stream));
+    SDH_HIP_CHECK(hipEventSynchronize(s.span_ev[1]));
+    float ms = 0.0f;
+    SDH_HIP_CHECK(hipEventElapsedTime(&ms, s.span_ev[0], s.span_ev[1]));
+    if (elapsed_ms) *elapsed_ms = (double) ms;
+    if (forwards) *forwards = s.span_forwards;
     return SDH_OK;
 }
 

@@ -94,6 +94,8 @@ struct LibState {
     int     prof_used = 0;              // pairs recorded and not yet read
     double  prof_ms = 0.0;              // accumulated from flushed pairs
     int64_t prof_n = 0;
+    hipEvent_t span_ev[2] = {nullptr, nullptr};   // sdh_profile_span_*
+    int64_t span_forwards = 0;          // sdh_forward calls since span_begin
 };
 LibState & lib();
 

@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "sdh_init", "sdh_abi_version", "sdh_last_error", "sdh_device_synchronize",
     "sdh_weight_create", "sdh_weight_destroy", "sdh_weight_op_kind", "sdh_weight_payload_bytes",
     "sdh_forward", "sdh_nonfinite_count", "sdh_w0_tile",
-    "sdh_profile_enable", "sdh_profile_read",
+    "sdh_profile_enable", "sdh_profile_read", "sdh_profile_span_begin", "sdh_profile_span_end",
 ]
 
 
@@ -107,6 +107,8 @@ def load_library(path: str = LIB_PATH):
                                 C.c_int, C.c_void_p]
     lib.sdh_profile_enable.argtypes = [C.c_int]
     lib.sdh_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.sdh_profile_span_begin.argtypes = [C.c_void_p]
+    lib.sdh_profile_span_end.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     _lib = lib
     return lib
 
@@ -135,6 +137,18 @@ def profile_read():
     """-> (total_ms, launches) of the dominant kernel since the last read (HIP events)."""
     ms, n = C.c_double(0.0), C.c_int64(0)
     _check(load_library().sdh_profile_read(C.byref(ms), C.byref(n)), "sdh_profile_read")
+    return ms.value, n.value
+
+
+def profile_span_begin(stream: int = 0):
+    _check(load_library().sdh_profile_span_begin(C.c_void_p(stream) if stream else None), "sdh_profile_span_begin")
+
+
+def profile_span_end(stream: int = 0):
+    """-> (elapsed_ms, forwards) between the two HIP events recorded on `stream`."""
+    ms, n = C.c_double(0.0), C.c_int64(0)
+    _check(load_library().sdh_profile_span_end(C.c_void_p(stream) if stream else None, C.byref(ms), C.byref(n)),
+           "sdh_profile_span_end")
     return ms.value, n.value
 
 
