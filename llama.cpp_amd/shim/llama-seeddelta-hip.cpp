@@ -1,0 +1,329 @@
+// llama-seeddelta-hip.cpp — drop-in replacement for the reference's src/llama-seeddelta.cpp.
+//
+// A maintainer swaps this file for src/llama-seeddelta.cpp in the llama target:
+// it defines the same four graph constructors declared in src/llama-seeddelta.h:41-84, with the same
+// argument meaning, node shape ([n_out, n_tokens] F32), source order and userdata (w_ref), so
+// src/llama-graph.cpp:681-703 and src/llama-context.cpp need no change. The difference is what the
+// node's callback does: instead of the CPU loops of src/llama-seeddelta.cpp:582/:714/:1014/:1178 it
+// hands the payload to libseeddelta_hip.so (include/seeddelta_hip.h) once, keeps it resident in
+// HBM, and forwards every evaluation to sdh_forward().
+//
+// Host-side responsibilities kept here, because they need ggml types the C ABI does not see:
+//   - activations may be F16 or strided (the reference reads them through read_x_f16_or_f32,
+//     src/llama-seeddelta.cpp:42-50): they are widened / packed to contiguous F32 first;
+//   - the non-finite repair of src/llama-seeddelta.cpp:363-392: an output that is not finite is
+//     replaced by the dense row·x product in double when the dense weight is still present on the
+//     host and x is at least 2-D, else by 0.0f. The GPU reports how many outputs were non-finite,
+//     so the repair scan only runs when that count is non-zero.
+//
+// The reference's LLAMA_SEEDDELTA_DEBUG_* comparison paths (src/llama-seeddelta.cpp:81-203,
+// :394-458) are diagnostics of the CPU op and are not reproduced.
+#include "llama-seeddelta.h"
+
+#include "ggml.h"
+#include "ggml-backend.h"
+
+#include "seeddelta_hip.h"
+
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+// ---- payload cache: one device-resident sdh_weight per distinct set of payload tensors --------
+struct payload_key {
+    const void * data[10];
+    int64_t      n_in, n_out;
+    bool operator==(const payload_key & o) const {
+        return std::memcmp(data, o.data, sizeof(data)) == 0 && n_in == o.n_in && n_out == o.n_out;
+    }
+};
+struct payload_key_hash {
+    size_t operator()(const payload_key & k) const {
+        uint64_t h = 0x9e3779b97f4a7c15ull ^ (uint64_t) k.n_in * 0x100000001b3ull ^ (uint64_t) k.n_out;
+        for (const void * p : k.data) {
+            h ^= (uint64_t) (uintptr_t) p + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+        }
+        return (size_t) h;
+    }
+};
+
+std::mutex g_mu;
+std::unordered_map<payload_key, sdh_weight *, payload_key_hash> g_payloads;
+bool g_inited = false;
+std::atomic<int64_t> g_nonfinite_total{0};
+std::atomic_flag g_nonfinite_warned = ATOMIC_FLAG_INIT;
+
+[[noreturn]] void die(const char * what) {
+    std::fprintf(stderr, "llama-seeddelta-hip: %s: %s\n", what, sdh_last_error());
+    std::abort();
+}
+
+bool on_host(const ggml_tensor * t) {
+    const ggml_tensor * root = t->view_src ? t->view_src : t;
+    return !root->buffer || ggml_backend_buffer_is_host(root->buffer);
+}
+
+sdh_tensor view_of(const ggml_tensor * t) {
+    sdh_tensor v;
+    std::memset(&v, 0, sizeof(v));
+    if (!t) {
+        return v;
+    }
+    if (!t->data || !on_host(t)) {
+        std::fprintf(stderr, "llama-seeddelta-hip: payload tensor '%s' is not readable host memory\n", ggml_get_name(t));
+        std::abort();
+    }
+    v.data   = t->data;
+    v.type   = (int32_t) t->type;   // sdh_type is numerically ggml_type
+    v.n_dims = ggml_n_dims(t);
+    for (int i = 0; i < 4; ++i) {
+        v.ne[i] = t->ne[i];
+        v.nb[i] = (int64_t) t->nb[i];
+    }
+    return v;
+}
+
+// Sources of the node, in the order the constructors below store them (same as the reference).
+struct node_payload {
+    const ggml_tensor * x = nullptr;
+    const ggml_tensor * d_idx = nullptr, * d_val = nullptr, * b_idx = nullptr, * b_val = nullptr;
+    const ggml_tensor * row_scale = nullptr;
+    const ggml_tensor * d1 = nullptr, * d2 = nullptr, * d3 = nullptr, * p1 = nullptr, * p2 = nullptr;
+};
+
+template <bool BASE, bool BLOCK>
+node_payload sources_of(const ggml_tensor * dst) {
+    node_payload n;
+    n.x = dst->src[0];
+    int s = 1;
+    if (BASE) {
+        n.d1 = dst->src[1]; n.d2 = dst->src[2]; n.d3 = dst->src[3];
+        n.p1 = dst->src[4]; n.p2 = dst->src[5];
+        s = 6;
+    }
+    (BLOCK ? n.b_idx : n.d_idx) = dst->src[s];
+    (BLOCK ? n.b_val : n.d_val) = dst->src[s + 1];
+    n.row_scale = dst->src[s + 2];
+    return n;
+}
+
+sdh_weight * resident_payload(const node_payload & n) {
+    const ggml_tensor * idx = n.b_idx ? n.b_idx : n.d_idx;
+    payload_key key;
+    const ggml_tensor * all[10] = { n.d_idx, n.d_val, n.b_idx, n.b_val, n.row_scale, n.d1, n.d2, n.d3, n.p1, n.p2 };
+    for (int i = 0; i < 10; ++i) {
+        key.data[i] = all[i] ? all[i]->data : nullptr;
+    }
+    key.n_in  = n.x->ne[0];
+    key.n_out = idx->ne[1];
+
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (!g_inited) {
+        const char * dev = std::getenv("SEEDDELTA_HIP_DEVICE");
+        if (sdh_init(dev ? std::atoi(dev) : 0) != SDH_OK) {
+            die("sdh_init");
+        }
+        g_inited = true;
+    }
+    auto it = g_payloads.find(key);
+    if (it != g_payloads.end()) {
+        return it->second;
+    }
+    sdh_weight_desc d;
+    std::memset(&d, 0, sizeof(d));
+    d.n_in = key.n_in;
+    d.n_out = key.n_out;
+    d.d_idx = view_of(n.d_idx);   d.d_val = view_of(n.d_val);
+    d.b_idx = view_of(n.b_idx);   d.b_val = view_of(n.b_val);
+    d.row_scale  = view_of(n.row_scale);
+    d.base_d1    = view_of(n.d1); d.base_d2 = view_of(n.d2); d.base_d3 = view_of(n.d3);
+    d.base_perm1 = view_of(n.p1); d.base_perm2 = view_of(n.p2);
+    sdh_weight * w = nullptr;
+    if (sdh_weight_create(&d, &w) != SDH_OK) {
+        die("sdh_weight_create");
+    }
+    g_payloads.emplace(key, w);
+    return w;
+}
+
+// ---- activations: contiguous F32 columns -------------------------------------------------------
+thread_local std::vector<float> t_xpack;
+
+const float * packed_x(const ggml_tensor * x, int64_t n_in, int64_t n_tok, int64_t * ldx) {
+    if (x->type == GGML_TYPE_F32 && x->nb[0] == sizeof(float) && x->nb[1] % sizeof(float) == 0) {
+        *ldx = n_tok > 1 ? (int64_t) (x->nb[1] / sizeof(float)) : n_in;
+        return (const float *) x->data;
+    }
+    t_xpack.resize((size_t) (n_in * n_tok));
+    const uint8_t * base = (const uint8_t *) x->data;
+    for (int64_t t = 0; t < n_tok; ++t) {
+        for (int64_t i = 0; i < n_in; ++i) {
+            const uint8_t * p = base + i * x->nb[0] + t * x->nb[1];
+            t_xpack[(size_t) (t * n_in + i)] =
+                x->type == GGML_TYPE_F16 ? ggml_fp16_to_fp32(*(const ggml_fp16_t *) p) : *(const float *) p;
+        }
+    }
+    *ldx = n_in;
+    return t_xpack.data();
+}
+
+// ---- non-finite repair (semantics of src/llama-seeddelta.cpp:294-392) -----------------------------
+thread_local std::vector<float> t_wrow;
+
+bool dense_row_dot(const ggml_tensor * w, const ggml_tensor * x, int64_t o, int64_t t, float * out) {
+    if (!w || !w->data || !x->data || !on_host(w) || !on_host(x)) {
+        return false;
+    }
+    if (ggml_n_dims(x) < 2 || ggml_n_dims(w) != 2) {
+        return false;   // a single-token activation is 1-D for ggml: the reference declines here too
+    }
+    const int64_t n_in = x->ne[0];
+    if (w->ne[0] != n_in || o < 0 || o >= w->ne[1] || t < 0 || t >= x->ne[1]) {
+        return false;
+    }
+    if ((size_t) (o + 1) * w->nb[1] > ggml_nbytes(w)) {
+        return false;
+    }
+    const uint8_t * row = (const uint8_t *) w->data + (size_t) o * w->nb[1];
+    t_wrow.resize((size_t) n_in);
+    if (w->type == GGML_TYPE_F32) {
+        for (int64_t i = 0; i < n_in; ++i) t_wrow[(size_t) i] = *(const float *) (row + i * w->nb[0]);
+    } else if (w->type == GGML_TYPE_F16) {
+        for (int64_t i = 0; i < n_in; ++i) t_wrow[(size_t) i] = ggml_fp16_to_fp32(*(const ggml_fp16_t *) (row + i * w->nb[0]));
+    } else {
+        const ggml_type_traits * tr = ggml_get_type_traits(w->type);
+        if (!tr || !tr->to_float) {
+            return false;
+        }
+        tr->to_float(row, t_wrow.data(), n_in);
+    }
+    const uint8_t * xc = (const uint8_t *) x->data + (size_t) t * x->nb[1];
+    double acc = 0.0;
+    for (int64_t i = 0; i < n_in; ++i) {
+        const uint8_t * p = xc + i * x->nb[0];
+        const float xv = x->type == GGML_TYPE_F16 ? ggml_fp16_to_fp32(*(const ggml_fp16_t *) p) : *(const float *) p;
+        acc += (double) t_wrow[(size_t) i] * (double) xv;
+    }
+    *out = (float) acc;
+    return std::isfinite(*out);
+}
+
+void repair_nonfinite(ggml_tensor * dst, const ggml_tensor * w_ref, const ggml_tensor * x, int64_t n_out, int64_t n_tok) {
+    for (int64_t t = 0; t < n_tok; ++t) {
+        for (int64_t o = 0; o < n_out; ++o) {
+            float * y = (float *) ((uint8_t *) dst->data + o * dst->nb[0] + t * dst->nb[1]);
+            if (std::isfinite(*y)) {
+                continue;
+            }
+            float fixed = 0.0f;
+            const bool dense = dense_row_dot(w_ref, x, o, t, &fixed);
+            *y = dense ? fixed : 0.0f;
+            g_nonfinite_total.fetch_add(1, std::memory_order_relaxed);
+            if (!g_nonfinite_warned.test_and_set(std::memory_order_relaxed)) {
+                const char * name = w_ref ? ggml_get_name(w_ref) : "<null>";
+                std::fprintf(stderr, "llama-seeddelta-hip: non-finite output for tensor '%s'; %s\n", name,
+                             dense ? "using the dense weight row instead" : "writing 0.0 (dense weight unavailable)");
+            }
+        }
+    }
+}
+
+// ---- the custom-op callback ---------------------------------------------------------------------
+template <bool BASE, bool BLOCK>
+void seeddelta_hip_op(ggml_tensor * dst, int ith, int /*nth*/, void * userdata) {
+    if (ith != 0) {
+        return;   // one host thread submits; the GPU is the parallel part
+    }
+    const ggml_tensor * w_ref = (const ggml_tensor *) userdata;
+    const node_payload n = sources_of<BASE, BLOCK>(dst);
+    const int64_t n_in  = n.x->ne[0];
+    const int64_t n_tok = n.x->ne[1];
+    const int64_t n_out = (BLOCK ? n.b_idx : n.d_idx)->ne[1];
+    if (n_tok <= 0 || n_out <= 0) {
+        return;
+    }
+    GGML_ASSERT(dst->type == GGML_TYPE_F32 && dst->nb[0] == sizeof(float) && dst->nb[1] % sizeof(float) == 0);
+
+    sdh_weight * w = resident_payload(n);
+    int64_t ldx = n_in;
+    const float * xs = packed_x(n.x, n_in, n_tok, &ldx);
+    const int64_t ldy = n_tok > 1 ? (int64_t) (dst->nb[1] / sizeof(float)) : n_out;
+    if (sdh_forward(w, xs, ldx, n_tok, (float *) dst->data, ldy, SDH_FWD_HOST_IO, nullptr) != SDH_OK) {
+        die("sdh_forward");
+    }
+    const int64_t bad = sdh_nonfinite_count(w);
+    if (bad < 0) {
+        die("sdh_nonfinite_count");
+    }
+    if (bad > 0) {
+        repair_nonfinite(dst, w_ref, n.x, n_out, n_tok);
+    }
+}
+
+template <bool BASE, bool BLOCK>
+ggml_tensor * make_node(ggml_context * ctx, ggml_tensor * x, ggml_tensor * w_ref, ggml_tensor ** args, int n_args, const ggml_tensor * idx) {
+    // n_tasks = 1: the callback is a submit-and-wait, extra ggml worker threads would only spin
+    return ggml_custom_4d(ctx, GGML_TYPE_F32, idx->ne[1], x->ne[1], 1, 1, args, n_args,
+                          seeddelta_hip_op<BASE, BLOCK>, 1, w_ref);
+}
+
+} // namespace
+
+// Exported for teardown paths and tests: frees every device-resident payload.
+extern "C" void llama_seeddelta_hip_release_all(void) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    for (auto & kv : g_payloads) {
+        sdh_weight_destroy(kv.second);
+    }
+    g_payloads.clear();
+}
+
+extern "C" int64_t llama_seeddelta_hip_nonfinite_total(void) {
+    return g_nonfinite_total.load(std::memory_order_relaxed);
+}
+
+// ---- the four constructors of src/llama-seeddelta.h ------------------------------------------------
+ggml_tensor * llama_seeddelta_mul_mat(
+        ggml_context * ctx, ggml_tensor * x, ggml_tensor * w_ref,
+        ggml_tensor * d_idx, ggml_tensor * d_val, ggml_tensor * row_scale) {
+    GGML_ASSERT(d_idx != nullptr && d_val != nullptr);
+    ggml_tensor * args[4] = { x, d_idx, d_val, row_scale };
+    return make_node<false, false>(ctx, x, w_ref, args, 4, d_idx);
+}
+
+ggml_tensor * llama_seeddelta_mul_mat_block(
+        ggml_context * ctx, ggml_tensor * x, ggml_tensor * w_ref,
+        ggml_tensor * b_idx, ggml_tensor * b_val, ggml_tensor * row_scale) {
+    GGML_ASSERT(b_idx != nullptr && b_val != nullptr);
+    ggml_tensor * args[4] = { x, b_idx, b_val, row_scale };
+    return make_node<false, true>(ctx, x, w_ref, args, 4, b_idx);
+}
+
+ggml_tensor * llama_seeddelta_mul_mat_base(
+        ggml_context * ctx, ggml_tensor * x, ggml_tensor * w_ref,
+        ggml_tensor * base_d1, ggml_tensor * base_d2, ggml_tensor * base_d3,
+        ggml_tensor * base_perm1, ggml_tensor * base_perm2,
+        ggml_tensor * d_idx, ggml_tensor * d_val, ggml_tensor * row_scale) {
+    GGML_ASSERT(base_d1 != nullptr);
+    GGML_ASSERT(d_idx != nullptr && d_val != nullptr);
+    ggml_tensor * args[9] = { x, base_d1, base_d2, base_d3, base_perm1, base_perm2, d_idx, d_val, row_scale };
+    return make_node<true, false>(ctx, x, w_ref, args, 9, d_idx);
+}
+
+ggml_tensor * llama_seeddelta_mul_mat_base_block(
+        ggml_context * ctx, ggml_tensor * x, ggml_tensor * w_ref,
+        ggml_tensor * base_d1, ggml_tensor * base_d2, ggml_tensor * base_d3,
+        ggml_tensor * base_perm1, ggml_tensor * base_perm2,
+        ggml_tensor * b_idx, ggml_tensor * b_val, ggml_tensor * row_scale) {
+    GGML_ASSERT(base_d1 != nullptr);
+    GGML_ASSERT(b_idx != nullptr && b_val != nullptr);
+    ggml_tensor * args[9] = { x, base_d1, base_d2, base_d3, base_perm1, base_perm2, b_idx, b_val, row_scale };
+    return make_node<true, true>(ctx, x, w_ref, args, 9, b_idx);
+}

@@ -16,6 +16,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "liboracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libsdref.so")
+SHIM_SO = os.path.join(HERE, "_ref", "libsdshim.so")   # same harness + ggml, op TU = llama.cpp_amd/shim
 
 TYPE_OF_DTYPE = {np.dtype(np.float32): 0, np.dtype(np.float16): 1, np.dtype(np.int16): 25, np.dtype(np.int32): 26}
 SDO_Q8_0 = 8
@@ -66,6 +67,13 @@ def build_oracle(force: bool = False) -> None:
         subprocess.check_call(["make", "-C", HERE, "-j8", "ref"], stdout=subprocess.DEVNULL)
 
 
+def build_shim() -> None:
+    """Compile oracle/_ref/libsdshim.so (needs /root/reference for the ggml headers/objects and the
+    built libseeddelta_hip.so to link against)."""
+    if os.path.exists("/root/reference/src/llama-seeddelta.h"):
+        subprocess.check_call(["make", "-C", HERE, "-j8", "shim"], stdout=subprocess.DEVNULL)
+
+
 _lib = None
 _ref = None
 
@@ -108,6 +116,40 @@ def ref_lib():
         _ref.sdref_fp32_to_fp16.argtypes = [C.c_float]
         _ref.sdref_fp32_to_fp16.restype = C.c_uint16
     return _ref
+
+
+_shim = None
+
+
+def shim_available() -> bool:
+    return os.path.exists(SHIM_SO)
+
+
+def shim_lib():
+    """The reference harness with the reference's op TU swapped for the HIP shim (needs a GPU at
+    run time; libseeddelta_hip.so must already be loaded so torch's HIP runtime is the one used)."""
+    global _shim
+    if _shim is None:
+        _shim = C.CDLL(SHIM_SO)
+        _shim.sdref_run.argtypes = [C.c_int, C.POINTER(SdoOpArgs), C.c_int]
+        _shim.sdref_run.restype = C.c_int
+        _shim.llama_seeddelta_hip_release_all.restype = None
+        _shim.llama_seeddelta_hip_nonfinite_total.restype = C.c_int64
+    return _shim
+
+
+def forward_shim(payload, x: np.ndarray, nth: int = 1, w_ref_q8=None) -> np.ndarray:
+    """Evaluate through the drop-in TU: reference constructors -> ggml custom op -> C ABI -> GPU."""
+    y = np.full((x.shape[0], payload.n_out), np.nan, dtype=np.float32)
+    a = _args(payload, x, y, w_ref_q8)
+    lib = shim_lib()
+    try:
+        rc = lib.sdref_run(payload.kind, C.byref(a), nth)
+    finally:
+        lib.llama_seeddelta_hip_release_all()    # numpy buffers are reused across cases
+    if rc != 0:
+        raise RuntimeError(f"sdref_run (shim) failed: {rc}")
+    return y
 
 
 def _args(payload, x: np.ndarray, y: np.ndarray, w_ref_q8=None) -> SdoOpArgs:

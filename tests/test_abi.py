@@ -82,3 +82,19 @@ def test_no_silent_fallback_without_gpu():
         seeddelta.init(0)
     with pytest.raises(seeddelta.SeedDeltaError):
         seeddelta.SeedDeltaWeight(make_payload(64, 64))
+
+
+def test_shim_library_defines_the_reference_constructors():
+    """oracle/_ref/libsdshim.so (built where /root/reference exists) must define the four
+    constructors of src/llama-seeddelta.h:41-84 and bind the C ABI rather than carry CPU loops."""
+    import subprocess
+    import oracle_py as O
+    if not O.shim_available():
+        pytest.skip("shim test library not built (needs /root/reference at build time)")
+    defined = subprocess.run(["nm", "-D", "--defined-only", "-C", O.SHIM_SO], capture_output=True, text=True).stdout
+    for name in ("llama_seeddelta_mul_mat(", "llama_seeddelta_mul_mat_block(", "llama_seeddelta_mul_mat_base(",
+                 "llama_seeddelta_mul_mat_base_block(", "llama_seeddelta_hip_release_all"):
+        assert name in defined, name
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", O.SHIM_SO], capture_output=True, text=True).stdout
+    for name in ("sdh_init", "sdh_weight_create", "sdh_forward", "sdh_nonfinite_count"):
+        assert name in undefined, name
