@@ -52,6 +52,9 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--host-io", action="store_true",
+                    help="also time the PCIe-inclusive boundary (host x in, host y out, one sync per call: what "
+                         "the shim pays per graph node); reported as a separate field, never as value")
     return ap.parse_args()
 
 
@@ -202,6 +205,19 @@ def main():
                 "kernel": kname, "avg_kernel_us": dur_s * 1e6, "launches": n, "timing": how,
                 "algorithmic_bytes_per_launch": alg_bytes}
 
+    host_io = None
+    if args.host_io and rank == 0:
+        xh = [x.cpu().numpy() for x in xs]
+        for i in range(NP):
+            weights[i].forward_host(xh[i])
+        n_h, th = 0, time.perf_counter()
+        while time.perf_counter() - th < 2.0:
+            for i in range(NP):
+                weights[i].forward_host(xh[i])
+            n_h += NP
+        host_io = {"value": n_h * T / (time.perf_counter() - th), "unit": "tok/s",
+                   "note": "SDH_FWD_HOST_IO: pageable host x -> device, kernel, y -> host, synchronous per call"}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.workload, T, args.cpu_seconds)
@@ -218,6 +234,8 @@ def main():
                        "parallelism": "replicas only" if world > 1 else "single GPU"},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if host_io is not None:
+            line["pcie_inclusive"] = host_io
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist
