@@ -155,6 +155,72 @@ int64_t sdh_nonfinite_count(sdh_weight * w);
 int sdh_w0_tile(sdh_weight * w, int64_t o0, int64_t o1, int64_t i0, int64_t i1,
                 float * out, int flags, void * stream);
 
+/* ---- scan: the builder's candidate evaluation (tools/seeddelta-build) ------------------------------
+ * One sdh_scan is one `llama-seeddelta-build` process as scripts/seeddelta-layer-scan.py:215-262
+ * launches it: a std::mt19937 seeded with --seed (tools/seeddelta-build/sd_build.cpp:260) that every
+ * tensor evaluated afterwards draws from, in the builder's order. A candidate is one (tensor, scheme,
+ * K[, base][, row_scale]) trial = one call of the run_trial lambda (sd_build.cpp:463-800).          */
+typedef struct sdh_dense sdh_dense;   /* opaque: a dense FFN weight resident in HBM in its stored type */
+typedef struct sdh_scan  sdh_scan;    /* opaque: RNG stream + the last candidate's outputs on device   */
+
+/* Upload a dense weight W [n_in, n_out] (F32, F16 or Q8_0; ne[0] = n_in; rows may be strided by
+ * nb[1]). Replaces the per-row read_column_f32 of tools/seeddelta-build/sd_eval.cpp:20-40 (Q8_0 rule:
+ * ggml/src/ggml-quants.c:401-414): kernels dequantise on the fly, bit-exactly. */
+int     sdh_dense_create(const sdh_tensor * W, sdh_dense ** out);
+void    sdh_dense_destroy(sdh_dense * W);
+int64_t sdh_dense_bytes(const sdh_dense * W);      /* bytes as stored (the scan's algorithmic bytes) */
+
+typedef struct sdh_scan_params {
+    int32_t scheme;             /* 0 = COO, 1 = block                     (--scheme)                    */
+    int32_t kind;               /* 0 ffn_gate, 1 ffn_up, 2 ffn_down       (selects the proxy variant)   */
+    int64_t K;                  /* residual budget per output row         (--K / policy K)              */
+    int64_t block;              /* block length for scheme 1              (--block)                     */
+    int32_t write_base;         /* fit and use the XOR-circulant base     (--base)                      */
+    int32_t write_row_scale;    /* least-squares row scale                (--row-scale)                 */
+    int64_t base_max_samples;   /* (--base-max-samples, default 2048)                                   */
+    int32_t base_perm_trials;   /* (--base-perm-trials, builder default 1, layer-scan passes 4)         */
+    int32_t want_proxy;         /* evaluate the FFN proxy when the builder would (COO, no base, eval_x>0) */
+    int64_t eval_cols;          /* (--eval-cols)                                                        */
+    int64_t eval_x;             /* (--eval-x)                                                           */
+    int32_t proxy_seed;         /* seed + 101*layer + {1,2,3}             (sd_build.cpp:1032)            */
+    int32_t reserved;
+} sdh_scan_params;
+
+/* What one report.json entry is computed from (tools/seeddelta-build/sd_report.cpp:112-288). Metric
+ * vectors are {rel_l2_mean, rel_l2_p95, cos_mean, cos_p05, norm_ratio_mean} (struct eval_metrics,
+ * include/sd_eval.h:23-29); cost = {L, B, ops_dense, ops_base, ops_delta, ops_row_scale, ops_total,
+ * ops_ratio} (sd_cost.cpp:7-40); proxy = {cos_mean, cos_p05, l2_mean, l2_p95, log_norm_ratio_mean,
+ * log_norm_ratio_p95, eval_x, eval_out} (sd_ffn_proxy.cpp:238-245). */
+typedef struct sdh_scan_result {
+    int64_t K_eff;              /* entries per row actually kept (block scheme: keep*block)              */
+    int64_t n_blocks;           /* ceil(K / block)                                                       */
+    int64_t L, B;               /* base dims, 0 when no base                                             */
+    int32_t has_x;
+    int32_t proxy_available;
+    double  em[5];              /* weight-space metrics   (eval_*_residual, sd_eval.cpp:118-995)         */
+    double  em_x[5];            /* activation-space       (eval_seeddelta_x[_block], sd_eval.cpp:997-1419) */
+    double  cost[8];
+    double  proxy[8];
+    double  gpu_ms;             /* device time of this candidate (HIP events on the library stream)      */
+} sdh_scan_result;
+
+int  sdh_scan_create(uint32_t seed, sdh_scan ** out);
+void sdh_scan_destroy(sdh_scan * s);
+/* Evaluate one candidate on W. Wg/Wu/Wd (the layer's three dense weights) are only read by the FFN
+ * proxy and may be NULL. Draws from the scan's RNG exactly as the builder does (base fit, then the
+ * eval row sample, then the eval-x row sample and Gaussian activations). Blocks until done. */
+int  sdh_scan_tensor(sdh_scan * s, const sdh_dense * W, const sdh_dense * Wg, const sdh_dense * Wu,
+                     const sdh_dense * Wd, const sdh_scan_params * p, sdh_scan_result * out);
+/* Advance the RNG as sdh_scan_tensor would for a tensor of these dims, without touching the GPU:
+ * lets a rank that owns (layer, ffn_up) reproduce the stream position after ffn_gate (sharding). */
+int  sdh_scan_skip(sdh_scan * s, int64_t n_in, int64_t n_out, const sdh_scan_params * p);
+/* Copy out what the last sdh_scan_tensor produced (any pointer may be NULL): idx int32 [n_out][K_eff]
+ * or [n_out][n_blocks]; val f32 [n_out][K_eff] or [n_out][n_blocks][block]; row_scale f32 [n_out];
+ * base arrays [B][L] (d2, h2 f32; perm1, perm1_inv int32) — the staging the builder packs into the
+ * GGUF (sd_build.cpp:1104-1236). */
+int  sdh_scan_fetch(sdh_scan * s, int32_t * idx, float * val, float * row_scale,
+                    float * d2, float * h2, int32_t * perm1, int32_t * perm1_inv);
+
 /* ---- measurement hooks (no counterpart in the reference; used by bench.py) -------------------
  * sdh_profile_enable(1): from now on every sdh_forward brackets its dominant kernel (the
  * residual/epilogue kernel that streams the payload) with a pair of hipEvents recorded on the

@@ -117,6 +117,38 @@ static void launch_reg(const DeviceWeight & w, const float * x, int64_t ldx, int
     }
 }
 
+// generic launcher on plain f32 / i32 parameter arrays (any power-of-two L that fits LDS); also used
+// by the scan pipeline for the freshly fitted base (sdh_scan.hip)
+int launch_base_apply_generic(const float * x, int64_t ldx, int n_in, int L, int B, bool tall,
+                              const float * d1, const float * d2, const float * d3, const int * p1, const int * p2,
+                              int64_t T, float * v, hipStream_t s) {
+    if (T <= 0) return SDH_OK;
+    if (T > 65535) { set_error("base: token chunk %lld exceeds grid limit", (long long) T); return SDH_ERR_UNSUPPORTED; }
+    const size_t lds = (size_t) 2 * L * sizeof(float);
+    if (lds > 160 * 1024) {
+        set_error("base block length L=%d needs %zu B of LDS (max 163840)", L, lds);
+        return SDH_ERR_UNSUPPORTED;
+    }
+    dim3 grid((unsigned) B, (unsigned) T);
+    if (L >= 2048) {
+        constexpr int TH = 1024;
+        static bool attr_set = false;
+        if (!attr_set) {
+            SDH_HIP_CHECK(hipFuncSetAttribute((const void *) base_apply_lds_kernel<TH>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(base_apply_lds_kernel<TH>, grid, dim3(TH), lds, s, x, ldx, n_in, L, B, tall ? 1 : 0,
+                           d1, d2, d3, p1, p2, v);
+    } else {
+        constexpr int TH = 256;
+        hipLaunchKernelGGL(base_apply_lds_kernel<TH>, grid, dim3(TH), lds, s, x, ldx, n_in, L, B, tall ? 1 : 0,
+                           d1, d2, d3, p1, p2, v);
+    }
+    SDH_HIP_CHECK(hipGetLastError());
+    return SDH_OK;
+}
+
 int launch_base_apply(const DeviceWeight & w, const float * x, int64_t ldx, int64_t T,
                       float * v, hipStream_t s) {
     const int L = (int) w.L;
@@ -127,29 +159,8 @@ int launch_base_apply(const DeviceWeight & w, const float * x, int64_t ldx, int6
         case 2048: launch_reg<3>(w, x, ldx, T, v, s); break;
         case 4096: launch_reg<4>(w, x, ldx, T, v, s); break;
         case 8192: launch_reg<5>(w, x, ldx, T, v, s); break;
-        default: {
-            const size_t lds = (size_t) 2 * L * sizeof(float);
-            if (lds > 160 * 1024) {
-                set_error("base block length L=%d needs %zu B of LDS (max 163840)", L, lds);
-                return SDH_ERR_UNSUPPORTED;
-            }
-            dim3 grid((unsigned) w.B, (unsigned) T);
-            if (L >= 2048) {
-                constexpr int TH = 1024;
-                static bool attr_set = false;
-                if (!attr_set) {
-                    SDH_HIP_CHECK(hipFuncSetAttribute((const void *) base_apply_lds_kernel<TH>,
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                    attr_set = true;
-                }
-                hipLaunchKernelGGL(base_apply_lds_kernel<TH>, grid, dim3(TH), lds, s, x, ldx, (int) w.n_in, L,
-                                   (int) w.B, w.tall ? 1 : 0, w.d1, w.d2, w.d3, w.p1, w.p2, v);
-            } else {
-                constexpr int TH = 256;
-                hipLaunchKernelGGL(base_apply_lds_kernel<TH>, grid, dim3(TH), lds, s, x, ldx, (int) w.n_in, L,
-                                   (int) w.B, w.tall ? 1 : 0, w.d1, w.d2, w.d3, w.p1, w.p2, v);
-            }
-        }
+        default:
+            return launch_base_apply_generic(x, ldx, (int) w.n_in, L, (int) w.B, w.tall, w.d1, w.d2, w.d3, w.p1, w.p2, T, v, s);
     }
     SDH_HIP_CHECK(hipGetLastError());
     return SDH_OK;

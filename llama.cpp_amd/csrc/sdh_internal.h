@@ -104,6 +104,10 @@ LibState & lib();
 int launch_base_apply(const DeviceWeight & w, const float * x, int64_t ldx, int64_t T,
                       float * v, hipStream_t s);
 
+int launch_base_apply_generic(const float * x, int64_t ldx, int n_in, int L, int B, bool tall,
+                              const float * d1, const float * d2, const float * d3, const int * p1, const int * p2,
+                              int64_t T, float * v, hipStream_t s);
+
 struct DeltaLaunch {
     const float * x; int64_t ldx; int64_t T;
     float * y; int64_t ldy;

@@ -1,0 +1,966 @@
+// sdh_scan.hip — the builder's candidate evaluation as a GPU pipeline (gfx950).
+//
+// One candidate = one run_trial of the reference builder (tools/seeddelta-build/sd_build.cpp:463-800)
+// on one dense FFN weight: [fit the XOR-circulant base] -> per output row: residual, top-K / top-block
+// selection, least-squares row scale -> weight-space metrics on sampled rows -> activation-space
+// metrics on Gaussian x -> [FFN proxy]. The dense weight stays in HBM in its stored type (Q8_0 split
+// into an int8 plane and an fp16 scale plane at upload) and is dequantised on the fly with the
+// reference's rule (q * fp32(d)), so every value a kernel sees is the value the CPU builder sees.
+//
+// What is exact and what is not:
+//   * base fit: each thread owns one XOR bin u and adds its samples in sample order — the same
+//     order the CPU loop produces for that bin — so sum / sum2 / wgt, hence h2, d2 and the chosen
+//     perm, are bit-identical (sd_eval.cpp:486-555);
+//   * selection: keys are the fp32 scores' bit patterns (COO) or sequentially accumulated double
+//     block energies (block), so the selected sets are identical; equal scores are ordered by
+//     ascending index (the reference leaves tie order to std::sort);
+//   * sums of doubles over a whole row (row-scale LSQ, metric norms and dots) are tree-reduced, so
+//     they agree with the CPU's sequential sums to ~1e-15 relative, not bit-for-bit.
+//
+// Host side: libstdc++'s std::mt19937 / std::shuffle / std::normal_distribution<float> — the same
+// library routines the reference calls, consumed in the same order.
+#include "sdh_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <random>
+#include <vector>
+
+#include <hip/hip_fp16.h>
+
+#pragma clang fp contract(off)
+
+namespace sdh {
+
+// ---- dense weight on device ----------------------------------------------------------------------
+struct DenseView {
+    const void *    data;   // F32 / F16 rows, contiguous [n_out][n_in]
+    const int8_t *  q;      // Q8_0: [n_out][n_in]
+    const __half *  d;      // Q8_0: [n_out][n_in/32]
+    int     type;
+    int64_t n_in, n_out;
+};
+
+struct DeviceDense {
+    DenseView v{};
+    void * alloc0 = nullptr, * alloc1 = nullptr;
+    int64_t stored_bytes = 0;
+};
+
+__device__ __forceinline__ float dense_at(const DenseView & W, int64_t row, int64_t i) {
+    if (W.type == SDH_TYPE_Q8_0) {
+        const float d = __half2float(W.d[row * (W.n_in >> 5) + (i >> 5)]);
+        return (float) W.q[row * W.n_in + i] * d;
+    }
+    if (W.type == SDH_TYPE_F16) return __half2float(((const __half *) W.data)[row * W.n_in + i]);
+    return ((const float *) W.data)[row * W.n_in + i];
+}
+
+struct BaseView {            // fitted base on device, [B][L]
+    const float * h2;
+    const int *   inv;
+    int L, B, tall;
+};
+
+__device__ __forceinline__ float base_weight(const BaseView & a, int64_t row, int64_t i) {
+    const int64_t L = a.L;
+    const int64_t b = a.tall ? row / L : i / L;
+    const int64_t p = a.tall ? row - b * L : row;
+    const int64_t q = a.tall ? i : i - b * L;
+    const int64_t j = a.inv[b * L + q];
+    return a.h2[b * L + ((p ^ j) & (L - 1))];
+}
+
+// ---- block-wide helpers (256 threads = 4 waves) -----------------------------------------------------
+__device__ __forceinline__ double block_sum(double v, double * scratch /* >= 4 doubles */) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[wave] = v;
+    __syncthreads();
+    return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+}
+
+// exclusive prefix over the block of one int per thread; total returned through *total
+__device__ __forceinline__ int block_excl_scan(int v, int * scratch /* >= 5 ints */, int * total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    __syncthreads();
+    if (lane == 63) scratch[wave] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += scratch[w];
+    *total = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+    return base + inc - v;
+}
+
+// ---- kernel: base fit accumulation ---------------------------------------------------------------------
+// grid (L/256, n_jobs); job = (base block, perm trial). Thread u adds, for every sampled row in sample
+// order, the one element of that row that falls into XOR bin u: j = u ^ p, src = in0 + perm[j].
+struct FitJob { int b; int rows_off; int n_rows; int perm_off; };
+
+__global__ __launch_bounds__(256)
+void scan_fit_kernel(DenseView W, int L, int tall, const FitJob * __restrict__ jobs, const int * __restrict__ rows,
+                     const int * __restrict__ perms, double * __restrict__ out /* [n_jobs][3][L] */) {
+    extern __shared__ int perm_s[];
+    const FitJob job = jobs[blockIdx.y];
+    for (int i = threadIdx.x; i < L; i += 256) perm_s[i] = perms[job.perm_off + i];
+    __syncthreads();
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    const int64_t in0 = tall ? 0 : (int64_t) job.b * L;
+    const int64_t in1 = tall ? W.n_in : min((int64_t) W.n_in, in0 + L);
+    double s = 0.0, s2 = 0.0, n = 0.0;
+    for (int si = 0; si < job.n_rows; ++si) {
+        const int row = rows[job.rows_off + si];
+        const int p = tall ? row - job.b * L : row;
+        const int j = (u ^ p) & (L - 1);
+        const int64_t src = in0 + perm_s[j];
+        if (src < in0 || src >= in1) continue;
+        const double v = (double) dense_at(W, row, src);
+        s  += v;            // ww == 1: ww*v == v, ww*v*v == v*v exactly
+        s2 += v * v;
+        n  += 1.0;
+    }
+    double * o = out + (size_t) blockIdx.y * 3 * L;
+    o[u] = s; o[L + u] = s2; o[2 * L + u] = n;
+}
+
+// ---- kernel: COO selection ---------------------------------------------------------------------------
+// One workgroup per output row. LDS: r[n_in] f32 | sort[Kpad] u64 | hist[256] | misc.
+__device__ __forceinline__ uint32_t score_key(float r) { return __float_as_uint(fabsf(r)); }
+
+template <typename CMP>
+__device__ __forceinline__ void bitonic_desc(int n, CMP swap_if_needed) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < (n >> 1); t += 256) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                swap_if_needed(i, i | j, (i & k) == 0);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256)
+void scan_select_coo_kernel(DenseView W, BaseView base, int has_base, int K, int Kpad, int want_rs,
+                            int * __restrict__ idx_out, float * __restrict__ val_out, float * __restrict__ rs_out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int n_in = (int) W.n_in;
+    float *    r    = (float *) smem;
+    uint64_t * sbuf = (uint64_t *) (smem + (((size_t) n_in * 4 + 15) & ~(size_t) 15));
+    uint32_t * hist = (uint32_t *) (sbuf + Kpad);
+    double *   dsc  = (double *) (hist + 256);       // 4 doubles
+    int *      isc  = (int *) (dsc + 4);             // 8 ints
+    const int64_t row = blockIdx.x;
+    const int tid = threadIdx.x;
+
+    double dot = 0.0, nn = 0.0;
+    for (int i = tid; i < n_in; i += 256) {
+        const float w = dense_at(W, row, i);
+        if (has_base) {
+            const float bw = base_weight(base, row, i);
+            r[i] = w - bw;
+            dot += (double) w * (double) bw;
+            nn  += (double) bw * (double) bw;
+        } else {
+            r[i] = w;
+        }
+    }
+    __syncthreads();
+
+    // radix select: the K-th largest key, 8 bits per pass from the top
+    uint32_t prefix = 0;
+    int need = K;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        hist[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < n_in; i += 256) {
+            const uint32_t key = score_key(r[i]);
+            if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int cum = 0, d = 255;
+            for (; d > 0; --d) {
+                if (cum + (int) hist[d] >= need) break;
+                cum += (int) hist[d];
+            }
+            isc[0] = d;
+            isc[1] = need - cum;
+        }
+        __syncthreads();
+        prefix = (prefix << 8) | (uint32_t) isc[0];
+        need = isc[1];
+        __syncthreads();
+    }
+    const uint32_t T = prefix;          // key of the K-th largest; `need` entries equal to T are kept
+    const int n_greater = K - need;
+
+    // ordered compaction: thread t owns the contiguous range [lo, hi)
+    const int per = (n_in + 255) / 256;
+    const int lo = min(n_in, tid * per), hi = min(n_in, lo + per);
+    int cg = 0, ce = 0;
+    for (int i = lo; i < hi; ++i) {
+        const uint32_t key = score_key(r[i]);
+        cg += key > T;
+        ce += key == T;
+    }
+    int tot;
+    int og = block_excl_scan(cg, isc, &tot);
+    int oe = block_excl_scan(ce, isc, &tot);
+    for (int i = lo; i < hi; ++i) {
+        const uint32_t key = score_key(r[i]);
+        const uint64_t comp = ((uint64_t) key << 32) | (uint64_t) (0xffffffffu - (uint32_t) i);
+        if (key > T) sbuf[og++] = comp;
+        else if (key == T) { if (oe < need) sbuf[n_greater + oe] = comp; ++oe; }
+    }
+    for (int i = K + tid; i < Kpad; i += 256) sbuf[i] = 0;
+    __syncthreads();
+
+    bitonic_desc(Kpad, [&](int a, int b, bool desc) {
+        const uint64_t x = sbuf[a], y = sbuf[b];
+        if (desc ? (x < y) : (x > y)) { sbuf[a] = y; sbuf[b] = x; }
+    });
+
+    double dot2 = 0.0, nn2 = 0.0;
+    for (int rr = tid; rr < K; rr += 256) {
+        const int i = (int) (0xffffffffu - (uint32_t) sbuf[rr]);
+        idx_out[row * K + rr] = i;
+        val_out[row * K + rr] = r[i];
+        if (want_rs) {
+            const double wi = (double) dense_at(W, row, i), di = (double) r[i];
+            if (has_base) { dot2 += wi * di; nn2 += 2.0 * wi * di - di * di; }
+            else          { dot2 += wi * wi; nn2 += wi * wi; }
+        }
+    }
+    if (want_rs) {
+        const double d_all = block_sum(dot, dsc) + block_sum(dot2, dsc);
+        const double n_all = block_sum(nn, dsc) + block_sum(nn2, dsc);
+        if (tid == 0) rs_out[row] = n_all > 1e-30 ? (float) (d_all / n_all) : 1.0f;
+    }
+}
+
+// ---- kernel: block selection -------------------------------------------------------------------------
+// LDS: r[n_in] f32 | energy[NBpad] f64 | bid[NBpad] i32 | misc
+__global__ __launch_bounds__(256)
+void scan_select_block_kernel(DenseView W, BaseView base, int has_base, int block, int keep, int n_blocks, int NBpad,
+                              int want_rs, int * __restrict__ idx_out, float * __restrict__ val_out,
+                              float * __restrict__ rs_out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int n_in = (int) W.n_in;
+    float *  r   = (float *) smem;
+    double * en  = (double *) (smem + (((size_t) n_in * 4 + 15) & ~(size_t) 15));
+    int *    bid = (int *) (en + NBpad);
+    double * dsc = (double *) (bid + NBpad + (NBpad & 1));
+    const int64_t row = blockIdx.x;
+    const int tid = threadIdx.x;
+
+    double dot = 0.0, nn = 0.0;
+    for (int i = tid; i < n_in; i += 256) {
+        const float w = dense_at(W, row, i);
+        if (has_base) {
+            const float bw = base_weight(base, row, i);
+            r[i] = w - bw;
+            dot += (double) w * (double) bw;
+            nn  += (double) bw * (double) bw;
+        } else {
+            r[i] = w;
+        }
+    }
+    __syncthreads();
+    for (int b = tid; b < NBpad; b += 256) {
+        double e = -1.0;                                   // padding sorts last
+        if (b < n_blocks) {
+            e = 0.0;
+            const int i1 = min(n_in, (b + 1) * block);
+            for (int i = b * block; i < i1; ++i) { const double x = (double) r[i]; e += x * x; }   // sequential: exact
+        }
+        en[b] = e;
+        bid[b] = b;
+    }
+    __syncthreads();
+    bitonic_desc(NBpad, [&](int a, int b, bool desc) {
+        const double ea = en[a], eb = en[b];
+        const int ia = bid[a], ib = bid[b];
+        const bool a_first = ea > eb || (ea == eb && ia < ib);      // a belongs before b in descending order
+        if (desc ? !a_first : a_first) { en[a] = eb; en[b] = ea; bid[a] = ib; bid[b] = ia; }
+    });
+
+    double dot2 = 0.0, nn2 = 0.0;
+    for (int e = tid; e < keep * block; e += 256) {
+        const int bi = e / block, t = e - bi * block;
+        const int blk = bid[bi];
+        const int i = blk * block + t;
+        if (t == 0) idx_out[row * keep + bi] = blk;
+        float v = 0.0f;
+        if (i < n_in) {
+            v = r[i];
+            if (want_rs) {
+                const double wi = (double) dense_at(W, row, i), di = (double) v;
+                if (has_base) { dot2 += wi * di; nn2 += 2.0 * wi * di - di * di; }
+                else          { dot2 += wi * wi; nn2 += wi * wi; }
+            }
+        }
+        val_out[((size_t) row * keep + bi) * block + t] = v;
+    }
+    if (want_rs) {
+        const double d_all = block_sum(dot, dsc) + block_sum(dot2, dsc);
+        const double n_all = block_sum(nn, dsc) + block_sum(nn2, dsc);
+        if (tid == 0) rs_out[row] = n_all > 1e-30 ? (float) (d_all / n_all) : 1.0f;
+    }
+}
+
+// ---- kernel: weight-space metric triples (w_norm2, hat_norm2, dot) per sampled row -------------------
+__global__ __launch_bounds__(256)
+void scan_evalw_kernel(DenseView W, BaseView base, int has_base, int scheme, int K, int block,
+                       const int * __restrict__ idx, const float * __restrict__ val, const float * __restrict__ rs,
+                       const int * __restrict__ rows, double * __restrict__ out /* [n_rows][3] */) {
+    __shared__ double dsc[4];
+    const int64_t row = rows[blockIdx.x];
+    const int n_in = (int) W.n_in;
+    const double scale = rs ? (double) rs[row] : 1.0;
+    double wn = 0.0, hn = 0.0, dt = 0.0;
+    for (int i = threadIdx.x; i < n_in; i += 256) {
+        const double wi = (double) dense_at(W, row, i);
+        wn += wi * wi;
+        if (has_base) {
+            const double bs = (double) base_weight(base, row, i);
+            hn += bs * bs;
+            dt += wi * bs;
+        }
+    }
+    const int n_ent = scheme == 1 ? K * block : K;
+    for (int e = threadIdx.x; e < n_ent; e += 256) {
+        int64_t i;
+        float dv;
+        if (scheme == 1) {
+            const int bi = e / block, t = e - bi * block;
+            const int blk = idx[row * K + bi];
+            if (blk < 0) continue;
+            i = (int64_t) blk * block + t;
+            if (i >= n_in) continue;
+            dv = val[((size_t) row * K + bi) * block + t];
+        } else {
+            const int ii = idx[row * K + e];
+            if (ii < 0 || ii >= n_in) continue;
+            i = ii;
+            dv = val[row * K + e];
+        }
+        const double wi = (double) dense_at(W, row, i);
+        if (has_base) {
+            const double ds = (double) dv, bs = (double) base_weight(base, row, i);
+            dt += wi * ds;
+            hn += 2.0 * bs * ds + ds * ds;
+        } else {
+            const double wh = scale * (double) dv;
+            hn += wh * wh;
+            dt += wi * wh;
+        }
+    }
+    wn = block_sum(wn, dsc); hn = block_sum(hn, dsc); dt = block_sum(dt, dsc);
+    if (has_base) { dt = scale * dt; hn = scale * scale * hn; }
+    if (threadIdx.x == 0) { out[blockIdx.x * 3] = wn; out[blockIdx.x * 3 + 1] = hn; out[blockIdx.x * 3 + 2] = dt; }
+}
+
+// ---- kernel: y_true[xi][ci] = sum_i W[row_ci][i] * x[xi][i] in double -----------------------------------
+__global__ __launch_bounds__(256)
+void scan_dense_dot_kernel(DenseView W, const int * __restrict__ rows, int n_rows, const float * __restrict__ xs,
+                           double * __restrict__ out /* [n_x][n_rows] */) {
+    __shared__ double dsc[4];
+    const int ci = blockIdx.x, xi = blockIdx.y;
+    const int64_t row = rows[ci];
+    const float * x = xs + (size_t) xi * W.n_in;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < (int) W.n_in; i += 256) acc += (double) dense_at(W, row, i) * (double) x[i];
+    acc = block_sum(acc, dsc);
+    if (threadIdx.x == 0) out[(size_t) xi * n_rows + ci] = acc;
+}
+
+// ---- kernel: y_hat[xi][ci] = (base(x)[row] + sum_r val * x[idx]) * row_scale -----------------------------
+// v = base transforms [n_x][B][L] (fp32, exact); tall picks v[b][p], wide sums blocks in fp32 from 0.0f
+// in block order (sd_eval.cpp:1119-1134)
+__global__ __launch_bounds__(256)
+void scan_delta_dot_kernel(int n_in, int scheme, int K, int block, const int * __restrict__ idx,
+                           const float * __restrict__ val, const float * __restrict__ rs,
+                           const float * __restrict__ v, int L, int B, int tall,
+                           const int * __restrict__ rows, int n_rows, const float * __restrict__ xs,
+                           double * __restrict__ out /* [n_x][n_rows] */) {
+    __shared__ double dsc[4];
+    const int ci = blockIdx.x, xi = blockIdx.y;
+    const int64_t row = rows[ci];
+    const float * x = xs + (size_t) xi * n_in;
+    double acc = 0.0;
+    const int n_ent = scheme == 1 ? K * block : K;
+    for (int e = threadIdx.x; e < n_ent; e += 256) {
+        if (scheme == 1) {
+            const int bi = e / block, t = e - bi * block;
+            const int blk = idx[row * K + bi];
+            if (blk < 0) continue;
+            const int64_t i = (int64_t) blk * block + t;
+            if (i >= n_in) continue;
+            acc += (double) val[((size_t) row * K + bi) * block + t] * (double) x[i];
+        } else {
+            const int ii = idx[row * K + e];
+            if (ii < 0 || ii >= n_in) continue;
+            acc += (double) val[row * K + e] * (double) x[ii];
+        }
+    }
+    acc = block_sum(acc, dsc);
+    if (threadIdx.x == 0) {
+        double y0 = 0.0;
+        if (v) {
+            const float * vx = v + (size_t) xi * B * L;
+            if (tall) {
+                const int64_t b = row / L;
+                if (b < B) y0 = (double) vx[b * L + (row - b * L)];
+            } else if (row < L) {
+                float s = 0.0f;
+                for (int b = 0; b < B; ++b) s += vx[(size_t) b * L + row];
+                y0 = (double) s;
+            }
+        }
+        out[(size_t) xi * n_rows + ci] = (y0 + acc) * (rs ? (double) rs[row] : 1.0);
+    }
+}
+
+__global__ void scan_gather_kernel(DenseView W, const int * __restrict__ rows, int n_rows, const int * __restrict__ cols,
+                                   int n_cols, float * __restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_rows * n_cols) return;
+    const int c = cols[e % n_cols];
+    out[e] = c < W.n_in ? dense_at(W, rows[e / n_cols], c) : 0.0f;
+}
+
+// ---- host: scan state --------------------------------------------------------------------------------
+template <typename T>
+struct DevBuf {
+    T * p = nullptr; size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return SDH_OK;
+        if (p) (void) hipFree(p);
+        p = nullptr; cap = 0;
+        SDH_HIP_CHECK(hipMalloc((void **) &p, n * sizeof(T)));
+        cap = n;
+        return SDH_OK;
+    }
+    int put(const std::vector<T> & h, hipStream_t s) {
+        int rc = ensure(h.size() ? h.size() : 1);
+        if (rc != SDH_OK) return rc;
+        if (!h.empty()) SDH_HIP_CHECK(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+        return SDH_OK;
+    }
+    ~DevBuf() { if (p) (void) hipFree(p); }
+};
+
+struct Scan {
+    std::mt19937 rng;
+    // last candidate
+    int64_t n_in = 0, n_out = 0, K = 0, block = 0, L = 0, B = 0;
+    int scheme = 0; bool has_base = false, has_rs = false;
+    DevBuf<int> idx; DevBuf<float> val; DevBuf<float> rs;
+    DevBuf<float> h2, d2, d1; DevBuf<int> inv, perm1;
+    std::vector<float> h_h2, h_d2, h_ones; std::vector<int> h_perm1, h_inv;
+    // scratch
+    DevBuf<int> rows, perms, cols; DevBuf<FitJob> jobs; DevBuf<double> dbl, dbl2; DevBuf<float> xs, v, gat;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    explicit Scan(uint32_t seed) : rng(seed) {}
+};
+
+static void fit_dims(int64_t n_in, int64_t n_out, int64_t * L, int64_t * B) {
+    int64_t p = 1;
+    while (p < std::min(n_in, n_out)) p <<= 1;
+    *L = p;
+    *B = (std::max(n_in, n_out) + p - 1) / p;
+}
+
+static void host_fwht(std::vector<float> & a) {
+    const size_t n = a.size();
+    for (size_t len = 1; len < n; len <<= 1)
+        for (size_t i = 0; i < n; i += len << 1)
+            for (size_t j = 0; j < len; ++j) {
+                const float u = a[i + j], v = a[i + j + len];
+                a[i + j] = u + v; a[i + j + len] = u - v;
+            }
+}
+
+static double percentile(std::vector<double> v, double p) {
+    if (v.empty()) return 0.0;
+    std::sort(v.begin(), v.end());
+    const double x = p * double(v.size() - 1);
+    const size_t i = (size_t) x, j = std::min(i + 1, v.size() - 1);
+    const double a = x - double(i);
+    return v[i] * (1.0 - a) + v[j] * a;
+}
+
+static void triple_metrics(double n_true, double n_hat, double dot, double * rel, double * cs, double * nr) {
+    const double err2 = std::max(n_true + n_hat - 2.0 * dot, 0.0);
+    const double dt = std::sqrt(std::max(n_true, 1e-20)), dh = std::sqrt(std::max(n_hat, 1e-20));
+    *rel = std::sqrt(err2) / dt; *cs = dot / (dt * dh); *nr = dh / dt;
+}
+
+static void summarise(const std::vector<double> & rel, const std::vector<double> & cs, const std::vector<double> & nr, double * o) {
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (double x : rel) a += x;
+    for (double x : cs) b += x;
+    for (double x : nr) c += x;
+    const double n = (double) rel.size();
+    o[0] = rel.empty() ? 0.0 : a / n; o[1] = percentile(rel, 0.95);
+    o[2] = cs.empty() ? 0.0 : b / n;  o[3] = percentile(cs, 0.05);
+    o[4] = nr.empty() ? 0.0 : c / n;
+}
+
+// the row sample every eval draws: iota, shuffle, truncate (sd_eval.cpp:138-141 and siblings)
+static std::vector<int> draw_rows(std::mt19937 & rng, int64_t n_out, int64_t want) {
+    std::vector<int64_t> all((size_t) n_out);
+    std::iota(all.begin(), all.end(), 0);
+    std::shuffle(all.begin(), all.end(), rng);
+    all.resize((size_t) std::min(want, n_out));
+    return std::vector<int>(all.begin(), all.end());
+}
+
+// RNG consumption of the base fit (sd_eval.cpp:557-651), with or without the work
+struct FitPlan {
+    std::vector<FitJob> jobs; std::vector<int> rows; std::vector<int> perms;
+};
+
+static FitPlan plan_fit(std::mt19937 & rng, int64_t n_in, int64_t n_out, int64_t L, int64_t B, int64_t max_samples, int trials) {
+    FitPlan pl;
+    const bool tall = n_out >= n_in;
+    trials = std::max(1, trials);
+    auto add_block = [&](int64_t b, int rows_off, int n_rows) {
+        for (int t = 0; t < trials; ++t) {
+            std::vector<int32_t> perm((size_t) L);
+            std::iota(perm.begin(), perm.end(), 0);
+            if (t > 0) std::shuffle(perm.begin(), perm.end(), rng);
+            pl.jobs.push_back(FitJob{ (int) b, rows_off, n_rows, (int) pl.perms.size() });
+            pl.perms.insert(pl.perms.end(), perm.begin(), perm.end());
+        }
+    };
+    if (tall) {
+        for (int64_t b = 0; b < B; ++b) {
+            const int64_t o0 = b * L, o1 = std::min(n_out, (b + 1) * L);
+            if (o1 <= o0) continue;
+            std::vector<int64_t> cols((size_t) (o1 - o0));
+            std::iota(cols.begin(), cols.end(), o0);
+            std::shuffle(cols.begin(), cols.end(), rng);
+            const int64_t S = max_samples <= 0 ? (o1 - o0) : std::min(o1 - o0, max_samples);
+            const int off = (int) pl.rows.size();
+            pl.rows.insert(pl.rows.end(), cols.begin(), cols.begin() + S);
+            add_block(b, off, (int) S);
+        }
+    } else {
+        const int64_t n_eff = std::min(n_out, L);
+        std::vector<int64_t> cols((size_t) n_eff);
+        std::iota(cols.begin(), cols.end(), 0);
+        std::shuffle(cols.begin(), cols.end(), rng);
+        const int64_t S = max_samples <= 0 ? n_eff : std::min(n_eff, max_samples);
+        pl.rows.assign(cols.begin(), cols.begin() + S);
+        for (int64_t b = 0; b < B; ++b) {
+            if (std::min(n_in, b * L + L) - b * L <= 0) continue;
+            add_block(b, 0, (int) S);
+        }
+    }
+    return pl;
+}
+
+static DenseView view_or_null(const sdh_dense * d) {
+    return d ? ((const DeviceDense *) d)->v : DenseView{};
+}
+
+static void clamp_budget(const sdh_scan_params & p, int64_t n_in, int64_t * K_eff, int64_t * keep) {
+    const int64_t Kc = std::max<int64_t>(1, std::min<int64_t>(p.K, n_in));
+    const int64_t blk = std::max<int64_t>(1, p.block);
+    *keep = (Kc + blk - 1) / blk;
+    *K_eff = p.scheme == 1 ? *keep * blk : Kc;
+}
+
+} // namespace sdh
+
+using namespace sdh;
+
+extern "C" {
+
+int sdh_dense_create(const sdh_tensor * W, sdh_dense ** out) {
+    if (!W || !out || !W->data) { set_error("sdh_dense_create: null argument"); return SDH_ERR_INVALID; }
+    LibState & ls = lib();
+    if (!ls.inited) { set_error("sdh_init() has not been called"); return SDH_ERR_NO_DEVICE; }
+    const int64_t n_in = W->ne[0], n_out = W->ne[1];
+    if (n_in <= 0 || n_out <= 0 || n_in > INT32_MAX / 2 || n_out > INT32_MAX / 2) {
+        set_error("sdh_dense_create: bad dims %lld x %lld", (long long) n_in, (long long) n_out);
+        return SDH_ERR_INVALID;
+    }
+    DeviceDense * d = new DeviceDense();
+    d->v.type = W->type; d->v.n_in = n_in; d->v.n_out = n_out;
+    const uint8_t * src = (const uint8_t *) W->data;
+    auto fail = [&](int rc) { (void) hipFree(d->alloc0); (void) hipFree(d->alloc1); delete d; return rc; };
+    if (W->type == SDH_TYPE_Q8_0) {
+        if (n_in % 32) { set_error("Q8_0 needs n_in %% 32 == 0"); return fail(SDH_ERR_INVALID); }
+        const int64_t nblk = n_in / 32;
+        std::vector<int8_t> q((size_t) (n_out * n_in));
+        std::vector<uint16_t> sc((size_t) (n_out * nblk));
+        for (int64_t r = 0; r < n_out; ++r) {
+            const uint8_t * row = src + r * W->nb[1];
+            for (int64_t b = 0; b < nblk; ++b) {
+                std::memcpy(&sc[(size_t) (r * nblk + b)], row + b * 34, 2);
+                std::memcpy(&q[(size_t) (r * n_in + b * 32)], row + b * 34 + 2, 32);
+            }
+        }
+        if (hipMalloc(&d->alloc0, q.size()) != hipSuccess || hipMalloc(&d->alloc1, sc.size() * 2) != hipSuccess) {
+            set_error("hipMalloc failed for a dense weight"); return fail(SDH_ERR_HIP);
+        }
+        (void) hipMemcpy(d->alloc0, q.data(), q.size(), hipMemcpyHostToDevice);
+        (void) hipMemcpy(d->alloc1, sc.data(), sc.size() * 2, hipMemcpyHostToDevice);
+        d->v.q = (const int8_t *) d->alloc0; d->v.d = (const __half *) d->alloc1;
+        d->stored_bytes = n_out * nblk * 34;
+    } else if (W->type == SDH_TYPE_F32 || W->type == SDH_TYPE_F16) {
+        const size_t es = W->type == SDH_TYPE_F32 ? 4 : 2;
+        if ((size_t) W->nb[0] != es) { set_error("dense rows must be contiguous"); return fail(SDH_ERR_INVALID); }
+        if (hipMalloc(&d->alloc0, (size_t) (n_out * n_in) * es) != hipSuccess) {
+            set_error("hipMalloc failed for a dense weight"); return fail(SDH_ERR_HIP);
+        }
+        (void) hipMemcpy2D(d->alloc0, (size_t) n_in * es, src, (size_t) W->nb[1], (size_t) n_in * es, (size_t) n_out, hipMemcpyHostToDevice);
+        d->v.data = d->alloc0;
+        d->stored_bytes = n_out * n_in * (int64_t) es;
+    } else {
+        set_error("dense weight type %d not supported (F32, F16, Q8_0)", W->type);
+        return fail(SDH_ERR_UNSUPPORTED);
+    }
+    if (hipGetLastError() != hipSuccess) { set_error("upload of a dense weight failed"); return fail(SDH_ERR_HIP); }
+    *out = (sdh_dense *) d;
+    return SDH_OK;
+}
+
+void sdh_dense_destroy(sdh_dense * W) {
+    if (!W) return;
+    DeviceDense * d = (DeviceDense *) W;
+    (void) hipFree(d->alloc0); (void) hipFree(d->alloc1);
+    delete d;
+}
+
+int64_t sdh_dense_bytes(const sdh_dense * W) { return W ? ((const DeviceDense *) W)->stored_bytes : -1; }
+
+int sdh_scan_create(uint32_t seed, sdh_scan ** out) {
+    if (!out) { set_error("sdh_scan_create: null argument"); return SDH_ERR_INVALID; }
+    if (!lib().inited) { set_error("sdh_init() has not been called"); return SDH_ERR_NO_DEVICE; }
+    Scan * s = new Scan(seed);
+    if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) {
+        set_error("hipEventCreate failed"); delete s; return SDH_ERR_HIP;
+    }
+    *out = (sdh_scan *) s;
+    return SDH_OK;
+}
+
+void sdh_scan_destroy(sdh_scan * h) {
+    if (!h) return;
+    Scan * s = (Scan *) h;
+    if (s->ev0) (void) hipEventDestroy(s->ev0);
+    if (s->ev1) (void) hipEventDestroy(s->ev1);
+    delete s;
+}
+
+int sdh_scan_skip(sdh_scan * h, int64_t n_in, int64_t n_out, const sdh_scan_params * p) {
+    if (!h || !p || n_in <= 0 || n_out <= 0) { set_error("sdh_scan_skip: bad argument"); return SDH_ERR_INVALID; }
+    Scan & s = *(Scan *) h;
+    if (p->write_base) {
+        int64_t L, B;
+        fit_dims(n_in, n_out, &L, &B);
+        (void) plan_fit(s.rng, n_in, n_out, L, B, p->base_max_samples, p->base_perm_trials);
+    }
+    if (p->eval_cols > 0) (void) draw_rows(s.rng, n_out, p->eval_cols);
+    if (p->eval_cols > 0 && p->eval_x > 0) {
+        (void) draw_rows(s.rng, n_out, p->eval_cols);
+        std::normal_distribution<float> nd(0.0f, 1.0f);
+        for (int64_t k = 0; k < p->eval_x * n_in; ++k) (void) nd(s.rng);
+    }
+    return SDH_OK;
+}
+
+int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, const sdh_dense * Wu,
+                    const sdh_dense * Wd, const sdh_scan_params * pp, sdh_scan_result * out) {
+    if (!h || !Wh || !pp || !out) { set_error("sdh_scan_tensor: null argument"); return SDH_ERR_INVALID; }
+    Scan & s = *(Scan *) h;
+    const sdh_scan_params & p = *pp;
+    LibState & ls = lib();
+    hipStream_t st = ls.stream;
+    const DenseView W = ((const DeviceDense *) Wh)->v;
+    const int64_t n_in = W.n_in, n_out = W.n_out;
+    const bool tall = n_out >= n_in;
+    std::memset(out, 0, sizeof(*out));
+    if (p.scheme != 0 && p.scheme != 1) { set_error("scan: scheme must be 0 (coo) or 1 (block)"); return SDH_ERR_INVALID; }
+    if (p.scheme == 1 && p.block <= 0) { set_error("scan: block must be > 0"); return SDH_ERR_INVALID; }
+
+    int64_t K_eff, keep;
+    clamp_budget(p, n_in, &K_eff, &keep);
+    const int64_t Ksel = p.scheme == 1 ? keep : K_eff;       // entries of idx per row
+    out->K_eff = K_eff; out->n_blocks = keep;
+    int rc;
+    SDH_HIP_CHECK(hipEventRecord(s.ev0, st));
+
+    // ---- base fit -------------------------------------------------------------------------------------
+    int64_t L = 0, B = 0;
+    BaseView bv{};
+    if (p.write_base) {
+        fit_dims(n_in, n_out, &L, &B);
+        if (L > 16384) { set_error("scan: base block length %lld too large", (long long) L); return SDH_ERR_UNSUPPORTED; }
+        FitPlan pl = plan_fit(s.rng, n_in, n_out, L, B, p.base_max_samples, p.base_perm_trials);
+        const int n_jobs = (int) pl.jobs.size();
+        if ((rc = s.jobs.put(pl.jobs, st)) || (rc = s.rows.put(pl.rows, st)) || (rc = s.perms.put(pl.perms, st))) return rc;
+        if ((rc = s.dbl.ensure((size_t) n_jobs * 3 * L))) return rc;
+        const int threads = 256;
+        if (L < threads) { set_error("scan: base block length %lld < 256 not supported on the GPU path", (long long) L); return SDH_ERR_UNSUPPORTED; }
+        hipLaunchKernelGGL(scan_fit_kernel, dim3((unsigned) (L / threads), (unsigned) n_jobs), dim3(threads),
+                           (size_t) L * sizeof(int), st, W, (int) L, tall ? 1 : 0, s.jobs.p, s.rows.p, s.perms.p, s.dbl.p);
+        SDH_HIP_CHECK(hipGetLastError());
+        std::vector<double> sums((size_t) n_jobs * 3 * L);
+        SDH_HIP_CHECK(hipMemcpyAsync(sums.data(), s.dbl.p, sums.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        SDH_HIP_CHECK(hipStreamSynchronize(st));
+        s.h_h2.assign((size_t) (L * B), 0.0f); s.h_d2.assign((size_t) (L * B), 0.0f);
+        s.h_perm1.assign((size_t) (L * B), 0);  s.h_inv.assign((size_t) (L * B), 0);
+        std::vector<double> best((size_t) B, INFINITY);
+        std::vector<float> h2((size_t) L);
+        for (int j = 0; j < n_jobs; ++j) {                     // jobs are in (block, trial) order
+            const double * sm = sums.data() + (size_t) j * 3 * L, * sm2 = sm + L, * wg = sm2 + L;
+            double sse = 0.0;
+            for (int64_t u = 0; u < L; ++u) {
+                h2[(size_t) u] = 0.0f;
+                if (wg[u] > 0.0) {
+                    h2[(size_t) u] = (float) (sm[u] / wg[u]);
+                    sse += std::max(sm2[u] - (sm[u] * sm[u]) / wg[u], 0.0);
+                }
+            }
+            const int b = pl.jobs[(size_t) j].b;
+            if (sse < best[(size_t) b]) {
+                best[(size_t) b] = sse;
+                std::copy(h2.begin(), h2.end(), s.h_h2.begin() + (size_t) b * L);
+                std::copy(pl.perms.begin() + pl.jobs[(size_t) j].perm_off, pl.perms.begin() + pl.jobs[(size_t) j].perm_off + L,
+                          s.h_perm1.begin() + (size_t) b * L);
+            }
+        }
+        for (int64_t b = 0; b < B; ++b) {
+            if (best[(size_t) b] == INFINITY) continue;        // block without rows / inputs: stays zero
+            std::vector<float> d2(s.h_h2.begin() + (size_t) b * L, s.h_h2.begin() + (size_t) (b + 1) * L);
+            host_fwht(d2);
+            const float inv_L = 1.0f / (float) L;
+            for (int64_t u = 0; u < L; ++u) s.h_d2[(size_t) (b * L + u)] = d2[(size_t) u] * inv_L;
+            for (int64_t i = 0; i < L; ++i) {
+                const int src = s.h_perm1[(size_t) (b * L + i)];
+                if (src >= 0 && src < (int) L) s.h_inv[(size_t) (b * L + src)] = (int) i;
+            }
+        }
+        if ((rc = s.h2.put(s.h_h2, st)) || (rc = s.inv.put(s.h_inv, st)) || (rc = s.d2.put(s.h_d2, st)) ||
+            (rc = s.perm1.put(s.h_perm1, st))) return rc;
+        s.h_ones.assign((size_t) (L * B), 1.0f);               // D1 = I in the fit (sd_eval.cpp:450)
+        if ((rc = s.d1.put(s.h_ones, st))) return rc;
+        bv.h2 = s.h2.p; bv.inv = s.inv.p; bv.L = (int) L; bv.B = (int) B; bv.tall = tall ? 1 : 0;
+    }
+    out->L = L; out->B = B;
+    s.n_in = n_in; s.n_out = n_out; s.K = Ksel; s.block = p.scheme == 1 ? p.block : 1; s.scheme = p.scheme;
+    s.L = L; s.B = B; s.has_base = p.write_base != 0; s.has_rs = p.write_row_scale != 0;
+
+    // ---- selection ------------------------------------------------------------------------------------
+    const size_t n_val = (size_t) n_out * (size_t) K_eff;
+    if ((rc = s.idx.ensure((size_t) n_out * (size_t) Ksel)) || (rc = s.val.ensure(n_val)) || (rc = s.rs.ensure((size_t) n_out))) return rc;
+    const size_t r_bytes = ((size_t) n_in * 4 + 15) & ~(size_t) 15;
+    if (p.scheme == 0) {
+        int Kpad = 2;
+        while (Kpad < K_eff) Kpad <<= 1;
+        const size_t lds = r_bytes + (size_t) Kpad * 8 + 256 * 4 + 4 * 8 + 8 * 4;
+        if (lds > 160 * 1024) {
+            set_error("scan: n_in=%lld with K=%lld needs %zu B of LDS (max 163840)", (long long) n_in, (long long) K_eff, lds);
+            return SDH_ERR_UNSUPPORTED;
+        }
+        SDH_HIP_CHECK(hipFuncSetAttribute((const void *) scan_select_coo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL(scan_select_coo_kernel, dim3((unsigned) n_out), dim3(256), lds, st, W, bv, p.write_base ? 1 : 0,
+                           (int) K_eff, Kpad, p.write_row_scale ? 1 : 0, s.idx.p, s.val.p, s.rs.p);
+    } else {
+        const int64_t n_blocks = (n_in + p.block - 1) / p.block;
+        int NBpad = 2;
+        while (NBpad < n_blocks) NBpad <<= 1;
+        const size_t lds = r_bytes + (size_t) NBpad * 8 + (size_t) (NBpad + (NBpad & 1)) * 4 + 4 * 8;
+        if (lds > 160 * 1024) {
+            set_error("scan: n_in=%lld block=%lld needs %zu B of LDS (max 163840)", (long long) n_in, (long long) p.block, lds);
+            return SDH_ERR_UNSUPPORTED;
+        }
+        SDH_HIP_CHECK(hipFuncSetAttribute((const void *) scan_select_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL(scan_select_block_kernel, dim3((unsigned) n_out), dim3(256), lds, st, W, bv, p.write_base ? 1 : 0,
+                           (int) p.block, (int) keep, (int) n_blocks, NBpad, p.write_row_scale ? 1 : 0, s.idx.p, s.val.p, s.rs.p);
+    }
+    SDH_HIP_CHECK(hipGetLastError());
+    const float * rs_dev = p.write_row_scale ? s.rs.p : nullptr;
+
+    // ---- cost model (sd_cost.cpp:7-40) --------------------------------------------------------------
+    {
+        double * c = out->cost;
+        c[2] = 2.0 * (double) n_in * (double) n_out;
+        c[4] = 2.0 * (double) K_eff * (double) n_out;
+        c[5] = p.write_row_scale ? (double) n_out : 0.0;
+        if (p.write_base && L > 0 && B > 0) {
+            c[0] = (double) L; c[1] = (double) B;
+            const double l = (double) L, lg = std::log2(std::max(2.0, l));
+            c[3] = (double) B * (2.0 * l * lg + 3.0 * l + (tall ? 0.0 : l));
+        }
+        c[6] = c[3] + c[4] + c[5];
+        c[7] = c[2] > 0.0 ? c[6] / c[2] : 0.0;
+    }
+
+    // ---- weight-space metrics -----------------------------------------------------------------------
+    if (p.eval_cols > 0) {
+        std::vector<int> rows = draw_rows(s.rng, n_out, p.eval_cols);
+        const int nr = (int) rows.size();
+        if ((rc = s.rows.put(rows, st)) || (rc = s.dbl.ensure((size_t) nr * 3))) return rc;
+        hipLaunchKernelGGL(scan_evalw_kernel, dim3((unsigned) nr), dim3(256), 0, st, W, bv, p.write_base ? 1 : 0, p.scheme,
+                           (int) Ksel, (int) s.block, s.idx.p, s.val.p, rs_dev, s.rows.p, s.dbl.p);
+        SDH_HIP_CHECK(hipGetLastError());
+        std::vector<double> tr((size_t) nr * 3);
+        SDH_HIP_CHECK(hipMemcpyAsync(tr.data(), s.dbl.p, tr.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        SDH_HIP_CHECK(hipStreamSynchronize(st));
+        std::vector<double> rel((size_t) nr), cs((size_t) nr), nrm((size_t) nr);
+        for (int i = 0; i < nr; ++i) triple_metrics(tr[(size_t) i * 3], tr[(size_t) i * 3 + 1], tr[(size_t) i * 3 + 2], &rel[(size_t) i], &cs[(size_t) i], &nrm[(size_t) i]);
+        summarise(rel, cs, nrm, out->em);
+    }
+
+    // ---- activation-space metrics ---------------------------------------------------------------------
+    if (p.eval_cols > 0 && p.eval_x > 0) {
+        std::vector<int> rows = draw_rows(s.rng, n_out, p.eval_cols);
+        const int nr = (int) rows.size();
+        const int nx = (int) p.eval_x;
+        std::vector<float> xs((size_t) nx * (size_t) n_in);
+        std::normal_distribution<float> nd(0.0f, 1.0f);
+        for (float & x : xs) x = nd(s.rng);
+        if ((rc = s.rows.put(rows, st)) || (rc = s.xs.put(xs, st)) || (rc = s.dbl.ensure((size_t) nr * nx)) ||
+            (rc = s.dbl2.ensure((size_t) nr * nx))) return rc;
+        const float * vdev = nullptr;
+        if (p.write_base) {
+            if ((rc = s.v.ensure((size_t) nx * (size_t) B * (size_t) L))) return rc;
+            if ((rc = launch_base_apply_generic(s.xs.p, n_in, (int) n_in, (int) L, (int) B, tall, s.d1.p, s.d2.p, nullptr,
+                                                s.perm1.p, nullptr, nx, s.v.p, st))) return rc;
+            vdev = s.v.p;
+        }
+        hipLaunchKernelGGL(scan_dense_dot_kernel, dim3((unsigned) nr, (unsigned) nx), dim3(256), 0, st, W, s.rows.p, nr, s.xs.p, s.dbl.p);
+        hipLaunchKernelGGL(scan_delta_dot_kernel, dim3((unsigned) nr, (unsigned) nx), dim3(256), 0, st, (int) n_in, p.scheme,
+                           (int) Ksel, (int) s.block, s.idx.p, s.val.p, rs_dev, vdev, (int) L, (int) B, tall ? 1 : 0,
+                           s.rows.p, nr, s.xs.p, s.dbl2.p);
+        SDH_HIP_CHECK(hipGetLastError());
+        std::vector<double> yt((size_t) nr * nx), yh((size_t) nr * nx);
+        SDH_HIP_CHECK(hipMemcpyAsync(yt.data(), s.dbl.p, yt.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        SDH_HIP_CHECK(hipMemcpyAsync(yh.data(), s.dbl2.p, yh.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        SDH_HIP_CHECK(hipStreamSynchronize(st));
+        std::vector<double> rel((size_t) nx), cs((size_t) nx), nrm((size_t) nx);
+        for (int xi = 0; xi < nx; ++xi) {
+            double n1 = 0.0, n2 = 0.0, dot = 0.0;
+            for (int ci = 0; ci < nr; ++ci) {
+                const double a = yt[(size_t) xi * nr + ci], b = yh[(size_t) xi * nr + ci];
+                n1 += a * a; n2 += b * b; dot += a * b;
+            }
+            triple_metrics(n1, n2, dot, &rel[(size_t) xi], &cs[(size_t) xi], &nrm[(size_t) xi]);
+        }
+        summarise(rel, cs, nrm, out->em_x);
+        out->has_x = 1;
+    }
+
+    // ---- FFN proxy (sd_ffn_proxy.cpp:20-247): COO, no base, gate/up only ------------------------------
+    if (p.want_proxy && p.scheme == 0 && !p.write_base && p.eval_x > 0 && p.kind != 2 && Wg && Wu && Wd) {
+        const DenseView G = view_or_null(Wg), U = view_or_null(Wu), D = view_or_null(Wd);
+        const int64_t n_hidden = G.n_out, n_o = D.n_out;
+        const int nx = (int) std::min<int64_t>(p.eval_x, 128);
+        const int64_t cap = p.eval_cols > 0 ? p.eval_cols : 128;
+        std::mt19937 prng((uint32_t) p.proxy_seed);
+        std::vector<int> hid = draw_rows(prng, n_hidden, std::min(n_hidden, cap));
+        std::vector<int> outs = draw_rows(prng, n_o, std::min(n_o, cap));
+        const int nh = (int) hid.size(), no = (int) outs.size();
+        std::vector<float> xs((size_t) nx * (size_t) G.n_in);
+        std::normal_distribution<float> nd(0.0f, 1.0f);
+        for (float & x : xs) x = nd(prng);
+        if ((rc = s.rows.put(hid, st)) || (rc = s.cols.put(outs, st)) || (rc = s.xs.put(xs, st)) ||
+            (rc = s.dbl.ensure((size_t) nh * nx * 2)) || (rc = s.dbl2.ensure((size_t) nh * nx)) ||
+            (rc = s.gat.ensure((size_t) no * nh))) return rc;
+        hipLaunchKernelGGL(scan_dense_dot_kernel, dim3((unsigned) nh, (unsigned) nx), dim3(256), 0, st, G, s.rows.p, nh, s.xs.p, s.dbl.p);
+        hipLaunchKernelGGL(scan_dense_dot_kernel, dim3((unsigned) nh, (unsigned) nx), dim3(256), 0, st, U, s.rows.p, nh, s.xs.p,
+                           s.dbl.p + (size_t) nh * nx);
+        hipLaunchKernelGGL(scan_delta_dot_kernel, dim3((unsigned) nh, (unsigned) nx), dim3(256), 0, st, (int) n_in, 0, (int) Ksel, 1,
+                           s.idx.p, s.val.p, (const float *) nullptr, (const float *) nullptr, 0, 0, 1, s.rows.p, nh, s.xs.p, s.dbl2.p);
+        // W_down[out rows][hidden cols]
+        hipLaunchKernelGGL(scan_gather_kernel, dim3((unsigned) ((no * nh + 255) / 256)), dim3(256), 0, st, D, s.cols.p, no, s.rows.p, nh, s.gat.p);
+        SDH_HIP_CHECK(hipGetLastError());
+        std::vector<double> gu((size_t) nh * nx * 2), hat((size_t) nh * nx);
+        std::vector<float> wd((size_t) no * nh);
+        SDH_HIP_CHECK(hipMemcpyAsync(gu.data(), s.dbl.p, gu.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        SDH_HIP_CHECK(hipMemcpyAsync(hat.data(), s.dbl2.p, hat.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        SDH_HIP_CHECK(hipMemcpyAsync(wd.data(), s.gat.p, wd.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+        SDH_HIP_CHECK(hipStreamSynchronize(st));
+        std::vector<double> cs_all, l2_all, lnr_all;
+        auto silu = [](double v) { return v / (1.0 + std::exp(-v)); };
+        for (int xi = 0; xi < nx; ++xi) {
+            const double * gt = gu.data() + (size_t) xi * nh, * ut = gu.data() + (size_t) nh * nx + (size_t) xi * nh;
+            const double * ht = hat.data() + (size_t) xi * nh;
+            double dot = 0.0, n1 = 0.0, n2 = 0.0, l2 = 0.0;
+            for (int oi = 0; oi < no; ++oi) {
+                double yt = 0.0, yh = 0.0;
+                for (int hi = 0; hi < nh; ++hi) {
+                    const double g_hat = p.kind == 0 ? ht[hi] : gt[hi], u_hat = p.kind == 1 ? ht[hi] : ut[hi];
+                    const double w = (double) wd[(size_t) oi * nh + hi];
+                    yt += silu(gt[hi]) * ut[hi] * w;
+                    yh += silu(g_hat) * u_hat * w;
+                }
+                dot += yt * yh; n1 += yt * yt; n2 += yh * yh;
+                const double d = yt - yh;
+                l2 += d * d;
+            }
+            const double den = std::sqrt(std::max(n1, 1e-20)) * std::sqrt(std::max(n2, 1e-20));
+            cs_all.push_back(den > 0.0 ? dot / den : 0.0);
+            l2_all.push_back(std::sqrt(std::max(l2, 0.0)));
+            const double nr = n1 > 0.0 ? std::sqrt(std::max(n2, 1e-20)) / std::sqrt(std::max(n1, 1e-20)) : 0.0;
+            if (nr > 0.0) lnr_all.push_back(std::log(nr));
+        }
+        auto mean = [](const std::vector<double> & v) { return v.empty() ? 0.0 : std::accumulate(v.begin(), v.end(), 0.0) / (double) v.size(); };
+        out->proxy[0] = mean(cs_all);  out->proxy[1] = percentile(cs_all, 0.05);
+        out->proxy[2] = mean(l2_all);  out->proxy[3] = percentile(l2_all, 0.95);
+        out->proxy[4] = mean(lnr_all); out->proxy[5] = percentile(lnr_all, 0.95);
+        out->proxy[6] = (double) nx;   out->proxy[7] = (double) no;
+        out->proxy_available = 1;
+    }
+
+    SDH_HIP_CHECK(hipEventRecord(s.ev1, st));
+    SDH_HIP_CHECK(hipEventSynchronize(s.ev1));
+    float ms = 0.0f;
+    SDH_HIP_CHECK(hipEventElapsedTime(&ms, s.ev0, s.ev1));
+    out->gpu_ms = (double) ms;
+    return SDH_OK;
+}
+
+int sdh_scan_fetch(sdh_scan * h, int32_t * idx, float * val, float * row_scale,
+                   float * d2, float * h2, int32_t * perm1, int32_t * perm1_inv) {
+    if (!h) { set_error("sdh_scan_fetch: null handle"); return SDH_ERR_INVALID; }
+    Scan & s = *(Scan *) h;
+    if (s.n_out <= 0) { set_error("sdh_scan_fetch: no candidate evaluated yet"); return SDH_ERR_INVALID; }
+    hipStream_t st = lib().stream;
+    const size_t n_idx = (size_t) s.n_out * (size_t) s.K;
+    if (idx) SDH_HIP_CHECK(hipMemcpyAsync(idx, s.idx.p, n_idx * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (val) SDH_HIP_CHECK(hipMemcpyAsync(val, s.val.p, n_idx * (size_t) s.block * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (row_scale) {
+        if (!s.has_rs) { set_error("sdh_scan_fetch: candidate had no row scale"); return SDH_ERR_INVALID; }
+        SDH_HIP_CHECK(hipMemcpyAsync(row_scale, s.rs.p, (size_t) s.n_out * sizeof(float), hipMemcpyDeviceToHost, st));
+    }
+    SDH_HIP_CHECK(hipStreamSynchronize(st));
+    if (d2 || h2 || perm1 || perm1_inv) {
+        if (!s.has_base) { set_error("sdh_scan_fetch: candidate had no base"); return SDH_ERR_INVALID; }
+        const size_t n = (size_t) (s.L * s.B);
+        if (d2) std::memcpy(d2, s.h_d2.data(), n * sizeof(float));
+        if (h2) std::memcpy(h2, s.h_h2.data(), n * sizeof(float));
+        if (perm1) std::memcpy(perm1, s.h_perm1.data(), n * sizeof(int32_t));
+        if (perm1_inv) std::memcpy(perm1_inv, s.h_inv.data(), n * sizeof(int32_t));
+    }
+    return SDH_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,401 @@
+"""The candidate-evaluation loop behind ``scripts/seeddelta-layer-scan.py`` / ``seeddelta-autogate.py``
+on the MI355X: host-side mirror of the reference's script and builder interfaces over the
+``sdh_scan_*`` C ABI (include/seeddelta_hip.h).
+
+What maps to what (reference paths relative to /root/reference):
+
+* ``DenseWeight``      — a dense FFN tensor resident in HBM (``read_column_f32``,
+                         tools/seeddelta-build/sd_eval.cpp:20-40, happens inside the kernels);
+* ``ScanSession``      — one ``llama-seeddelta-build`` process: an ``std::mt19937(seed)``
+                         (sd_build.cpp:260) consumed tensor after tensor in the builder's order;
+* ``ScanParams``       — the builder flags that shape one trial (sd_cli.cpp / include/sd_cli.h:20-50);
+* ``report_entry``     — the ``weights[]`` element of report.json (sd_report.cpp:163-281) with the
+                         single-K gating decision of sd_build.cpp:843-913;
+* ``write_policy``, ``collect_metrics``, ``layer_scan`` — scripts/seeddelta-layer-scan.py:31-59,
+                         :62-122, :206-286: same policy document, same field mapping, same
+                         ``layer_sensitivity_scan.json`` structure;
+* ``shard`` / ``gather_records`` — the multi-GPU split of SURVEY §8e: independent (layer, tensor, K)
+                         candidates dealt to ranks, one all_gather of fixed-size records at the end.
+
+No CPU fallback: everything numeric runs in libseeddelta_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import math
+from dataclasses import dataclass, field
+from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import seeddelta as sd
+from .dense import dense_dims, dense_type
+
+KINDS = ("ffn_gate", "ffn_up", "ffn_down")
+KIND_ID = {k: i for i, k in enumerate(KINDS)}
+METRIC_NAMES = ("rel_l2_mean", "rel_l2_p95", "cos_mean", "cos_p05", "norm_ratio_mean")
+COST_NAMES = ("base_L", "base_B", "ops_dense", "ops_base", "ops_delta", "ops_row_scale", "ops_total", "ops_ratio")
+PROXY_NAMES = ("ffn_proxy_cos_mean", "ffn_proxy_cos_p05", "ffn_proxy_l2_mean", "ffn_proxy_l2_p95",
+               "ffn_proxy_log_norm_ratio_mean", "ffn_proxy_log_norm_ratio_p95", "ffn_proxy_eval_x", "ffn_proxy_eval_out")
+
+
+class DenseWeight:
+    """Upload-once handle of a dense weight (numpy (n_out, n_in) f32 / f16, or raw Q8_0 rows)."""
+
+    def __init__(self, W: np.ndarray):
+        lib = sd.load_library()
+        W = np.ascontiguousarray(W)
+        self.n_in, self.n_out = dense_dims(W)
+        t = sd.SdhTensor()
+        t.data, t.type, t.n_dims = W.ctypes.data, dense_type(W), 2
+        elem = {0: 4, 1: 2, 8: 34}[t.type]
+        t.ne[:] = [self.n_in, self.n_out, 1, 1]
+        row = W.strides[0]
+        t.nb[:] = [elem, row, row * self.n_out, row * self.n_out]
+        h = C.c_void_p()
+        sd._check(lib.sdh_dense_create(C.byref(t), C.byref(h)), "sdh_dense_create")
+        self._h = h
+        self.stored_bytes = int(lib.sdh_dense_bytes(h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            sd.load_library().sdh_dense_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+@dataclass
+class ScanParams:
+    scheme: str = "coo"            # --scheme
+    K: int = 12                    # --K  (layer-scan default, scripts/seeddelta-layer-scan.py:132)
+    block: int = 32                # --block
+    base: bool = False             # --base
+    row_scale: bool = False        # --row-scale
+    base_max_samples: int = 2048   # --base-max-samples
+    base_perm_trials: int = 4      # --base-perm-trials (layer-scan default)
+    eval_cols: int = 64            # --eval-cols
+    eval_x: int = 32               # --eval-x
+    seed: int = 1234               # --seed
+    metric: str = "cos"            # policy gating metric
+
+    def c_struct(self, kind: str, layer: int) -> sd.SdhScanParams:
+        p = sd.SdhScanParams()
+        p.scheme = 1 if self.scheme == "block" else 0
+        p.kind = KIND_ID[kind]
+        p.K, p.block = self.K, self.block
+        p.write_base, p.write_row_scale = int(self.base), int(self.row_scale)
+        p.base_max_samples, p.base_perm_trials = self.base_max_samples, self.base_perm_trials
+        p.want_proxy = 1
+        p.eval_cols, p.eval_x = self.eval_cols, self.eval_x
+        p.proxy_seed = self.seed + layer * 101 + KIND_ID[kind] + 1        # sd_build.cpp:1032
+        return p
+
+
+class ScanSession:
+    """One builder process: RNG stream + the last candidate's outputs on the device."""
+
+    def __init__(self, seed: int):
+        lib = sd.load_library()
+        h = C.c_void_p()
+        sd._check(lib.sdh_scan_create(C.c_uint32(seed & 0xFFFFFFFF), C.byref(h)), "sdh_scan_create")
+        self._h = h
+        self._last = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            sd.load_library().sdh_scan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def tensor(self, W: DenseWeight, params: ScanParams, kind: str = "ffn_gate", layer: int = 0,
+               ffn: Optional[Tuple[DenseWeight, DenseWeight, DenseWeight]] = None) -> dict:
+        """Evaluate one candidate; returns the raw result (metric vectors as numpy arrays)."""
+        lib = sd.load_library()
+        p = params.c_struct(kind, layer)
+        r = sd.SdhScanResult()
+        g, u, d = (x._h if x is not None else None for x in (ffn or (None, None, None)))
+        sd._check(lib.sdh_scan_tensor(self._h, W._h, g, u, d, C.byref(p), C.byref(r)), "sdh_scan_tensor")
+        self._last = (W.n_in, W.n_out, params, int(r.K_eff), int(r.n_blocks), int(r.L), int(r.B))
+        return {"K_eff": int(r.K_eff), "n_blocks": int(r.n_blocks), "L": int(r.L), "B": int(r.B),
+                "has_x": bool(r.has_x), "proxy_available": bool(r.proxy_available),
+                "em": np.array(r.em[:]), "em_x": np.array(r.em_x[:]), "cost": np.array(r.cost[:]),
+                "proxy": np.array(r.proxy[:]), "gpu_ms": float(r.gpu_ms)}
+
+    def skip(self, n_in: int, n_out: int, params: ScanParams, kind: str = "ffn_gate", layer: int = 0):
+        """Advance the RNG as evaluating a tensor of these dims would (no GPU work)."""
+        p = params.c_struct(kind, layer)
+        sd._check(sd.load_library().sdh_scan_skip(self._h, n_in, n_out, C.byref(p)), "sdh_scan_skip")
+
+    def fetch(self) -> dict:
+        """The emitted staging of the last candidate: idx/val[/row_scale][/base arrays]."""
+        n_in, n_out, params, K_eff, n_blocks, L, B = self._last
+        block = params.scheme == "block"
+        idx = np.empty((n_out, n_blocks if block else K_eff), dtype=np.int32)
+        val = np.empty((n_out, n_blocks, params.block) if block else (n_out, K_eff), dtype=np.float32)
+        rs = np.empty(n_out, dtype=np.float32) if params.row_scale else None
+        out = {"idx": idx, "val": val, "row_scale": rs}
+        ptr = lambda a: None if a is None else C.c_void_p(a.ctypes.data)   # noqa: E731
+        base = [None] * 4
+        if params.base:
+            out.update(d2=np.empty((B, L), np.float32), h2=np.empty((B, L), np.float32),
+                       perm1=np.empty((B, L), np.int32), perm1_inv=np.empty((B, L), np.int32))
+            base = [out["d2"], out["h2"], out["perm1"], out["perm1_inv"]]
+        sd._check(sd.load_library().sdh_scan_fetch(self._h, ptr(idx), ptr(val), ptr(rs), *[ptr(a) for a in base]),
+                  "sdh_scan_fetch")
+        return out
+
+
+# ---- report entry (sd_report.cpp:163-281; gating of sd_build.cpp:810-913 for a one-K schedule) -----------
+def ffn_score(entry: dict) -> float:
+    """sd_report.cpp:76-88 with has_w = False: prefer the x metrics, else the plain ones."""
+    if entry["has_x"] and (entry["cos_mean_x"] != 0.0 or entry["cos_p05_x"] != 0.0):
+        return min(entry["cos_mean_x"], entry["cos_p05_x"])
+    return min(entry["cos_mean"], entry["cos_p05"])
+
+
+def report_entry(layer: int, kind: str, n_in: int, n_out: int, params: ScanParams, res: dict,
+                 min_mean: float = 0.0, min_p05: float = 0.0, gating_enabled: bool = True) -> dict:
+    e = {"layer": layer, "kind": kind, "n_in": n_in, "n_out": n_out, "K_budget": params.K, "K": res["K_eff"],
+         "block": params.block, "n_blocks": res["n_blocks"], "has_w": False, "has_x": res["has_x"]}
+    e.update({n: (int(v) if i < 2 else float(v)) for i, (n, v) in enumerate(zip(COST_NAMES, res["cost"]))})
+    e.update({n: float(v) for n, v in zip(METRIC_NAMES, res["em"])})
+    for suffix, vec in (("_w", np.zeros(5)), ("_x", res["em_x"]), ("_x_w", np.zeros(5))):
+        e.update({n + suffix: float(v) for n, v in zip(METRIC_NAMES, vec)})
+    e["ffn_score"] = ffn_score(e)
+    # gate/up prefer the FFN score when x metrics exist (sd_build.cpp:810-816)
+    metric = "ffn_score" if (kind in ("ffn_gate", "ffn_up") and res["has_x"]) else params.metric
+    needs_x = metric in ("cos_x", "cos_x_w", "ffn_score")
+    needs_w = metric in ("cos_w", "cos_x_w")
+    available = not (gating_enabled and ((needs_x and not res["has_x"]) or needs_w))
+    pick = {"cos": ("cos_mean", "cos_p05"), "cos_x": ("cos_mean_x", "cos_p05_x"), "cos_w": ("cos_mean_w", "cos_p05_w"),
+            "cos_x_w": ("cos_mean_x_w", "cos_p05_x_w")}
+    val, p05 = (e["ffn_score"], e["ffn_score"]) if metric == "ffn_score" else (e[pick[metric][0]], e[pick[metric][1]])
+    passed = (not gating_enabled) or (available and val >= min_mean and p05 >= min_p05)
+    e.update(gating_enabled=gating_enabled, gating_metric=metric, gating_value=val, gating_p05=p05,
+             gating_min_mean=min_mean, gating_min_p05=min_p05, gating_pass=bool(passed and available),
+             metric_used=metric, targets_used={"tau_mean": min_mean, "tau_p05": min_p05}, emit=bool(passed))
+    e["decision"] = ("no_gating" if not gating_enabled else "metric_unavailable" if not available
+                     else "pass_gating" if passed else "gating_fail")
+    e["reject_reason"] = e["decision"]
+    e["ffn_proxy_available"] = res["proxy_available"]
+    if res["proxy_available"]:
+        e["ffn_proxy_reason"] = ""
+        e["ffn_proxy_scope"] = "replace_only_current_tensor"
+        e["ffn_proxy_base_used"] = False
+        e["ffn_proxy_seed"] = params.seed + layer * 101 + KIND_ID[kind] + 1
+        for i, (n, v) in enumerate(zip(PROXY_NAMES, res["proxy"])):
+            e[n] = int(v) if i >= 6 else float(v)
+    else:
+        coo_nobase = params.scheme == "coo" and not params.base and params.eval_x > 0
+        e["ffn_proxy_reason"] = (("proxy_kind_not_supported" if kind == "ffn_down" else "proxy_unavailable") if coo_nobase
+                                 else "proxy_requires_eval_x" if params.eval_x <= 0 else "proxy_requires_coo")
+    return e
+
+
+def round_like_report(v):
+    """report.json is written through an ostream at default precision: 6 significant digits."""
+    if isinstance(v, bool) or not isinstance(v, float):
+        return v
+    return float(f"{v:.6g}")
+
+
+# ---- scripts/seeddelta-layer-scan.py ------------------------------------------------------------------------
+def write_policy(layer: int, tensors: Sequence[str], k: int, metric: str) -> dict:
+    """The per-layer policy document the scan hands to the builder (layer-scan.py:31-59)."""
+    return {
+        "version": 1,
+        "defaults": {"enabled": False, "gating": {"metric": metric, "min_mean": -1.0, "min_p05": -1.0},
+                     "autotune": {"enabled": False}},
+        "ranges": [{
+            "layers": str(layer), "enabled": True, "strip_dense": False,
+            "K": {"gate": k, "up": k, "down": k},
+            "gating": {"metric": metric, "min_mean": {"gate": 0.0, "up": 0.0, "down": 0.0},
+                       "min_p05": {"gate": 0.0, "up": 0.0, "down": 0.0}},
+            "tensors": {t: {"enabled": t in tensors} for t in KINDS},
+            "autotune": {"enabled": False},
+        }],
+    }
+
+
+def collect_metrics(entry: dict) -> dict:
+    """report.json entry -> scan record (layer-scan.py:62-122), field for field."""
+    def f(key):
+        v = entry.get(key)
+        try:
+            return None if v is None else float(v)
+        except (TypeError, ValueError):
+            return None
+    nr = f("norm_ratio_mean") or 0.0
+    proxy = {k: f(k) for k in PROXY_NAMES[:6]}
+    score = None
+    if None not in (proxy["ffn_proxy_cos_p05"], proxy["ffn_proxy_l2_p95"], proxy["ffn_proxy_log_norm_ratio_p95"]):
+        score = max(1.0 - proxy["ffn_proxy_cos_p05"], proxy["ffn_proxy_l2_p95"], abs(proxy["ffn_proxy_log_norm_ratio_p95"]))
+    out = {"S_mean": f("rel_l2_mean") or 0.0, "S_p95": f("rel_l2_p95") or 0.0,
+           "cos_mean": f("cos_mean") or 0.0, "cos_p05": f("cos_p05") or 0.0,
+           "cos_mean_x_w": f("cos_mean_x_w") or 0.0, "cos_p05_x_w": f("cos_p05_x_w") or 0.0,
+           "log_norm_ratio_mean": math.log(nr) if nr > 0 else 0.0, "log_norm_ratio_p95": None,
+           "ffn_proxy_available": bool(entry.get("ffn_proxy_available", False))}
+    out.update(proxy)
+    out["ffn_proxy_score"] = score
+    out["raw"] = {"rel_l2_mean": out["S_mean"], "rel_l2_p95": out["S_p95"], "norm_ratio_mean": nr}
+    return out
+
+
+ModelFn = Callable[[int, str], np.ndarray]        # (layer, kind) -> dense weight array
+
+
+@dataclass
+class Candidate:
+    layer: int
+    kind: str
+    K: int
+
+    def key(self):
+        return (self.layer, KIND_ID[self.kind], self.K)
+
+
+def enumerate_candidates(layers: Iterable[int], tensors: Sequence[str], k_grid: Dict[str, Sequence[int]]) -> List[Candidate]:
+    """All (layer, tensor, K) trials of a sweep, in the order a serial run visits them."""
+    return [Candidate(l, t, k) for l in layers for t in tensors for k in k_grid[t]]
+
+
+def shard(cands: Sequence[Candidate], rank: int, world: int, cost: Callable[[Candidate], float]) -> List[Candidate]:
+    """Deal candidates to ranks: heaviest first, each to the least-loaded rank so far (ties -> lowest
+    rank). Deterministic and independent of who calls it."""
+    load = [0.0] * world
+    mine = []
+    for c in sorted(cands, key=lambda c: (-cost(c), c.key())):
+        r = min(range(world), key=lambda i: (load[i], i))
+        load[r] += cost(c)
+        if r == rank:
+            mine.append(c)
+    return mine
+
+
+RECORD_LEN = 40
+
+
+def to_record(c: Candidate, res: dict) -> np.ndarray:
+    r = np.zeros(RECORD_LEN)
+    r[0:3] = c.key()
+    r[3:9] = [res["K_eff"], res["n_blocks"], res["L"], res["B"], res["has_x"], res["proxy_available"]]
+    r[9:14], r[14:19], r[19:27], r[27:35] = res["em"], res["em_x"], res["cost"], res["proxy"]
+    r[35] = res["gpu_ms"]
+    return r
+
+
+def from_record(r: np.ndarray) -> Tuple[Candidate, dict]:
+    c = Candidate(int(r[0]), KINDS[int(r[1])], int(r[2]))
+    res = {"K_eff": int(r[3]), "n_blocks": int(r[4]), "L": int(r[5]), "B": int(r[6]), "has_x": bool(r[7]),
+           "proxy_available": bool(r[8]), "em": r[9:14].copy(), "em_x": r[14:19].copy(), "cost": r[19:27].copy(),
+           "proxy": r[27:35].copy(), "gpu_ms": float(r[35])}
+    return c, res
+
+
+def gather_records(local: np.ndarray, counts: Sequence[int], device=None) -> np.ndarray:
+    """The scan's only collective: all ranks exchange their fixed-size result records
+    (``torch.distributed.all_gather`` — RCCL over xGMI on the GPU box, gloo in the CPU tests)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local
+    n_max = max(counts)
+    buf = torch.zeros((n_max, RECORD_LEN), dtype=torch.float64, device=device)
+    if len(local):
+        buf[:len(local)] = torch.from_numpy(np.ascontiguousarray(local)).to(buf.device)
+    parts = [torch.empty_like(buf) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, buf)
+    return np.concatenate([p[:n].cpu().numpy() for p, n in zip(parts, counts)], axis=0)
+
+
+class Evaluator:
+    """Runs candidates on this rank's GPU, keeping dense tensors resident across candidates."""
+
+    def __init__(self, model: ModelFn, params: ScanParams, tensors: Sequence[str] = KINDS, max_resident: int = 12):
+        self.model, self.params = model, params
+        self.tensors = tuple(t for t in KINDS if t in tensors)      # the builder's visiting order
+        self._cache: Dict[Tuple[int, str], DenseWeight] = {}
+        self._order: List[Tuple[int, str]] = []
+        self.max_resident = max_resident
+
+    def dense(self, layer: int, kind: str) -> DenseWeight:
+        key = (layer, kind)
+        if key not in self._cache:
+            while len(self._order) >= self.max_resident:
+                self._cache.pop(self._order.pop(0)).close()
+            self._cache[key] = DenseWeight(self.model(layer, kind))
+            self._order.append(key)
+        return self._cache[key]
+
+    def run(self, c: Candidate) -> dict:
+        """One (layer, tensor, K) trial with the RNG position a serial per-layer builder run has when
+        it reaches this tensor: fresh stream, earlier tensors of the layer skipped."""
+        p = ScanParams(**{**self.params.__dict__, "K": c.K})
+        s = ScanSession(p.seed)
+        try:
+            for t in self.tensors:
+                if t == c.kind:
+                    break
+                w = self.dense(c.layer, t)
+                s.skip(w.n_in, w.n_out, p, t, c.layer)
+            need_proxy = p.scheme == "coo" and not p.base and p.eval_x > 0 and c.kind != "ffn_down"
+            ffn = tuple(self.dense(c.layer, k) for k in KINDS) if need_proxy else None
+            return s.tensor(self.dense(c.layer, c.kind), p, c.kind, c.layer, ffn)
+        finally:
+            s.close()
+
+    def close(self):
+        for w in self._cache.values():
+            w.close()
+        self._cache.clear()
+        self._order.clear()
+
+
+def layer_scan(model: ModelFn, layers: Sequence[int], params: ScanParams, tensors: Sequence[str] = KINDS,
+               input_name: str = "<memory>", rounded: bool = True) -> dict:
+    """scripts/seeddelta-layer-scan.py main loop (:173-286) with the builder subprocess replaced by
+    the GPU pipeline. Returns the layer_sensitivity_scan.json document."""
+    scan = {
+        "version": 1, "input": input_name, "scheme": params.scheme,
+        "block": params.block if params.scheme == "block" else 0, "K_fixed": params.K,
+        "eval_cols": params.eval_cols, "eval_x": params.eval_x, "seed": params.seed,
+        "base_used": bool(params.base), "row_scale": bool(params.row_scale), "strip_dense": False,
+        "meta": {"scheme": params.scheme, "block": params.block if params.scheme == "block" else 0,
+                 "K_fixed": params.K, "eval_cols": params.eval_cols, "eval_x": params.eval_x, "seed": params.seed,
+                 "metric": params.metric, "tensors_scanned": list(tensors), "seed_delta_bin": "libseeddelta_hip.so",
+                 "threads": 0, "base_used": bool(params.base), "row_scale": bool(params.row_scale),
+                 "strip_dense": False, "imatrix": ""},
+        "layers": {}, "errors": [],
+    }
+    ev = Evaluator(model, params, tensors)
+    try:
+        for layer in layers:
+            out = {}
+            for kind in [t for t in KINDS if t in tensors]:
+                res = ev.run(Candidate(layer, kind, params.K))
+                w = ev.dense(layer, kind)
+                e = report_entry(layer, kind, w.n_in, w.n_out, params, res)
+                if rounded:
+                    e = {k: round_like_report(v) for k, v in e.items()}
+                out[kind] = collect_metrics(e)
+            if not out:
+                scan["errors"].append({"layer": layer, "error": "no weights matched"})
+            scan["layers"][str(layer)] = out
+    finally:
+        ev.close()
+    return scan
+
+
+def dumps(doc: dict) -> str:
+    return json.dumps(doc, indent=2) + "\n"

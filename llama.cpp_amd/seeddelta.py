@@ -34,6 +34,8 @@ ABI_SYMBOLS = [
     "sdh_weight_create", "sdh_weight_destroy", "sdh_weight_op_kind", "sdh_weight_payload_bytes",
     "sdh_forward", "sdh_nonfinite_count", "sdh_w0_tile",
     "sdh_profile_enable", "sdh_profile_read", "sdh_profile_span_begin", "sdh_profile_span_end",
+    "sdh_dense_create", "sdh_dense_destroy", "sdh_dense_bytes",
+    "sdh_scan_create", "sdh_scan_destroy", "sdh_scan_tensor", "sdh_scan_skip", "sdh_scan_fetch",
 ]
 
 
@@ -46,6 +48,20 @@ class SdhWeightDesc(C.Structure):
     _fields_ = [("n_in", C.c_int64), ("n_out", C.c_int64)] + [(n, SdhTensor) for n in (
         "d_idx", "d_val", "b_idx", "b_val", "row_scale",
         "base_d1", "base_d2", "base_d3", "base_perm1", "base_perm2")]
+
+
+class SdhScanParams(C.Structure):
+    _fields_ = [("scheme", C.c_int32), ("kind", C.c_int32), ("K", C.c_int64), ("block", C.c_int64),
+                ("write_base", C.c_int32), ("write_row_scale", C.c_int32), ("base_max_samples", C.c_int64),
+                ("base_perm_trials", C.c_int32), ("want_proxy", C.c_int32), ("eval_cols", C.c_int64),
+                ("eval_x", C.c_int64), ("proxy_seed", C.c_int32), ("reserved", C.c_int32)]
+
+
+class SdhScanResult(C.Structure):
+    _fields_ = [("K_eff", C.c_int64), ("n_blocks", C.c_int64), ("L", C.c_int64), ("B", C.c_int64),
+                ("has_x", C.c_int32), ("proxy_available", C.c_int32), ("em", C.c_double * 5),
+                ("em_x", C.c_double * 5), ("cost", C.c_double * 8), ("proxy", C.c_double * 8),
+                ("gpu_ms", C.c_double)]
 
 
 class SeedDeltaError(RuntimeError):
@@ -109,6 +125,18 @@ def load_library(path: str = LIB_PATH):
     lib.sdh_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.sdh_profile_span_begin.argtypes = [C.c_void_p]
     lib.sdh_profile_span_end.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.sdh_dense_create.argtypes = [C.POINTER(SdhTensor), C.POINTER(C.c_void_p)]
+    lib.sdh_dense_destroy.argtypes = [C.c_void_p]
+    lib.sdh_dense_destroy.restype = None
+    lib.sdh_dense_bytes.argtypes = [C.c_void_p]
+    lib.sdh_dense_bytes.restype = C.c_int64
+    lib.sdh_scan_create.argtypes = [C.c_uint32, C.POINTER(C.c_void_p)]
+    lib.sdh_scan_destroy.argtypes = [C.c_void_p]
+    lib.sdh_scan_destroy.restype = None
+    lib.sdh_scan_tensor.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.POINTER(SdhScanParams), C.POINTER(SdhScanResult)]
+    lib.sdh_scan_skip.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(SdhScanParams)]
+    lib.sdh_scan_fetch.argtypes = [C.c_void_p] + [C.c_void_p] * 7
     _lib = lib
     return lib
 

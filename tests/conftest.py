@@ -22,7 +22,18 @@ def pytest_configure(config):
 
 
 def golden_names():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+    """forward-op fixtures (reference TU outputs)"""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and not f.startswith("scan_"))
+
+
+def scan_golden_names():
+    """builder-evaluation fixtures (reference sd_eval / sd_ffn_proxy / sd_cost outputs)"""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f.startswith("scan_"))
+
+
+def load_scan_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    return {k: (z[k] if z[k].ndim else z[k].item()) for k in z.files}
 
 
 def load_golden(name):

@@ -1,0 +1,194 @@
+"""GPU parity tests of the scan pipeline (sdh_scan_* through the C ABI) against
+  * the committed goldens computed by the reference's own builder code (tests/golden/scan_*.npz,
+    made by oracle/make_scan_golden.py), and
+  * the scan oracle (oracle/sd_scan_oracle.c, pinned bit-for-bit to that reference code) on seeded
+    inputs, consuming an identical mt19937 stream.
+
+Bars:
+  * base fit (h2, d2, perm1, perm1_inv): bit-exact;
+  * selected indices and values: bit-exact (ties ordered by ascending index on both sides);
+  * row_scale: fp32, |diff| <= 1 ulp (the LSQ sums are tree-reduced in double on the GPU);
+  * metrics (double): relative 1e-9 when evaluated on identical idx/val/row_scale; 2e-6 end to end
+    when a 1-ulp row_scale difference may enter.
+"""
+import numpy as np
+import pytest
+
+import scan_py as S
+from conftest import load_scan_golden, scan_golden_names
+from llama_cpp_amd import scan as SC
+from llama_cpp_amd.dense import make_dense
+
+pytestmark = pytest.mark.gpu
+
+KIND = SC.KINDS
+
+
+def ulp_close(a, b, ulps=1):
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    return np.all(np.abs(a - b) <= ulps * np.spacing(np.maximum(np.abs(a), np.abs(b))))
+
+
+def run_gpu(g):
+    ws = {k: SC.DenseWeight(g[k]) for k in ("Wg", "Wu", "Wd") if k in g}
+    W = ws[("Wg", "Wu", "Wd")[g["kind"]]]
+    p = SC.ScanParams(scheme="block" if g["scheme"] else "coo", K=g["K"], block=g["block"], base=bool(g["base"]),
+                      row_scale=bool(g["row_scale"]), base_max_samples=g["max_samples"], base_perm_trials=g["trials"],
+                      eval_cols=g["eval_cols"], eval_x=g["eval_x"], seed=g["seed"])
+    s = SC.ScanSession(g["seed"])
+    ffn = (ws["Wg"], ws["Wu"], ws["Wd"]) if len(ws) == 3 else None
+    res = s.tensor(W, p, KIND[g["kind"]], g["layer"], ffn)
+    return s, p, res, W
+
+
+@pytest.mark.parametrize("name", scan_golden_names())
+def test_scan_matches_reference_goldens(hip, name):
+    g = load_scan_golden(name)
+    s, p, res, W = run_gpu(g)
+    out = s.fetch()
+    Wnp = g[("Wg", "Wu", "Wd")[g["kind"]]]
+    fit = None
+    if g["base"]:
+        for a, b in (("d2", "fit_d2"), ("h2", "fit_h2")):
+            assert np.array_equal(out[a].view(np.uint32), g[b].view(np.uint32)), a
+        assert np.array_equal(out["perm1"], g["fit_perm1"]) and np.array_equal(out["perm1_inv"], g["fit_inv"])
+        fit = S.Fit(res["L"], res["B"], g["fit_d2"], g["fit_h2"], g["fit_perm1"], g["fit_inv"])
+    Ksel = res["n_blocks"] if g["scheme"] else res["K_eff"]
+    idx, val, rs = S.select_rows(Wnp, fit, g["scheme"], Ksel, g["block"], bool(g["row_scale"]))
+    assert np.array_equal(out["idx"], idx)
+    assert np.array_equal(out["val"].view(np.uint32), val.view(np.uint32))
+    if g["row_scale"]:
+        assert ulp_close(out["row_scale"], rs)
+    assert np.array_equal(res["cost"], g["cost"])
+    assert np.allclose(res["em"], g["em"], rtol=2e-6, atol=1e-12), (res["em"], g["em"])
+    assert np.allclose(res["em_x"], g["em_x"], rtol=2e-6, atol=1e-12), (res["em_x"], g["em_x"])
+    assert res["proxy_available"] == bool(g["proxy_ok"])
+    if g["proxy_ok"]:
+        assert np.allclose(res["proxy"], g["proxy"], rtol=1e-9, atol=1e-12), (res["proxy"], g["proxy"])
+    # same idx/val/row_scale on both sides: only the reduction order differs
+    o = S.Engine("oracle", g["seed"])
+    if g["base"]:
+        o.fit_base(Wnp, g["max_samples"], g["trials"])
+    em = o.eval_w(Wnp, fit, g["scheme"], out["idx"], out["val"], Ksel, g["block"], out["row_scale"], g["eval_cols"])
+    em_x = o.eval_x(Wnp, fit, g["scheme"], out["idx"], out["val"], Ksel, g["block"], out["row_scale"], g["eval_cols"], g["eval_x"])
+    assert np.allclose(res["em"], em, rtol=1e-9, atol=1e-14)
+    assert np.allclose(res["em_x"], em_x, rtol=1e-9, atol=1e-14)
+    # and the session's RNG stands where the reference's does: a follow-up draw-only tensor agrees
+    assert o.u32() == g["next_u32"]
+
+
+@pytest.mark.parametrize("dims", [(512, 1408), (1408, 512), (1024, 1024), (288, 800)])
+@pytest.mark.parametrize("wtype", ["q8_0", "f16"])
+def test_base_fit_bit_exact(hip, dims, wtype):
+    n_in, n_out = dims
+    W = make_dense(n_in, n_out, wtype, seed=n_in + 1)
+    o = S.Engine("oracle", 77)
+    fit = o.fit_base(W, 200, 3)
+    s = SC.ScanSession(77)
+    dw = SC.DenseWeight(W)
+    res = s.tensor(dw, SC.ScanParams(K=8, base=True, base_max_samples=200, base_perm_trials=3, eval_cols=0, eval_x=0, seed=77))
+    out = s.fetch()
+    assert (res["L"], res["B"]) == (fit.L, fit.B)
+    assert np.array_equal(out["h2"].view(np.uint32), fit.h2.view(np.uint32))
+    assert np.array_equal(out["d2"].view(np.uint32), fit.d2.view(np.uint32))
+    assert np.array_equal(out["perm1"], fit.perm1) and np.array_equal(out["perm1_inv"], fit.perm1_inv)
+
+
+@pytest.mark.parametrize("scheme,K,block", [("coo", 1, 32), ("coo", 12, 32), ("coo", 200, 32), ("coo", 511, 32),
+                                            ("block", 16, 16), ("block", 100, 32), ("block", 24, 8)])
+@pytest.mark.parametrize("base", [False, True])
+def test_selection_vs_oracle(hip, scheme, K, block, base):
+    """int8-grid weights (Q8_0, no base) make equal scores common: the tie rule is exercised."""
+    W = make_dense(544, 700, "q8_0", seed=K)
+    o = S.Engine("oracle", 5)
+    fit = o.fit_base(W, 64, 2) if base else None
+    p = SC.ScanParams(scheme=scheme, K=K, block=block, base=base, row_scale=True, base_max_samples=64, base_perm_trials=2,
+                      eval_cols=0, eval_x=0, seed=5)
+    s = SC.ScanSession(5)
+    res = s.tensor(SC.DenseWeight(W), p)
+    out = s.fetch()
+    sch = 1 if scheme == "block" else 0
+    Ksel = res["n_blocks"] if sch else res["K_eff"]
+    idx, val, rs = S.select_rows(W, fit, sch, Ksel, block, True)
+    assert np.array_equal(out["idx"], idx)
+    assert np.array_equal(out["val"].view(np.uint32), val.view(np.uint32))
+    assert ulp_close(out["row_scale"], rs)
+    if not base:
+        assert np.all(out["row_scale"] == 1.0)
+
+
+def test_skip_reproduces_stream_position(hip):
+    """A rank that owns (layer, ffn_up) skips ffn_gate: same results as the serial gate -> up run."""
+    Wg, Wu = make_dense(320, 800, "q8_0", seed=1), make_dense(320, 800, "q8_0", seed=2)
+    p = SC.ScanParams(K=24, base=True, row_scale=True, base_max_samples=100, base_perm_trials=2, eval_cols=16, eval_x=4)
+    dg, du = SC.DenseWeight(Wg), SC.DenseWeight(Wu)
+    a = SC.ScanSession(p.seed)
+    a.tensor(dg, p, "ffn_gate", 3)
+    ra = a.tensor(du, p, "ffn_up", 3)
+    b = SC.ScanSession(p.seed)
+    b.skip(320, 800, p, "ffn_gate", 3)
+    rb = b.tensor(du, p, "ffn_up", 3)
+    for k in ("em", "em_x", "cost"):
+        assert np.array_equal(ra[k], rb[k]), k
+    fa, fb = a.fetch(), b.fetch()
+    assert np.array_equal(fa["idx"], fb["idx"]) and np.array_equal(fa["perm1"], fb["perm1"])
+
+
+def test_layer_scan_document(hip):
+    """layer_scan() == collect_metrics over oracle-built report entries, for a 2-layer toy model."""
+    def model(layer, kind):
+        n_embd, n_ff = 256, 640
+        shape = (n_ff, n_embd) if kind != "ffn_down" else (n_embd, n_ff)
+        return make_dense(shape[1], shape[0], "q8_0", seed=100 * layer + SC.KIND_ID[kind])
+    p = SC.ScanParams(K=12, eval_cols=16, eval_x=4)
+    doc = SC.layer_scan(model, [0, 1], p)
+    assert set(doc["layers"]) == {"0", "1"} and doc["K_fixed"] == 12 and doc["errors"] == []
+    for layer in (0, 1):
+        o = S.Engine("oracle", p.seed)
+        ws = {k: model(layer, k) for k in SC.KINDS}
+        for kind in SC.KINDS:
+            W = ws[kind]
+            idx, val, _ = S.select_rows(W, None, 0, 12, 32, False)
+            em = o.eval_w(W, None, 0, idx, val, 12, 32, None, 16)
+            em_x = o.eval_x(W, None, 0, idx, val, 12, 32, None, 16, 4)
+            ok, proxy = o.ffn_proxy(SC.KIND_ID[kind], ws["ffn_gate"], ws["ffn_up"], ws["ffn_down"], idx, val, 12, 4, 16,
+                                    p.seed + 101 * layer + SC.KIND_ID[kind] + 1)
+            rec = doc["layers"][str(layer)][kind]
+            assert rec["S_mean"] == pytest.approx(em[0], rel=2e-6)      # 6 significant digits, as report.json
+            assert rec["cos_p05"] == pytest.approx(em[3], rel=2e-6)
+            assert rec["ffn_proxy_available"] == ok == (kind != "ffn_down")
+            if ok:
+                assert rec["ffn_proxy_cos_p05"] == pytest.approx(proxy[1], rel=2e-6)
+                assert rec["ffn_proxy_score"] == pytest.approx(max(1 - proxy[1], proxy[3], abs(proxy[5])), rel=2e-5)
+
+
+def test_full_size_properties(hip):
+    """Mistral-7B gate dims (4096 -> 14336, Q8_0), K=128 COO + base: properties that need no oracle run."""
+    W = make_dense(4096, 14336, "q8_0", seed=9, structure=0.3)
+    p = SC.ScanParams(K=128, base=True, row_scale=True, eval_cols=64, eval_x=8)
+    s = SC.ScanSession(p.seed)
+    dw = SC.DenseWeight(W)
+    assert dw.stored_bytes == 14336 * 4096 // 32 * 34
+    res = s.tensor(dw, p)
+    out = s.fetch()
+    assert (res["L"], res["B"], res["K_eff"]) == (4096, 4, 128)
+    idx = out["idx"]
+    assert idx.min() >= 0 and idx.max() < 4096
+    assert all(len(set(r.tolist())) == 128 for r in idx[::997])              # no duplicates
+    a = np.abs(out["val"])
+    assert np.all(a[:, :-1] >= a[:, 1:])                                     # sorted by |residual| descending
+    for b in range(4):
+        assert sorted(out["perm1"][b].tolist()) == list(range(4096))          # a permutation
+        assert np.array_equal(out["perm1"][b][out["perm1_inv"][b]], np.arange(4096))
+    # threshold property on a few rows, against the oracle's row reader
+    o = S.Engine("oracle", 0)
+    fit = S.Fit(4096, 4, out["d2"], out["h2"], out["perm1"], out["perm1_inv"])
+    for row in (0, 5000, 14335):
+        w = o.read_row(W, row)
+        b, pp = divmod(row, 4096)
+        r = w - out["h2"][b][(pp ^ out["perm1_inv"][b]) & 4095]
+        assert np.array_equal(out["val"][row], r[idx[row]])
+        rest = np.delete(np.abs(r), idx[row])
+        assert rest.max() <= a[row, -1]
+    assert 0.0 < res["em"][0] < 1.0 and res["em"][2] > 0.5 and res["has_x"]
+    print(f"\nfull-size candidate: {res['gpu_ms']:.2f} ms on device")
