@@ -211,6 +211,20 @@ def round_like_report(v):
 
 
 # ---- scripts/seeddelta-layer-scan.py ------------------------------------------------------------------------
+def parse_layers(spec: str) -> List[int]:
+    """"0-31" / "0,2,4" / mixed -> sorted unique layer list (layer-scan.py:13-28; reversed ranges swap)."""
+    layers = set()
+    for token in (t.strip() for t in spec.split(",")):
+        if not token:
+            continue
+        if "-" in token:
+            lo, hi = (int(v) for v in token.split("-", 1))
+            layers.update(range(min(lo, hi), max(lo, hi) + 1))
+        else:
+            layers.add(int(token))
+    return sorted(layers)
+
+
 def write_policy(layer: int, tensors: Sequence[str], k: int, metric: str) -> dict:
     """The per-layer policy document the scan hands to the builder (layer-scan.py:31-59)."""
     return {

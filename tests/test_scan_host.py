@@ -1,0 +1,131 @@
+"""Host logic of the scan (no GPU): the script mirrors against fixtures produced by the reference's own
+scripts/seeddelta-layer-scan.py (tests/golden/layer_scan_script.json, made by
+oracle/make_script_golden.py), report-entry gating, candidate sharding, and the one collective of the
+multi-GPU scan on gloo with world_size 2."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, ROOT
+from llama_cpp_amd import scan as SC
+
+
+@pytest.fixture(scope="module")
+def script_golden():
+    with open(os.path.join(GOLDEN_DIR, "layer_scan_script.json")) as fh:
+        return json.load(fh)
+
+
+def test_parse_layers(script_golden):
+    for case in script_golden["parse_layers"]:
+        assert SC.parse_layers(case["spec"]) == case["layers"], case["spec"]
+
+
+def test_collect_metrics_matches_reference_script(script_golden):
+    for case in script_golden["collect_metrics"]:
+        got = SC.collect_metrics(case["entry"])
+        assert got == case["metrics"]
+        assert list(got) == list(case["metrics"])          # same key order in the JSON document
+
+
+def test_write_policy_matches_reference_script(script_golden):
+    for case in script_golden["write_policy"]:
+        assert SC.write_policy(case["layer"], case["tensors"], case["k"], case["metric"]) == case["policy"]
+
+
+def fake_result(has_x=True, proxy=False, cos=(0.6, 0.4), cos_x=(0.7, 0.5)):
+    return {"K_eff": 12, "n_blocks": 1, "L": 0, "B": 0, "has_x": has_x, "proxy_available": proxy,
+            "em": np.array([0.8, 0.9, cos[0], cos[1], 0.6]), "em_x": np.array([0.7, 0.8, cos_x[0], cos_x[1], 0.7]),
+            "cost": np.array([0, 0, 100.0, 0, 10.0, 0, 10.0, 0.1]), "proxy": np.arange(8.0), "gpu_ms": 1.0}
+
+
+def test_report_entry_gating_rules():
+    p = SC.ScanParams()
+    # gate/up with x metrics gate on ffn_score = min(cos_mean_x, cos_p05_x) (sd_build.cpp:810-816, sd_report.cpp:72-88)
+    e = SC.report_entry(3, "ffn_gate", 256, 704, p, fake_result())
+    assert e["gating_metric"] == "ffn_score" and e["ffn_score"] == 0.5 and e["gating_pass"] and e["decision"] == "pass_gating"
+    # down keeps the policy metric
+    e = SC.report_entry(3, "ffn_down", 704, 256, p, fake_result())
+    assert e["gating_metric"] == "cos" and e["gating_value"] == 0.6 and e["gating_p05"] == 0.4
+    assert e["ffn_proxy_available"] is False and e["ffn_proxy_reason"] == "proxy_kind_not_supported"
+    # thresholds
+    e = SC.report_entry(3, "ffn_down", 704, 256, p, fake_result(), min_mean=0.7)
+    assert not e["emit"] and e["decision"] == "gating_fail"
+    # metric needing x without x
+    q = SC.ScanParams(metric="cos_x", eval_x=0)
+    e = SC.report_entry(3, "ffn_down", 704, 256, q, fake_result(has_x=False))
+    assert e["decision"] == "metric_unavailable" and not e["gating_pass"] and e["ffn_proxy_reason"] == "proxy_requires_eval_x"
+    e = SC.report_entry(3, "ffn_gate", 256, 704, SC.ScanParams(scheme="block"), fake_result())
+    assert e["ffn_proxy_reason"] == "proxy_requires_coo"
+    e = SC.report_entry(3, "ffn_up", 256, 704, p, fake_result(proxy=True))
+    assert e["ffn_proxy_seed"] == 1234 + 303 + 2 and e["ffn_proxy_eval_x"] == 6 and e["ffn_proxy_cos_p05"] == 1.0
+    assert SC.round_like_report(0.123456789) == 0.123457 and SC.round_like_report(True) is True
+
+
+def test_shard_is_a_balanced_partition():
+    grid = {"ffn_gate": [128, 256, 384], "ffn_up": [128, 256, 384], "ffn_down": [256, 512, 1536]}
+    cands = SC.enumerate_candidates(range(32), SC.KINDS, grid)
+    assert len(cands) == 32 * 9
+    cost = lambda c: 1.0 + c.K / 1536.0        # noqa: E731
+    for world in (1, 2, 4, 8):
+        parts = [SC.shard(cands, r, world, cost) for r in range(world)]
+        keys = sorted(k for p in parts for k in (c.key() for c in p))
+        assert keys == sorted(c.key() for c in cands)                        # a partition: nothing lost or doubled
+        loads = [sum(cost(c) for c in p) for p in parts]
+        assert max(loads) - min(loads) <= 2.0                                # within one candidate of each other
+    assert SC.shard(cands, 1, 4, cost) == SC.shard(list(reversed(cands)), 1, 4, cost)   # order-independent
+
+
+def test_record_round_trip():
+    c = SC.Candidate(17, "ffn_down", 1536)
+    res = fake_result(proxy=True)
+    c2, r2 = SC.from_record(SC.to_record(c, res))
+    assert c2 == c
+    for k in ("em", "em_x", "cost", "proxy"):
+        assert np.array_equal(res[k], r2[k])
+    assert r2["has_x"] and r2["proxy_available"] and r2["K_eff"] == 12
+
+
+WORKER = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import torch.distributed as dist
+import llama_cpp_amd
+from llama_cpp_amd import scan as SC
+dist.init_process_group(backend="gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+grid = {"ffn_gate": [128, 256], "ffn_up": [128], "ffn_down": [256, 512]}
+cands = SC.enumerate_candidates(range(3), SC.KINDS, grid)
+cost = lambda c: 1.0 + c.K / 512.0
+mine = SC.shard(cands, rank, world, cost)
+def fake(c):
+    v = float(c.layer * 1000 + SC.KIND_ID[c.kind] * 100) + c.K / 1000.0
+    return {"K_eff": c.K, "n_blocks": 1, "L": 0, "B": 0, "has_x": True, "proxy_available": False,
+            "em": np.full(5, v), "em_x": np.full(5, v + 0.5), "cost": np.zeros(8), "proxy": np.zeros(8), "gpu_ms": 1.0}
+local = np.stack([SC.to_record(c, fake(c)) for c in mine]) if mine else np.zeros((0, SC.RECORD_LEN))
+counts = [len(SC.shard(cands, r, world, cost)) for r in range(world)]
+allr = SC.gather_records(local, counts)
+got = {SC.from_record(r)[0].key(): SC.from_record(r)[1]["em"][0] for r in allr}
+want = {c.key(): fake(c)["em"][0] for c in cands}
+assert got == want, (rank, len(got), len(want))
+dist.barrier()
+if rank == 0:
+    print("GATHER_OK", len(allr))
+dist.destroy_process_group()
+"""
+
+
+def test_gather_records_world_size_2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29517", str(script), ROOT],
+                         capture_output=True, text=True, env=env, timeout=240)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "GATHER_OK 15" in out.stdout
