@@ -52,6 +52,9 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-scan", action="store_true", help="skip the scan (candidates/s) leg")
+    ap.add_argument("--scan-layers", type=int, default=8, help="synthetic Mistral-7B layers in the scan job")
+    ap.add_argument("--scan-threads", type=int, default=8, help="host threads preparing candidates per rank")
     ap.add_argument("--host-io", action="store_true",
                     help="also time the PCIe-inclusive boundary (host x in, host y out, one sync per call: what "
                          "the shim pays per graph node); reported as a separate field, never as value")
@@ -86,6 +89,126 @@ def cpu_baseline(workload: str, tokens: int, budget_s: float):
         "kind": "reference" if use_ref else "port",
         "sample": f"{n} evaluations of {workload} at T={tokens} in {el:.1f}s, {cores} threads{note}",
     }
+
+
+# K schedules of policies/policy.mistral7b.base.json (gate/up 128..768, down 256..1536): two points each
+SCAN_K = {"ffn_gate": (128, 768), "ffn_up": (128, 768), "ffn_down": (256, 1536)}
+MISTRAL = {"n_embd": 4096, "n_ff": 14336}
+
+
+_SCAN_BASE = {}
+
+
+def scan_dims(layer, kind):
+    return (MISTRAL["n_ff"], MISTRAL["n_embd"]) if kind == "ffn_down" else (MISTRAL["n_embd"], MISTRAL["n_ff"])
+
+
+def scan_model(layer, kind):
+    """Synthetic Mistral-7B FFN tensor in Q8_0: 0.02*N(0,1) with an XOR-circulant component, one
+    draw per tensor kind; layers differ by a rotation of the output rows (cheap to make, distinct
+    contents, same statistics)."""
+    from llama_cpp_amd.dense import make_dense
+    from llama_cpp_amd.scan import KIND_ID
+    if kind not in _SCAN_BASE:
+        n_in, n_out = scan_dims(layer, kind)
+        _SCAN_BASE[kind] = make_dense(n_in, n_out, "q8_0", seed=1234 + KIND_ID[kind], structure=0.3)
+    return np.roll(_SCAN_BASE[kind], 97 * layer, axis=0)
+
+
+def scan_variants():
+    from llama_cpp_amd.scan import ScanParams
+    return {0: ScanParams(scheme="coo", base=False, row_scale=False, eval_cols=64, eval_x=32),          # proxy on
+            1: ScanParams(scheme="coo", base=True, row_scale=True, eval_cols=64, eval_x=32, base_perm_trials=4)}
+
+
+def run_scan(args, rank, world, dev):
+    """The sweep of config 5, scaled to --scan-layers layers: (layer, tensor, K) candidates in two
+    variants (COO without base + FFN proxy; COO with base + row scale), dealt to ranks, evaluated on
+    each rank's GPU, one all_gather of the records (RCCL). Strong scaling: the job is fixed."""
+    import torch
+    from llama_cpp_amd import scan as SC
+    variants = scan_variants()
+    cands = []
+    for v in variants:
+        for c in SC.enumerate_candidates(range(args.scan_layers), SC.KINDS, SCAN_K):
+            c.variant = v
+            cands.append(c)
+    cost = lambda c: (2.0 if c.variant else 1.0) + c.K / 1536.0       # noqa: E731
+    # all trials of one (layer, tensor) stay on one rank: its dense weight is uploaded once (SURVEY §8e)
+    groups = {}
+    for c in cands:
+        groups.setdefault((c.layer, SC.KIND_ID[c.kind]), []).append(c)
+    load, owner = [0.0] * world, {}
+    for g in sorted(groups, key=lambda g: (-sum(cost(c) for c in groups[g]), g)):     # same greedy deal on every rank
+        r = min(range(world), key=lambda i: (load[i], i))
+        load[r] += sum(cost(c) for c in groups[g])
+        owner[g] = r
+    own = lambda c: owner[(c.layer, SC.KIND_ID[c.kind])]             # noqa: E731
+    mine = [c for c in cands if own(c) == rank]
+    counts = [sum(1 for c in cands if own(c) == r) for r in range(world)]
+    ev = SC.Evaluator(scan_model, variants[0], max_resident=3 * max(1, args.scan_layers), dims_of=scan_dims)
+    for c in mine:                                                    # weights resident before the clock starts
+        for k in (SC.KINDS if c.kind != "ffn_down" else (c.kind,)):
+            ev.dense(c.layer, k)
+    dense_bytes = sum(w.stored_bytes for w in ev._cache.values())
+    ev.run_many(mine[:2], threads=2, params_of=lambda c: variants[c.variant])        # warm-up
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    t0 = time.perf_counter()
+    res = ev.run_many(mine, threads=args.scan_threads, params_of=lambda c: variants[c.variant])
+    local = np.stack([SC.to_record(c, r) for c, r in zip(mine, res)]) if mine else np.zeros((0, SC.RECORD_LEN))
+    allr = SC.gather_records(local, counts, device=dev)
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ev.close()
+    assert len(allr) == len(cands)
+    # algorithmic bytes per candidate (SURVEY §8d): the quantised tensor read once + idx/val/row_scale emitted
+    q8 = MISTRAL["n_embd"] * MISTRAL["n_ff"] // 32 * 34
+    alg = sum(q8 + scan_dims(c.layer, c.kind)[1] * (8 * c.K + 4) for c in cands)
+    out = {"metric": "scan candidates/s", "value": len(cands) / elapsed, "unit": "candidates/s", "n_gpus": world,
+           "scaling": "strong", "candidates": len(cands), "seconds": elapsed,
+           "roofline": {"bound": "hbm", "achieved": alg / elapsed / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                        "frac": alg / elapsed / 1e9 / (HBM_PEAK_GBS * world), "traffic": None,
+                        "note": "whole-pipeline rate (host sample drawing included), not one kernel: the scan is "
+                                "bound by per-row selection and host RNG, not by the weight stream"},
+           "config": {"workload": f"cfg5 subset: {args.scan_layers} synthetic Mistral-7B layers x gate/up/down x "
+                                  f"K {SCAN_K} x {{coo no-base + proxy, coo base + row_scale}}, eval_cols=64 eval_x=32, Q8_0",
+                      "host_threads_per_rank": args.scan_threads, "dense_bytes_resident_per_rank": dense_bytes,
+                      "collective": "one all_gather of %d-double records" % SC.RECORD_LEN}}
+    return out
+
+
+def scan_cpu_baseline(budget_s):
+    """The oracle's restatement of one base+row_scale candidate (fit, run_trial loop on all host
+    threads, evals) on one gate tensor: kind 'port' (sd_build.cpp's run_trial cannot be compiled here)."""
+    import scan_py as S
+    W = scan_model(0, "ffn_gate")
+    cores = min(16, os.cpu_count() or 1)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        o = S.Engine("oracle", 1234)
+        fit = o.fit_base(W, 2048, 4)
+        idx, val, rs = S.select_rows(W, fit, 0, 128, 32, True, nth=cores)
+        o.eval_w(W, fit, 0, idx, val, 128, 32, rs, 64)
+        o.eval_x(W, fit, 0, idx, val, 128, 32, rs, 64, 32)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 50:
+            break
+    return {"value": n / el, "unit": "candidates/s", "cores": cores, "kind": "port",
+            "sample": f"{n} candidates (ffn_gate 4096->14336 Q8_0, COO K=128, base fit 2048 samples x 4 perms, row_scale, "
+                      f"eval_cols=64, eval_x=32) in {el:.1f}s; base fit and evals single-threaded as in the reference, "
+                      f"row loop on {cores} threads"}
 
 
 def main():
@@ -222,6 +345,16 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.workload, T, args.cpu_seconds)
 
+    scan = None
+    if not args.no_scan:
+        for w in weights:
+            w.close()
+        weights.clear()
+        torch.cuda.empty_cache()
+        scan = run_scan(args, rank, world, dev)
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            scan["cpu_baseline"] = scan_cpu_baseline(args.cpu_seconds)
+
     if rank == 0:
         value = world * steps * T / elapsed
         line = {
@@ -236,6 +369,8 @@ def main():
         }
         if host_io is not None:
             line["pcie_inclusive"] = host_io
+        if scan is not None:
+            line["scan"] = scan
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist

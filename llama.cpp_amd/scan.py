@@ -336,12 +336,35 @@ def gather_records(local: np.ndarray, counts: Sequence[int], device=None) -> np.
 class Evaluator:
     """Runs candidates on this rank's GPU, keeping dense tensors resident across candidates."""
 
-    def __init__(self, model: ModelFn, params: ScanParams, tensors: Sequence[str] = KINDS, max_resident: int = 12):
+    def __init__(self, model: ModelFn, params: ScanParams, tensors: Sequence[str] = KINDS, max_resident: int = 12,
+                 dims_of: Optional[Callable[[int, str], Tuple[int, int]]] = None):
         self.model, self.params = model, params
+        self.dims_of = dims_of          # (layer, kind) -> (n_in, n_out) without touching the weights
         self.tensors = tuple(t for t in KINDS if t in tensors)      # the builder's visiting order
         self._cache: Dict[Tuple[int, str], DenseWeight] = {}
         self._order: List[Tuple[int, str]] = []
-        self.max_resident = max_resident
+        self.max_resident = max(3, max_resident)
+
+    def run_many(self, cands: Sequence[Candidate], threads: int = 8, params_of: Optional[Callable] = None) -> List[dict]:
+        """Evaluate candidates layer by layer with a pool of host threads. Every candidate owns its RNG
+        stream, and drawing its samples (std::shuffle, ~26 ns per Gaussian) is the host-side cost of a
+        candidate, so several are prepared concurrently while the GPU works through their kernels in
+        stream order. Dense tensors are uploaded by the calling thread before the pool touches them."""
+        from concurrent.futures import ThreadPoolExecutor
+        out: Dict[tuple, dict] = {}
+        layers: Dict[int, List[Candidate]] = {}
+        for c in cands:
+            layers.setdefault(c.layer, []).append(c)
+        with ThreadPoolExecutor(max_workers=max(1, threads)) as pool:
+            for layer, group in layers.items():
+                proxy = any(c.kind != "ffn_down" for c in group)      # the FFN proxy reads all three tensors
+                for k in KINDS:
+                    if proxy or any(c.kind == k for c in group) or self.dims_of is None:
+                        self.dense(layer, k)
+                fn = self.run if params_of is None else (lambda c: self.run(c, params_of(c)))
+                for c, r in zip(group, pool.map(fn, group)):
+                    out[id(c)] = r
+        return [out[id(c)] for c in cands]
 
     def dense(self, layer: int, kind: str) -> DenseWeight:
         key = (layer, kind)
@@ -352,17 +375,21 @@ class Evaluator:
             self._order.append(key)
         return self._cache[key]
 
-    def run(self, c: Candidate) -> dict:
+    def run(self, c: Candidate, params: Optional[ScanParams] = None) -> dict:
         """One (layer, tensor, K) trial with the RNG position a serial per-layer builder run has when
         it reaches this tensor: fresh stream, earlier tensors of the layer skipped."""
-        p = ScanParams(**{**self.params.__dict__, "K": c.K})
+        p = ScanParams(**{**(params or self.params).__dict__, "K": c.K})
         s = ScanSession(p.seed)
         try:
             for t in self.tensors:
                 if t == c.kind:
                     break
-                w = self.dense(c.layer, t)
-                s.skip(w.n_in, w.n_out, p, t, c.layer)
+                if self.dims_of is not None:
+                    n_in, n_out = self.dims_of(c.layer, t)
+                else:
+                    w = self.dense(c.layer, t)
+                    n_in, n_out = w.n_in, w.n_out
+                s.skip(n_in, n_out, p, t, c.layer)
             need_proxy = p.scheme == "coo" and not p.base and p.eval_x > 0 and c.kind != "ffn_down"
             ffn = tuple(self.dense(c.layer, k) for k in KINDS) if need_proxy else None
             return s.tensor(self.dense(c.layer, c.kind), p, c.kind, c.layer, ffn)
