@@ -101,6 +101,8 @@ typedef enum sdh_op_kind {
                                       result is bit-identical to the CPU op. Slow.             */
 #define SDH_FWD_NO_FUSE      0x10  /* batch-1 decode with a base: run the base and the residual as two
                                       launches instead of the single fused launch (A/B measurement)  */
+#define SDH_FWD_NO_SPMM      0x20  /* many tokens: use the per-token row kernels instead of the token-tiled
+                                      sparse x dense kernel (A/B measurement)                                */
 #define SDH_FWD_W0_MFMA       0x8  /* prefill: evaluate the base as W0 tiles regenerated in LDS
                                       and contracted on MFMA instead of the FWHT form          */
 

@@ -529,7 +529,11 @@ int sdh_forward(sdh_weight * h, const float * x, int64_t ldx, int64_t n_tokens,
         }
         int pair, rc = prof_begin(pair);
         if (rc != SDH_OK) return rc;
-        rc = launch_delta(*w, a, s);
+        // many tokens: token-tiled sparse x dense product (bit-exact order); few: per-token row kernels
+        static const int64_t spmm_min_t = [] { const char * e = getenv("SDH_SPMM_MIN_T"); return e ? (int64_t) atoll(e) : (int64_t) 8; }();
+        rc = 1;
+        if (tc >= spmm_min_t && !a.exact_order && !(flags & SDH_FWD_NO_SPMM)) rc = launch_delta_spmm(*w, a, s);
+        if (rc == 1) rc = launch_delta(*w, a, s);
         if (rc != SDH_OK) return rc;
         rc = prof_end(pair);
         if (rc != SDH_OK) return rc;

@@ -118,6 +118,9 @@ struct DeltaLaunch {
 };
 int launch_delta(const DeviceWeight & w, const DeltaLaunch & a, hipStream_t s);
 
+// Prefill: token-tiled SpMM (sdh_spmm.hip). Returns SDH_OK if launched, 1 if the shape does not fit.
+int launch_delta_spmm(const DeviceWeight & w, const DeltaLaunch & a, hipStream_t s);
+
 // Batch-1 decode with a base as ONE launch (sdh_decode.hip). Returns SDH_OK if launched, 1 if the
 // payload / call does not qualify (caller runs base + delta kernels instead), <0 on error.
 int launch_decode_fused(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s);

@@ -1,0 +1,170 @@
+// sdh_spmm.hip — the residual Δ·X for many tokens (prefill) as a token-tiled sparse × dense product.
+//
+// One workgroup (1024 threads) stages the activations of TT tokens transposed in LDS,
+// xs[i][t] (token fastest, up to 128 KB), then walks a chunk of output rows. A lane owns one
+// (row, token) pair and runs over the row's entries IN ORDER, one separately rounded multiply and
+// one add per entry, starting from the base term — the very sequence the CPU op performs
+// (src/llama-seeddelta.cpp:676-700, :905-945, :1104-1125, :1150-1174), so this path is bit-identical
+// to the reference, not merely within tolerance. The TT lanes of a row read the same idx / val
+// addresses (one broadcast transaction, 8 entries per 16-byte load) and TT consecutive floats of LDS.
+//
+// Costs per launch: the payload is streamed once per token tile (T/TT times, from L2 after the first
+// tile of a row chunk — consecutive workgroups share the chunk), every multiply-add costs one LDS
+// read of 4 bytes. No atomics, no cross-lane reduction.
+#include "sdh_internal.h"
+#include "sdh_delta_dev.h"
+
+namespace sdh {
+
+template <typename IDX_T, typename VAL_T, bool BLOCK, bool VEC, int TT>
+__global__ __launch_bounds__(1024)
+void delta_spmm_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
+#pragma clang fp contract(off)
+    extern __shared__ float xs[];                       // [n_in][TT]
+    const int tid = threadIdx.x;
+    const int64_t t0 = (int64_t) blockIdx.x * TT;
+    const int nt = (int) ((T - t0 < TT) ? (T - t0) : TT);
+    for (int t = 0; t < nt; ++t) {
+        const float * xt = p.x + (t0 + t) * p.ldx;
+        for (int i = tid; i < p.n_in; i += 1024) xs[i * TT + t] = xt[i];
+    }
+    if (nt < TT) {                                      // ragged last tile: idle lanes read zeros
+        for (int i = tid; i < p.n_in; i += 1024)
+            for (int t = nt; t < TT; ++t) xs[i * TT + t] = 0.0f;
+    }
+    __syncthreads();
+
+    const int t = tid % TT;
+    const bool t_ok = t < nt;
+    const int64_t tok = t0 + (t_ok ? t : 0);
+    const int r1 = min(p.n_out, ((int) blockIdx.y + 1) * rows_per_wg);
+    for (int o = (int) blockIdx.y * rows_per_wg + tid / TT; o < r1; o += 1024 / TT) {
+        const VAL_T * vrow = reinterpret_cast<const VAL_T *>(p.val) + (size_t) o * p.Ktot;
+        const IDX_T * irow = reinterpret_cast<const IDX_T *>(p.idx) + (size_t) o * (BLOCK ? p.nb : p.Ktot);
+        float y = 0.0f;
+        if (p.v) {                                      // base term: tall picks, wide sums blocks in order
+            const float * vt = p.v + (size_t) tok * p.B * p.L;
+            if (p.tall) y = vt[o];
+            else for (int b = 0; b < p.B; ++b) y += vt[(size_t) b * p.L + o];
+        }
+        if constexpr (BLOCK) {
+            for (int bi = 0; bi < p.nb; ++bi) {
+                const int blk = idx_to_i32<IDX_T>(irow[bi]);
+                const int64_t in0 = (int64_t) blk * p.block;
+                if (blk < 0 || in0 >= p.n_in) continue;             // uniform over the TT lanes of the row
+                const int len = (int) ((in0 + p.block < p.n_in) ? p.block : (p.n_in - in0));
+                const VAL_T * vb = vrow + (size_t) bi * p.block;
+                const float * xb = xs + (size_t) in0 * TT + t;
+                if constexpr (VEC) {
+                    for (int j = 0; j < p.block; j += 8) {
+                        Vec8<VAL_T> vv;
+                        vv.load(vb + j);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const bool ok = j + u < len;
+                            const float prod = val_to_f32<VAL_T>(vv.get(u)) * xb[(ok ? j + u : 0) * TT];
+                            y = ok ? y + prod : y;
+                        }
+                    }
+                } else {
+                    for (int j = 0; j < len; ++j) {
+                        const float prod = val_to_f32<VAL_T>(vb[j]) * xb[j * TT];
+                        y = y + prod;
+                    }
+                }
+            }
+        } else {
+            if constexpr (VEC) {
+                for (int e = 0; e < p.Ktot; e += 8) {
+                    Vec8<IDX_T> ii;
+                    Vec8<VAL_T> vv;
+                    ii.load(irow + e);
+                    vv.load(vrow + e);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = idx_to_i32<IDX_T>(ii.get(u));
+                        const bool ok = (unsigned) i < (unsigned) p.n_in;
+                        const float prod = val_to_f32<VAL_T>(vv.get(u)) * xs[(ok ? i : 0) * TT + t];
+                        y = ok ? y + prod : y;
+                    }
+                }
+            } else {
+                for (int e = 0; e < p.Ktot; ++e) {
+                    const int i = idx_to_i32<IDX_T>(irow[e]);
+                    if ((unsigned) i >= (unsigned) p.n_in) continue;
+                    const float prod = val_to_f32<VAL_T>(vrow[e]) * xs[i * TT + t];
+                    y = y + prod;
+                }
+            }
+        }
+        if (t_ok) store_output(p, o, tok, y, p.rs ? p.rs[o] : 1.0f);
+    }
+}
+
+template <typename IDX_T, typename VAL_T, bool BLOCK, bool VEC, int TT>
+static int launch_tt(const DeltaParams & p, int64_t T, hipStream_t s) {
+    const size_t lds = (size_t) p.n_in * TT * sizeof(float);
+    auto kern = delta_spmm_kernel<IDX_T, VAL_T, BLOCK, VEC, TT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SDH_HIP_CHECK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int64_t tiles = (T + TT - 1) / TT;
+    if (tiles > 0x7fffffff) { set_error("spmm: too many token tiles"); return SDH_ERR_UNSUPPORTED; }
+    const int rows_pass = 1024 / TT;
+    // ~4 workgroups per CU in flight over the whole launch; a chunk is a whole number of row passes
+    int64_t chunks = (4 * (int64_t) lib().num_cu + tiles - 1) / tiles;
+    const int64_t max_chunks = (p.n_out + rows_pass - 1) / rows_pass;
+    if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks < 1) chunks = 1;
+    if (chunks > 65535) chunks = 65535;
+    int rows_per_wg = (int) ((p.n_out + chunks - 1) / chunks);
+    rows_per_wg = (rows_per_wg + rows_pass - 1) / rows_pass * rows_pass;
+    const unsigned gy = (unsigned) ((p.n_out + rows_per_wg - 1) / rows_per_wg);
+    hipLaunchKernelGGL(kern, dim3((unsigned) tiles, gy), dim3(1024), lds, s, p, T, rows_per_wg);
+    SDH_HIP_CHECK(hipGetLastError());
+    return SDH_OK;
+}
+
+template <typename IDX_T, typename VAL_T, bool BLOCK, bool VEC>
+static int launch_vec(const DeltaParams & p, int64_t T, hipStream_t s) {
+    const size_t budget = 152 * 1024;                   // LDS for the tile, leaving headroom
+    const size_t col = (size_t) p.n_in * sizeof(float);
+    if (col * 16 <= budget / 2 && T >= 16) return launch_tt<IDX_T, VAL_T, BLOCK, VEC, 16>(p, T, s);   // two workgroups per CU
+    if (col * 8 <= budget) return launch_tt<IDX_T, VAL_T, BLOCK, VEC, 8>(p, T, s);
+    // narrower tiles re-stream the payload T/TT times: measured on MI355X (T=512, n_in=14336) the COO
+    // form still wins 4x over the per-token kernels, the block form loses (0.25 vs 0.15 ms at K=128,
+    // 2.6 vs 0.8 ms at K=1536), so block payloads with long inputs keep the per-token kernels
+    if (BLOCK) return 1;
+    if (col * 4 <= budget) return launch_tt<IDX_T, VAL_T, BLOCK, VEC, 4>(p, T, s);
+    if (col * 2 <= budget) return launch_tt<IDX_T, VAL_T, BLOCK, VEC, 2>(p, T, s);
+    return 1;                                           // does not fit: caller uses the per-token kernels
+}
+
+template <typename IDX_T, typename VAL_T, bool BLOCK>
+static int launch_typed(const DeltaParams & p, int64_t T, hipStream_t s) {
+    // 16-byte payload loads need 8-element runs that never straddle a row or a block
+    const bool vec = (p.Ktot % 8 == 0) && (!BLOCK || p.block % 8 == 0);
+    return vec ? launch_vec<IDX_T, VAL_T, BLOCK, true>(p, T, s) : launch_vec<IDX_T, VAL_T, BLOCK, false>(p, T, s);
+}
+
+// Returns SDH_OK if launched, 1 if the shape does not fit this path, <0 on error.
+int launch_delta_spmm(const DeviceWeight & w, const DeltaLaunch & a, hipStream_t s) {
+    if (a.T <= 0) return SDH_OK;
+    DeltaParams p = make_delta_params(w, a);
+    const bool is_block = (w.kind == SDH_OP_BLOCK || w.kind == SDH_OP_BASE_BLOCK);
+    const bool i16 = w.idx_type == SDH_TYPE_I16, f16 = w.val_type == SDH_TYPE_F16;
+    if (is_block) {
+        if (i16 && f16)  return launch_typed<uint16_t, uint16_t, true>(p, a.T, s);
+        if (i16 && !f16) return launch_typed<uint16_t, uint32_t, true>(p, a.T, s);
+        if (!i16 && f16) return launch_typed<uint32_t, uint16_t, true>(p, a.T, s);
+        return launch_typed<uint32_t, uint32_t, true>(p, a.T, s);
+    }
+    if (i16 && f16)  return launch_typed<uint16_t, uint16_t, false>(p, a.T, s);
+    if (i16 && !f16) return launch_typed<uint16_t, uint32_t, false>(p, a.T, s);
+    if (!i16 && f16) return launch_typed<uint32_t, uint16_t, false>(p, a.T, s);
+    return launch_typed<uint32_t, uint32_t, false>(p, a.T, s);
+}
+
+} // namespace sdh

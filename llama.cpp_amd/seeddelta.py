@@ -26,7 +26,7 @@ LIB_PATH = os.path.join(HERE, "csrc", "libseeddelta_hip.so")
 
 SDH_TYPE = {np.dtype(np.float32): 0, np.dtype(np.float16): 1, np.dtype(np.int16): 25, np.dtype(np.int32): 26}
 
-FWD_DEVICE_IO, FWD_HOST_IO, FWD_ZERO_NONFINITE, FWD_EXACT_ORDER, FWD_W0_MFMA, FWD_NO_FUSE = 0x0, 0x1, 0x2, 0x4, 0x8, 0x10
+FWD_DEVICE_IO, FWD_HOST_IO, FWD_ZERO_NONFINITE, FWD_EXACT_ORDER, FWD_W0_MFMA, FWD_NO_FUSE, FWD_NO_SPMM = 0x0, 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
 
 # every symbol include/seeddelta_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [

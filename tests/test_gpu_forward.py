@@ -270,3 +270,35 @@ def test_device_io_path_matches_host_io(hip):
     w.forward_device(xd.data_ptr(), 1024, 4, yd.data_ptr(), 512, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert np.array_equal(bits(yd.cpu().numpy()), bits(y_host))
+
+
+@pytest.mark.parametrize("scheme,K,block", [("coo", 64, 16), ("coo", 20, 16), ("block", 64, 16), ("block", 96, 32), ("block", 24, 12)])
+@pytest.mark.parametrize("base", [False, True])
+@pytest.mark.parametrize("dims", [(256, 1024), (1024, 256), (1152, 864), (2500, 300)])
+@pytest.mark.parametrize("T", [8, 9, 37, 130])
+def test_prefill_spmm_is_bit_exact(hip, scheme, K, block, base, dims, T):
+    """T >= 8 takes the token-tiled SpMM kernel: a lane per (row, token) walks the entries in the
+    reference's order with separately rounded multiply and add, so the fast path itself is
+    bit-identical to the CPU op; the per-token row kernels (SDH_FWD_NO_SPMM) stay within tolerance."""
+    n_in, n_out = dims
+    p = make_payload(n_in, n_out, scheme=scheme, K=K, block=block, base=base, d13_random=base, seed=K + n_in + T)
+    x = make_x(n_in, T, seed=T)
+    y_ref = O.forward(p, x, nth=8)
+    w = hip.SeedDeltaWeight(p)
+    y = w.forward_host(x)
+    assert np.array_equal(bits(y), bits(y_ref)), f"max abs diff {np.abs(y - y_ref).max()}"
+    check_fast(p, x, w.forward_host(x, hip.FWD_NO_SPMM), y_ref)
+
+
+def test_prefill_spmm_dtypes_and_bad_indices(hip):
+    for idx_dtype, val_dtype in ((np.int32, np.float32), (np.int16, np.float32), (np.int32, np.float16)):
+        for scheme in ("coo", "block"):
+            p = make_payload(512, 384, scheme=scheme, K=64, block=16, base=True, idx_dtype=idx_dtype, val_dtype=val_dtype,
+                             rs_dtype=np.float32, base_dtype=np.float32, perm_dtype=np.int32, seed=3)
+            if scheme == "coo":
+                p.d_idx = p.d_idx.copy(); p.d_idx[::7, 3] = -1; p.d_idx[::5, 9] = 600
+            else:
+                p.b_idx = p.b_idx.copy(); p.b_idx[::7, 1] = -1; p.b_idx[::5, 2] = 40
+            x = make_x(512, 19)
+            w = hip.SeedDeltaWeight(p)
+            assert np.array_equal(bits(w.forward_host(x)), bits(O.forward(p, x, nth=4))), (idx_dtype, val_dtype, scheme)
