@@ -246,6 +246,7 @@ def main():
     torch.cuda.synchronize()
 
     fwd_flags = seeddelta.FWD_NO_FUSE if (args.no_fuse or args.launch == "graph") else 0
+    fwd_flags |= int(os.environ.get("SDH_BENCH_FLAGS", "0"))        # dev: extra SDH_FWD_* bits (A/B runs)
     fused = (T == 1 and args.launch == "eager" and not args.no_fuse)
 
     def run_rotation(stream_ptr):

@@ -523,7 +523,12 @@ int sdh_forward(sdh_weight * h, const float * x, int64_t ldx, int64_t n_tokens,
         if (has_base) {
             int rc = ensure_ws(w, per_tok * (size_t) chunk);
             if (rc != SDH_OK) return rc;
-            rc = launch_base_apply(*w, xc, dldx, tc, w->ws, s);
+            rc = 1;
+            if ((flags & SDH_FWD_W0_MFMA) && !a.exact_order) {
+                rc = launch_w0_mfma(*w, xc, dldx, tc, w->ws, s);
+                if (rc == SDH_OK && !w->tall) a.v_blocks = 1;
+            }
+            if (rc == 1) rc = launch_base_apply(*w, xc, dldx, tc, w->ws, s);
             if (rc != SDH_OK) return rc;
             a.v = w->ws;
         }

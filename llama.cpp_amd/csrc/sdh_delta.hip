@@ -199,7 +199,7 @@ DeltaParams make_delta_params(const DeviceWeight & w, const DeltaLaunch & a) {
     const bool is_block = (w.kind == SDH_OP_BLOCK || w.kind == SDH_OP_BASE_BLOCK);
     p.nb = (int) w.nb; p.block = (int) w.block;
     p.Ktot = is_block ? (int) (w.nb * w.block) : (int) w.K;
-    p.L = (int) w.L; p.B = (int) w.B; p.tall = w.tall ? 1 : 0;
+    p.L = (int) w.L; p.B = a.v_blocks > 0 ? a.v_blocks : (int) w.B; p.tall = w.tall ? 1 : 0;
     p.G = 1;
     p.zero_nf = a.zero_nonfinite ? 1 : 0;
     p.x_vec_ok = (((uintptr_t) a.x % 16) == 0 && (a.ldx % 4) == 0) ? 1 : 0;

@@ -115,8 +115,13 @@ struct DeltaLaunch {
     int * nf_counter;       // device counter for this call
     bool zero_nonfinite;
     bool exact_order;
+    int  v_blocks = 0;      // 0: v is [T][B][L] (FWHT form); 1: v is [T][L], base blocks already summed (MFMA form, wide)
 };
 int launch_delta(const DeviceWeight & w, const DeltaLaunch & a, hipStream_t s);
+
+// Prefill: base term as W0 tiles regenerated in registers and contracted on MFMA (sdh_w0mfma.hip).
+// Returns SDH_OK if launched, 1 if the payload has no closed-form W0 (caller uses the FWHT form).
+int launch_w0_mfma(const DeviceWeight & w, const float * x, int64_t ldx, int64_t T, float * v_out, hipStream_t s);
 
 // Prefill: token-tiled SpMM (sdh_spmm.hip). Returns SDH_OK if launched, 1 if the shape does not fit.
 int launch_delta_spmm(const DeviceWeight & w, const DeltaLaunch & a, hipStream_t s);

@@ -302,3 +302,25 @@ def test_prefill_spmm_dtypes_and_bad_indices(hip):
             x = make_x(512, 19)
             w = hip.SeedDeltaWeight(p)
             assert np.array_equal(bits(w.forward_host(x)), bits(O.forward(p, x, nth=4))), (idx_dtype, val_dtype, scheme)
+
+
+@pytest.mark.parametrize("dims", [(256, 1024), (1024, 256), (1152, 864), (864, 1152)])
+@pytest.mark.parametrize("scheme", ["coo", "block"])
+@pytest.mark.parametrize("T", [5, 40, 130])
+def test_prefill_w0_mfma_path(hip, dims, scheme, T):
+    """SDH_FWD_W0_MFMA: the base as W0 fragments regenerated in registers (closed form, fp32) and
+    contracted in f16 on MFMA with fp32 accumulation. f16 operands: each product carries up to
+    2 * 2^-11 relative error, so |y - y_ref| <= 1.5e-3 * |rs| * sum_i |W0[o,i] x[i]| + the fast-path
+    tolerance of the residual."""
+    n_in, n_out = dims
+    p = make_payload(n_in, n_out, scheme=scheme, K=32, block=16, base=True, d13_random=True, seed=n_in + T)
+    x = make_x(n_in, T, seed=T + 1)
+    y_ref = O.forward(p, x, nth=8)
+    w = hip.SeedDeltaWeight(p)
+    y = w.forward_host(x, hip.FWD_W0_MFMA)
+    W0 = np.abs(O.w0_tile(p, 0, n_out, 0, n_in).astype(np.float64))
+    rs = np.abs(p.row_scale.astype(np.float64))[None, :] if p.row_scale is not None else 1.0
+    bound = 1.5e-3 * rs * (np.abs(x.astype(np.float64)) @ W0.T) + fast_tolerance(p, x, y_ref)
+    err = np.abs(y.astype(np.float64) - y_ref.astype(np.float64))
+    assert np.all(err <= bound), f"max err/bound = {np.max(err / bound):.3g}"
+    assert np.max(err / bound) > 1e-4      # the MFMA path really ran (it is not bit-exact)
