@@ -440,3 +440,69 @@ def layer_scan(model: ModelFn, layers: Sequence[int], params: ScanParams, tensor
 
 def dumps(doc: dict) -> str:
     return json.dumps(doc, indent=2) + "\n"
+
+
+# ---- report.json (sd_report.cpp:112-288) -------------------------------------------------------------------
+# Field order of one weights[] element as the builder writes it. Fields this pipeline does not
+# produce (tiles, K selector, autotune attempts) take the builder's defaults for a one-K run.
+_ENTRY_ORDER = (
+    ["layer", "kind", "n_in", "n_out", "K_budget", "K", "block", "n_blocks", "has_w", "has_x"] + list(COST_NAMES)
+    + [n + s for s in ("", "_w", "_x", "_x_w") for n in METRIC_NAMES]
+    + ["gating_enabled", "gating_metric", "gating_value", "gating_p05", "gating_min_mean", "gating_min_p05", "gating_pass",
+       "metric_used", "targets_used", "stack_cost_delta", "stack_cost_total", "ffn_score", "ffn_proxy_available",
+       "ffn_proxy_reason", "ffn_proxy_scope", "ffn_proxy_base_used", "ffn_proxy_eval_x", "ffn_proxy_eval_out",
+       "ffn_proxy_seed"] + list(PROXY_NAMES[:6])
+    + ["emit", "strip_dense", "decision", "reject_reason", "tile_rows", "tile_rows_align", "k_total_per_tensor", "k_levels",
+       "unique_k_count", "tiles_rounded_count", "tiles_rounded_pct", "tiles_dropped_count", "tiles_dropped_pct",
+       "k_per_tile", "kselector_mode", "kselector_rank", "kselector_tiles_sampled", "kselector_gap_vs_uniform",
+       "k_custom_used", "k_requested_stats", "k_selected_stats", "autotune_enabled", "autotune_selected_budget",
+       "autotune_attempts"])
+
+
+def complete_entry(e: dict) -> dict:
+    """Fill the fields of a report entry the builder derives after the trial for a plain one-K run
+    (single tile, K selector 'cycle', no autotune; sd_build.cpp:959-1021, :1060-1076)."""
+    out = dict(e)
+    k_stats = {"has": False, "min": 0, "max": 0, "mean": 0}
+    cost_delta = 0.0
+    if e.get("emit"):
+        cost_delta = max(0.0, e["gating_min_mean"] - e["gating_value"]) + max(0.0, e["gating_min_p05"] - e["gating_p05"])
+    defaults = {
+        "stack_cost_delta": cost_delta, "stack_cost_total": cost_delta, "ffn_proxy_reason": "", "ffn_proxy_scope": "",
+        "ffn_proxy_base_used": False, "ffn_proxy_eval_x": 0, "ffn_proxy_eval_out": 0, "ffn_proxy_seed": 0,
+        **{n: 0.0 for n in PROXY_NAMES[:6]}, "strip_dense": False,
+        "tile_rows": e["n_out"], "tile_rows_align": 1, "k_total_per_tensor": e["K"], "k_levels": [e["K"]],
+        "unique_k_count": 1, "tiles_rounded_count": 0, "tiles_rounded_pct": 0.0, "tiles_dropped_count": 0,
+        "tiles_dropped_pct": 0.0, "k_per_tile": [e["K"]], "kselector_mode": "", "kselector_rank": 1,
+        "kselector_tiles_sampled": 1, "kselector_gap_vs_uniform": 0.0, "k_custom_used": False,
+        "k_requested_stats": dict(k_stats), "k_selected_stats": dict(k_stats), "autotune_enabled": False,
+        "autotune_selected_budget": e["K_budget"] if e.get("emit") else 0, "autotune_attempts": [],
+    }
+    for k, v in defaults.items():
+        out.setdefault(k, v)
+    return {k: out[k] for k in _ENTRY_ORDER}
+
+
+def report_document(entries: Sequence[dict], params: ScanParams, input_name: str = "", output_name: str = "",
+                    policy_file: str = "", policy_hash: str = "") -> dict:
+    """The report.json document (sd_report.cpp:122-161 header + weights[]), numbers at 6 significant
+    digits as the builder's ostream prints them."""
+    doc = {"input": input_name, "output": output_name, "base": bool(params.base), "policy_file": policy_file,
+           "policy_hash": policy_hash}
+    if params.base:
+        doc.update(base_kind="xor_circulant", base_max_samples=params.base_max_samples, base_perm_trials=params.base_perm_trials)
+    resid = {"scheme": params.scheme}
+    if params.scheme == "block":
+        resid["block"] = params.block
+    resid.update(K=params.K, K_gate=params.K, K_up=params.K, K_down=params.K, idx_type="i16", val_type="f16",
+                 row_scale=bool(params.row_scale))
+    doc.update(resid=resid, eval_cols=params.eval_cols, eval_x=params.eval_x, stack_pass_gate_up=0, stack_pass_down=0)
+
+    def rnd(v):
+        if isinstance(v, dict):
+            return {k: rnd(x) for k, x in v.items()}
+        if isinstance(v, list):
+            return [rnd(x) for x in v]
+        return round_like_report(v)
+    doc["weights"] = [rnd(complete_entry(e)) for e in entries]
+    return doc

@@ -44,7 +44,13 @@ def main():
             ls.write_policy(path, layer, tensors, k, metric)
             policies.append({"layer": layer, "tensors": tensors, "k": k, "metric": metric,
                              "policy": json.loads(path.read_text())})
+    # field names of one report.json weights[] element, in the order sd_report.cpp:166-279 writes them
+    import re
+    src = open("/root/reference/tools/seeddelta-build/sd_report.cpp").read()
+    body = src[src.index("for (size_t i = 0; i < report.size(); ++i)"):]
+    fields = re.findall(r'out << "      \\"([A-Za-z0-9_]+)\\"', body)
     out = {
+        "report_entry_fields": fields,
         "parse_layers": [{"spec": s, "layers": ls.parse_layers(s)} for s in ("0-31", "0,2,4", "5-3, 9", "", "7")],
         "collect_metrics": [{"entry": e, "metrics": ls.collect_metrics(e)} for e in entries],
         "write_policy": policies,

@@ -192,3 +192,42 @@ def test_full_size_properties(hip):
         assert rest.max() <= a[row, -1]
     assert 0.0 < res["em"][0] < 1.0 and res["em"][2] > 0.5 and res["has_x"]
     print(f"\nfull-size candidate: {res['gpu_ms']:.2f} ms on device")
+
+
+@pytest.mark.parametrize("scheme,K,block", [("coo", 96, 32), ("block", 96, 16)])
+def test_scan_to_gguf_to_forward(hip, tmp_path, scheme, K, block):
+    """End to end across both halves of the path: evaluate a candidate, pack its staging with the
+    builder's rules, store it in a GGUF under the builder's names, load it back as a SeedDelta
+    context and run the FFN op: the op's outputs track the dense W.x with the cosine the scan
+    predicted (eval_x metrics), and equal the oracle's evaluation of the same payload."""
+    import oracle_py as O
+    from llama_cpp_amd import gguf_io as G, pack as P
+    from llama_cpp_amd.dense import dequantize_q8_0
+    from conftest import bits
+    n_in, n_out, layer, kind = 512, 1408, 4, "ffn_gate"
+    W = make_dense(n_in, n_out, "q8_0", seed=31, structure=0.4)
+    p = SC.ScanParams(scheme=scheme, K=K, block=block, base=True, row_scale=True, base_max_samples=256, base_perm_trials=2,
+                      eval_cols=64, eval_x=16)
+    s = SC.ScanSession(p.seed)
+    res = s.tensor(SC.DenseWeight(W), p, kind, layer)
+    payload = P.pack_candidate(s.fetch(), n_in, n_out, scheme)
+    tensors = P.payload_tensors(layer, kind, payload)
+    tensors[f"blk.{layer}.{kind}.weight"] = W
+    entry = SC.report_entry(layer, kind, n_in, n_out, p, res)
+    kv = {"general.architecture": "llama", **P.metadata(scheme, K, block, True, True, base_perm_trials=2, entries=[entry])}
+    path = str(tmp_path / "sd.gguf")
+    G.write_gguf(path, kv, tensors, q8_0=(f"blk.{layer}.{kind}.weight",))
+
+    reader, payloads, meta = G.load_seeddelta_context(path)
+    assert meta[f"seeddelta.blk.{layer}.{kind}.enabled"] is True and meta["seeddelta.scheme"] == (1 if scheme == "block" else 0)
+    ctx = hip.SeedDeltaContext(enabled=True)
+    key = f"blk.{layer}.{kind}.weight"
+    assert ctx.try_add(key, payloads[key])
+    x = np.random.default_rng(3).standard_normal((24, n_in)).astype(np.float32)
+    y = ctx.mul_mat(key, x)
+    assert np.array_equal(bits(y), bits(O.forward(payloads[key], x, nth=4)))        # T >= 8: exact-order SpMM path
+    y_dense = x.astype(np.float64) @ dequantize_q8_0(W).astype(np.float64).T
+    cos = np.sum(y * y_dense, axis=1) / (np.linalg.norm(y, axis=1) * np.linalg.norm(y_dense, axis=1))
+    assert abs(cos.mean() - res["em_x"][2]) < 0.03, (cos.mean(), res["em_x"][2])
+    assert cos.mean() > 0.7
+    reader.close()

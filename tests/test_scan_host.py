@@ -129,3 +129,23 @@ def test_gather_records_world_size_2_gloo(tmp_path):
                          capture_output=True, text=True, env=env, timeout=240)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "GATHER_OK 15" in out.stdout
+
+
+def test_report_document_has_the_builder_fields(script_golden):
+    """Field list and order of sd_report.cpp:163-281 (parity unpinned: sd_report.cpp includes the policy
+    header GCC 11 rejects, so the reference writer cannot be run here); the scan script consumes it."""
+    p = SC.ScanParams(K=12)
+    entries = [SC.report_entry(3, k, 256, 704, p, fake_result(proxy=(k != "ffn_down"))) for k in SC.KINDS]
+    doc = SC.report_document(entries, p, input_name="base.gguf")
+    assert list(doc)[:5] == ["input", "output", "base", "policy_file", "policy_hash"] and "base_kind" not in doc
+    w = doc["weights"][0]
+    keys = list(w)
+    assert keys == script_golden["report_entry_fields"]          # names and order as the reference source writes them
+    assert keys.index("rel_l2_mean") < keys.index("rel_l2_mean_w") < keys.index("rel_l2_mean_x") < keys.index("rel_l2_mean_x_w")
+    assert w["k_levels"] == [12] and w["targets_used"] == {"tau_mean": 0.0, "tau_p05": 0.0}
+    # the reference's layer-scan script logic consumes the document unchanged
+    for e in doc["weights"]:
+        m = SC.collect_metrics(e)
+        assert m["S_mean"] == 0.8 and m["ffn_proxy_available"] == (e["kind"] != "ffn_down")
+    assert json.loads(SC.dumps(doc))["resid"]["K_down"] == 12
+    assert SC.report_document(entries, SC.ScanParams(base=True))["base_kind"] == "xor_circulant"
