@@ -13,10 +13,10 @@ rc=$?; echo "smoke_exit=$rc"; tail -2 gpurun_out/smoke.log
 timeout -k 10 600 python -u bench.py > gpurun_out/bench_${TAG}.log 2>&1
 rc=$?; echo "bench_exit=$rc"; tail -1 gpurun_out/bench_${TAG}.log
 [ $rc -ne 0 ] && exit $rc
-timeout -k 10 600 python -u bench.py --no-fuse --no-cpu-baseline > gpurun_out/bench_${TAG}_nofuse.log 2>&1
+timeout -k 10 600 python -u bench.py --no-fuse --no-cpu-baseline --no-scan > gpurun_out/bench_${TAG}_nofuse.log 2>&1
 rc=$?; echo "bench_nofuse_exit=$rc"; tail -1 gpurun_out/bench_${TAG}_nofuse.log
 [ $rc -ne 0 ] && exit $rc
-timeout -k 10 600 python -u bench.py --launch graph --no-cpu-baseline > gpurun_out/bench_${TAG}_graph.log 2>&1
+timeout -k 10 600 python -u bench.py --launch graph --no-cpu-baseline --no-scan > gpurun_out/bench_${TAG}_graph.log 2>&1
 rc=$?; echo "bench_graph_exit=$rc"; tail -1 gpurun_out/bench_${TAG}_graph.log
 [ $rc -ne 0 ] && exit $rc
 cd /tmp && export TMPDIR=/tmp

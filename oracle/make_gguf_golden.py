@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Write tests/golden/seeddelta_toy.gguf with the REFERENCE's own gguf-py writer (imported from
-/root/reference/gguf-py in this container) plus tests/golden/seeddelta_toy_expect.npz holding the arrays
+"""Write tests/golden/gguf_toy.gguf with the REFERENCE's own gguf-py writer (imported from
+/root/reference/gguf-py in this container) plus tests/golden/gguf_toy_expect.npz holding the arrays
 that went in. The GGUF mimics what llama-seeddelta-build emits for one layer: Q8_0 dense FFN weights,
 SeedDelta tensors under the builder's names, the seeddelta.* metadata of sd_write.cpp:44-74.
 
@@ -26,7 +26,7 @@ N_EMBD, N_FF, LAYER = 64, 160, 2
 
 
 def main():
-    w = gguf.GGUFWriter(os.path.join(OUT, "seeddelta_toy.gguf"), "llama")
+    w = gguf.GGUFWriter(os.path.join(OUT, "gguf_toy.gguf"), "llama")
     expect = {}
     dense = {"ffn_gate": make_dense(N_EMBD, N_FF, "q8_0", seed=1), "ffn_up": make_dense(N_EMBD, N_FF, "q8_0", seed=2),
              "ffn_down": make_dense(N_FF, N_EMBD, "q8_0", seed=3)}
@@ -62,8 +62,8 @@ def main():
     w.write_kv_data_to_file()
     w.write_tensors_to_file()
     w.close()
-    np.savez_compressed(os.path.join(OUT, "seeddelta_toy_expect.npz"), **{k.replace(".", "__"): v for k, v in expect.items()})
-    print("wrote seeddelta_toy.gguf", os.path.getsize(os.path.join(OUT, "seeddelta_toy.gguf")), "bytes,", len(expect), "tensors")
+    np.savez_compressed(os.path.join(OUT, "gguf_toy_expect.npz"), **{k.replace(".", "__"): v for k, v in expect.items()})
+    print("wrote gguf_toy.gguf", os.path.getsize(os.path.join(OUT, "gguf_toy.gguf")), "bytes,", len(expect), "tensors")
 
 
 if __name__ == "__main__":

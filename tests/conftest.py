@@ -23,7 +23,7 @@ def pytest_configure(config):
 
 def golden_names():
     """forward-op fixtures (reference TU outputs)"""
-    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and not f.startswith("scan_"))
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and not f.startswith(("scan_", "gguf_")))
 
 
 def scan_golden_names():

@@ -1,8 +1,8 @@
 """Packing (builder rules, tools/seeddelta-build/sd_build.cpp:1104-1236), tensor naming / metadata
 (sd_write.cpp:44-74) and the GGUF reader / writer, on the CPU.
 
-Fixtures: tests/golden/seeddelta_toy.gguf was written by the reference's own gguf-py (see
-oracle/make_gguf_golden.py); seeddelta_toy_expect.npz holds the arrays that went in."""
+Fixtures: tests/golden/gguf_toy.gguf was written by the reference's own gguf-py (see
+oracle/make_gguf_golden.py); gguf_toy_expect.npz holds the arrays that went in."""
 import os
 
 import numpy as np
@@ -62,8 +62,8 @@ def test_metadata_keys():
 
 
 def test_reads_gguf_written_by_reference_gguf_py():
-    path = os.path.join(GOLDEN_DIR, "seeddelta_toy.gguf")
-    expect = {k.replace("__", "."): v for k, v in np.load(os.path.join(GOLDEN_DIR, "seeddelta_toy_expect.npz")).items()}
+    path = os.path.join(GOLDEN_DIR, "gguf_toy.gguf")
+    expect = {k.replace("__", "."): v for k, v in np.load(os.path.join(GOLDEN_DIR, "gguf_toy_expect.npz")).items()}
     with G.GGUFReader(path) as r:
         assert r.version == 3 and r.kv["general.architecture"] == "llama"
         assert r.kv["seeddelta.enabled"] is True and r.kv["seeddelta.resid.K"] == 8 and r.kv["seeddelta.blk.2.ffn_gate.K"] == 8
