@@ -14,6 +14,8 @@
 #include "sdh_internal.h"
 #include "sdh_delta_dev.h"
 
+#include <cstdlib>
+
 namespace sdh {
 
 template <typename IDX_T, typename VAL_T, bool BLOCK, bool VEC, int TT>
@@ -101,18 +103,115 @@ void delta_spmm_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
     }
 }
 
+// Four tokens per lane: one 16-byte LDS read feeds four multiply-adds, and the index / value unpacking
+// is paid once per entry instead of once per (entry, token). The one-token kernel above spends ~10
+// VALU instructions per multiply-add and is issue-bound (rocprof: 141.5 M VALU wave-instructions for
+// 14.7 M wave-level multiply-adds, profiles/r01_d_prefill_pmc.json); this form needs ~3. Same
+// accumulation order per (row, token), so still bit-identical to the CPU op. Vector payload shapes only.
+template <typename IDX_T, typename VAL_T, bool BLOCK, int TT>
+__global__ __launch_bounds__(1024)
+void delta_spmm4_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
+#pragma clang fp contract(off)
+    extern __shared__ float xs[];                       // [n_in][TT]
+    static_assert(TT % 4 == 0, "four tokens per lane");
+    constexpr int LPR = TT / 4;                         // lanes per row
+    const int tid = threadIdx.x;
+    const int64_t t0 = (int64_t) blockIdx.x * TT;
+    const int nt = (int) ((T - t0 < TT) ? (T - t0) : TT);
+    for (int t = 0; t < nt; ++t) {
+        const float * xt = p.x + (t0 + t) * p.ldx;
+        for (int i = tid; i < p.n_in; i += 1024) xs[i * TT + t] = xt[i];
+    }
+    if (nt < TT) {
+        for (int i = tid; i < p.n_in; i += 1024)
+            for (int t = nt; t < TT; ++t) xs[i * TT + t] = 0.0f;
+    }
+    __syncthreads();
+
+    const int tq = (tid % LPR) * 4;                     // first of this lane's four tokens within the tile
+    const float4 * xq = reinterpret_cast<const float4 *>(xs + tq);     // xq[i * LPR] = x[i][tq .. tq+3]
+    const int r1 = min(p.n_out, ((int) blockIdx.y + 1) * rows_per_wg);
+    for (int o = (int) blockIdx.y * rows_per_wg + tid / LPR; o < r1; o += 1024 / LPR) {
+        const VAL_T * vrow = reinterpret_cast<const VAL_T *>(p.val) + (size_t) o * p.Ktot;
+        const IDX_T * irow = reinterpret_cast<const IDX_T *>(p.idx) + (size_t) o * (BLOCK ? p.nb : p.Ktot);
+        float y[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (p.v) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t tok = t0 + ((tq + u < nt) ? tq + u : 0);
+                const float * vt = p.v + (size_t) tok * p.B * p.L;
+                if (p.tall) y[u] = vt[o];
+                else for (int b = 0; b < p.B; ++b) y[u] += vt[(size_t) b * p.L + o];
+            }
+        }
+        auto mac = [&](float v, const float4 x) {
+            float pr;
+            pr = v * x.x; y[0] = y[0] + pr;
+            pr = v * x.y; y[1] = y[1] + pr;
+            pr = v * x.z; y[2] = y[2] + pr;
+            pr = v * x.w; y[3] = y[3] + pr;
+        };
+        if constexpr (BLOCK) {
+            for (int bi = 0; bi < p.nb; ++bi) {
+                const int blk = idx_to_i32<IDX_T>(irow[bi]);
+                const int64_t in0 = (int64_t) blk * p.block;
+                if (blk < 0 || in0 >= p.n_in) continue;
+                const int len = (int) ((in0 + p.block < p.n_in) ? p.block : (p.n_in - in0));
+                const VAL_T * vb = vrow + (size_t) bi * p.block;
+                const float4 * xb = xq + (size_t) in0 * LPR;
+                for (int j = 0; j < p.block; j += 8) {
+                    Vec8<VAL_T> vv;
+                    vv.load(vb + j);
+                    if (j + 8 <= len) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) mac(val_to_f32<VAL_T>(vv.get(u)), xb[(j + u) * LPR]);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) if (j + u < len) mac(val_to_f32<VAL_T>(vv.get(u)), xb[(j + u) * LPR]);
+                    }
+                }
+            }
+        } else {
+            for (int e = 0; e < p.Ktot; e += 8) {
+                Vec8<IDX_T> ii;
+                Vec8<VAL_T> vv;
+                ii.load(irow + e);
+                vv.load(vrow + e);
+                int ix[8];
+                bool all_ok = true;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    ix[u] = idx_to_i32<IDX_T>(ii.get(u));
+                    all_ok = all_ok & ((unsigned) ix[u] < (unsigned) p.n_in);
+                }
+                if (all_ok) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) mac(val_to_f32<VAL_T>(vv.get(u)), xq[ix[u] * LPR]);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) if ((unsigned) ix[u] < (unsigned) p.n_in) mac(val_to_f32<VAL_T>(vv.get(u)), xq[ix[u] * LPR]);
+                }
+            }
+        }
+        const float scale = p.rs ? p.rs[o] : 1.0f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (tq + u < nt) store_output(p, o, t0 + tq + u, y[u], scale);
+    }
+}
+
 template <typename IDX_T, typename VAL_T, bool BLOCK, bool VEC, int TT>
 static int launch_tt(const DeltaParams & p, int64_t T, hipStream_t s) {
     const size_t lds = (size_t) p.n_in * TT * sizeof(float);
-    auto kern = delta_spmm_kernel<IDX_T, VAL_T, BLOCK, VEC, TT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SDH_HIP_CHECK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+    static const bool one_token = getenv("SDH_SPMM_ONE_TOKEN") != nullptr;      // dev: A/B against the four-token form
+    void (*kern)(const DeltaParams, int64_t, int) = delta_spmm_kernel<IDX_T, VAL_T, BLOCK, VEC, TT>;
+    int lanes_per_row = TT;
+    if constexpr (VEC && TT % 4 == 0) {
+        if (!one_token) { kern = delta_spmm4_kernel<IDX_T, VAL_T, BLOCK, TT>; lanes_per_row = TT / 4; }
     }
+    SDH_HIP_CHECK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const int64_t tiles = (T + TT - 1) / TT;
     if (tiles > 0x7fffffff) { set_error("spmm: too many token tiles"); return SDH_ERR_UNSUPPORTED; }
-    const int rows_pass = 1024 / TT;
+    const int rows_pass = 1024 / lanes_per_row;
     // ~4 workgroups per CU in flight over the whole launch; a chunk is a whole number of row passes
     int64_t chunks = (4 * (int64_t) lib().num_cu + tiles - 1) / tiles;
     const int64_t max_chunks = (p.n_out + rows_pass - 1) / rows_pass;
