@@ -186,6 +186,9 @@ typedef struct sdh_scan_params {
     int64_t eval_x;             /* (--eval-x)                                                           */
     int32_t proxy_seed;         /* seed + 101*layer + {1,2,3}             (sd_build.cpp:1032)            */
     int32_t reserved;
+    const float * w_scale;      /* host, n_in floats or NULL: the imatrix scale of sdh_imatrix_scale(); when
+                                   set the fit, the selection scores and the row scale are weighted and the
+                                   _w / _x_w metric passes run as well (sd_build.cpp:421-422, :753-794)      */
 } sdh_scan_params;
 
 /* What one report.json entry is computed from (tools/seeddelta-build/sd_report.cpp:112-288). Metric
@@ -204,7 +207,16 @@ typedef struct sdh_scan_result {
     double  cost[8];
     double  proxy[8];
     double  gpu_ms;             /* device time of this candidate (HIP events on the library stream)      */
+    int32_t has_w;              /* w_scale was given: em_w / em_x_w are valid                            */
+    int32_t reserved;
+    double  em_w[5];            /* weight-space metrics with the imatrix weighting                       */
+    double  em_x_w[5];          /* activation-space metrics with x drawn as N(0,1) * w_scale             */
 } sdh_scan_result;
+
+/* The builder's per-input weighting from an importance matrix row (sd_make_imatrix_sqrt_scale,
+ * tools/seeddelta-build/sd_utils.cpp:254-295): s_i = max(imatrix_i, eps)^(power/2), NaN/Inf -> 1,
+ * normalised to mean 1. Host arithmetic (powf), identical to the reference's on the same libm. */
+int  sdh_imatrix_scale(const float * imatrix, int64_t n_in, float eps, float power, float * scale_out);
 
 int  sdh_scan_create(uint32_t seed, sdh_scan ** out);
 void sdh_scan_destroy(sdh_scan * s);

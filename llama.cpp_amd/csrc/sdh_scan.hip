@@ -109,7 +109,7 @@ struct FitJob { int b; int rows_off; int n_rows; int perm_off; };
 
 __global__ __launch_bounds__(256)
 void scan_fit_kernel(DenseView W, int L, int tall, const FitJob * __restrict__ jobs, const int * __restrict__ rows,
-                     const int * __restrict__ perms, double * __restrict__ out /* [n_jobs][3][L] */) {
+                     const int * __restrict__ perms, const float * __restrict__ ws, double * __restrict__ out /* [n_jobs][3][L] */) {
     extern __shared__ int perm_s[];
     const FitJob job = jobs[blockIdx.y];
     for (int i = threadIdx.x; i < L; i += 256) perm_s[i] = perms[job.perm_off + i];
@@ -125,9 +125,17 @@ void scan_fit_kernel(DenseView W, int L, int tall, const FitJob * __restrict__ j
         const int64_t src = in0 + perm_s[j];
         if (src < in0 || src >= in1) continue;
         const double v = (double) dense_at(W, row, src);
-        s  += v;            // ww == 1: ww*v == v, ww*v*v == v*v exactly
-        s2 += v * v;
-        n  += 1.0;
+        if (ws) {
+            const double w1 = (double) ws[src];
+            const double ww = w1 * w1;
+            s  += ww * v;
+            s2 += ww * v * v;
+            n  += ww;
+        } else {            // ww == 1: ww*v == v, ww*v*v == v*v exactly
+            s  += v;
+            s2 += v * v;
+            n  += 1.0;
+        }
     }
     double * o = out + (size_t) blockIdx.y * 3 * L;
     o[u] = s; o[L + u] = s2; o[2 * L + u] = n;
@@ -152,6 +160,7 @@ __device__ __forceinline__ void bitonic_desc(int n, CMP swap_if_needed) {
 
 __global__ __launch_bounds__(256)
 void scan_select_coo_kernel(DenseView W, BaseView base, int has_base, int K, int Kpad, int want_rs,
+                            const float * __restrict__ ws,
                             int * __restrict__ idx_out, float * __restrict__ val_out, float * __restrict__ rs_out) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int n_in = (int) W.n_in;
@@ -169,13 +178,19 @@ void scan_select_coo_kernel(DenseView W, BaseView base, int has_base, int K, int
         if (has_base) {
             const float bw = base_weight(base, row, i);
             r[i] = w - bw;
-            dot += (double) w * (double) bw;
-            nn  += (double) bw * (double) bw;
+            const double s1 = ws ? (double) ws[i] : 1.0;
+            dot += (double) w * (double) bw * s1 * s1;
+            nn  += (double) bw * (double) bw * s1 * s1;
         } else {
             r[i] = w;
         }
     }
     __syncthreads();
+    // the score is |r| (times the imatrix scale, one fp32 product, sd_eval.cpp:53-56); keys are its bits
+    auto key_of = [&](int i) -> uint32_t {
+        const float sc = fabsf(r[i]);
+        return __float_as_uint(ws ? sc * ws[i] : sc);
+    };
 
     // radix select: the K-th largest key, 8 bits per pass from the top
     uint32_t prefix = 0;
@@ -185,7 +200,7 @@ void scan_select_coo_kernel(DenseView W, BaseView base, int has_base, int K, int
         hist[tid] = 0;
         __syncthreads();
         for (int i = tid; i < n_in; i += 256) {
-            const uint32_t key = score_key(r[i]);
+            const uint32_t key = key_of(i);
             if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
         }
         __syncthreads();
@@ -211,7 +226,7 @@ void scan_select_coo_kernel(DenseView W, BaseView base, int has_base, int K, int
     const int lo = min(n_in, tid * per), hi = min(n_in, lo + per);
     int cg = 0, ce = 0;
     for (int i = lo; i < hi; ++i) {
-        const uint32_t key = score_key(r[i]);
+        const uint32_t key = key_of(i);
         cg += key > T;
         ce += key == T;
     }
@@ -219,7 +234,7 @@ void scan_select_coo_kernel(DenseView W, BaseView base, int has_base, int K, int
     int og = block_excl_scan(cg, isc, &tot);
     int oe = block_excl_scan(ce, isc, &tot);
     for (int i = lo; i < hi; ++i) {
-        const uint32_t key = score_key(r[i]);
+        const uint32_t key = key_of(i);
         const uint64_t comp = ((uint64_t) key << 32) | (uint64_t) (0xffffffffu - (uint32_t) i);
         if (key > T) sbuf[og++] = comp;
         else if (key == T) { if (oe < need) sbuf[n_greater + oe] = comp; ++oe; }
@@ -239,8 +254,9 @@ void scan_select_coo_kernel(DenseView W, BaseView base, int has_base, int K, int
         val_out[row * K + rr] = r[i];
         if (want_rs) {
             const double wi = (double) dense_at(W, row, i), di = (double) r[i];
-            if (has_base) { dot2 += wi * di; nn2 += 2.0 * wi * di - di * di; }
-            else          { dot2 += wi * wi; nn2 += wi * wi; }
+            const double s1 = ws ? (double) ws[i] : 1.0;
+            if (has_base) { dot2 += wi * di * s1 * s1; nn2 += (2.0 * wi * di - di * di) * s1 * s1; }
+            else          { dot2 += wi * wi * s1 * s1; nn2 += wi * wi * s1 * s1; }
         }
     }
     if (want_rs) {
@@ -254,8 +270,8 @@ void scan_select_coo_kernel(DenseView W, BaseView base, int has_base, int K, int
 // LDS: r[n_in] f32 | energy[NBpad] f64 | bid[NBpad] i32 | misc
 __global__ __launch_bounds__(256)
 void scan_select_block_kernel(DenseView W, BaseView base, int has_base, int block, int keep, int n_blocks, int NBpad,
-                              int want_rs, int * __restrict__ idx_out, float * __restrict__ val_out,
-                              float * __restrict__ rs_out) {
+                              int want_rs, const float * __restrict__ ws,
+                              int * __restrict__ idx_out, float * __restrict__ val_out, float * __restrict__ rs_out) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int n_in = (int) W.n_in;
     float *  r   = (float *) smem;
@@ -271,8 +287,9 @@ void scan_select_block_kernel(DenseView W, BaseView base, int has_base, int bloc
         if (has_base) {
             const float bw = base_weight(base, row, i);
             r[i] = w - bw;
-            dot += (double) w * (double) bw;
-            nn  += (double) bw * (double) bw;
+            const double s1 = ws ? (double) ws[i] : 1.0;
+            dot += (double) w * (double) bw * s1 * s1;
+            nn  += (double) bw * (double) bw * s1 * s1;
         } else {
             r[i] = w;
         }
@@ -283,7 +300,10 @@ void scan_select_block_kernel(DenseView W, BaseView base, int has_base, int bloc
         if (b < n_blocks) {
             e = 0.0;
             const int i1 = min(n_in, (b + 1) * block);
-            for (int i = b * block; i < i1; ++i) { const double x = (double) r[i]; e += x * x; }   // sequential: exact
+            for (int i = b * block; i < i1; ++i) {                                                 // sequential: exact
+                const double x = (double) r[i] * (ws ? (double) ws[i] : 1.0);
+                e += x * x;
+            }
         }
         en[b] = e;
         bid[b] = b;
@@ -307,8 +327,9 @@ void scan_select_block_kernel(DenseView W, BaseView base, int has_base, int bloc
             v = r[i];
             if (want_rs) {
                 const double wi = (double) dense_at(W, row, i), di = (double) v;
-                if (has_base) { dot2 += wi * di; nn2 += 2.0 * wi * di - di * di; }
-                else          { dot2 += wi * wi; nn2 += wi * wi; }
+                const double s1 = ws ? (double) ws[i] : 1.0;
+                if (has_base) { dot2 += wi * di * s1 * s1; nn2 += (2.0 * wi * di - di * di) * s1 * s1; }
+                else          { dot2 += wi * wi * s1 * s1; nn2 += wi * wi * s1 * s1; }
             }
         }
         val_out[((size_t) row * keep + bi) * block + t] = v;
@@ -324,17 +345,18 @@ void scan_select_block_kernel(DenseView W, BaseView base, int has_base, int bloc
 __global__ __launch_bounds__(256)
 void scan_evalw_kernel(DenseView W, BaseView base, int has_base, int scheme, int K, int block,
                        const int * __restrict__ idx, const float * __restrict__ val, const float * __restrict__ rs,
-                       const int * __restrict__ rows, double * __restrict__ out /* [n_rows][3] */) {
+                       const float * __restrict__ ws, const int * __restrict__ rows, double * __restrict__ out /* [n_rows][3] */) {
     __shared__ double dsc[4];
     const int64_t row = rows[blockIdx.x];
     const int n_in = (int) W.n_in;
     const double scale = rs ? (double) rs[row] : 1.0;
     double wn = 0.0, hn = 0.0, dt = 0.0;
     for (int i = threadIdx.x; i < n_in; i += 256) {
-        const double wi = (double) dense_at(W, row, i);
+        const double s1 = ws ? (double) ws[i] : 1.0;
+        const double wi = (double) dense_at(W, row, i) * s1;
         wn += wi * wi;
         if (has_base) {
-            const double bs = (double) base_weight(base, row, i);
+            const double bs = (double) base_weight(base, row, i) * s1;
             hn += bs * bs;
             dt += wi * bs;
         }
@@ -356,15 +378,17 @@ void scan_evalw_kernel(DenseView W, BaseView base, int has_base, int scheme, int
             i = ii;
             dv = val[row * K + e];
         }
-        const double wi = (double) dense_at(W, row, i);
+        const double s1 = ws ? (double) ws[i] : 1.0;
         if (has_base) {
-            const double ds = (double) dv, bs = (double) base_weight(base, row, i);
+            const double wi = (double) dense_at(W, row, i) * s1;
+            const double ds = (double) dv * s1, bs = (double) base_weight(base, row, i) * s1;
             dt += wi * ds;
             hn += 2.0 * bs * ds + ds * ds;
         } else {
             const double wh = scale * (double) dv;
-            hn += wh * wh;
-            dt += wi * wh;
+            const double whs = wh * s1;
+            hn += whs * whs;
+            dt += (double) dense_at(W, row, i) * s1 * whs;
         }
     }
     wn = block_sum(wn, dsc); hn = block_sum(hn, dsc); dt = block_sum(dt, dsc);
@@ -471,7 +495,8 @@ struct Scan {
     DevBuf<float> h2, d2, d1; DevBuf<int> inv, perm1;
     std::vector<float> h_h2, h_d2, h_ones; std::vector<int> h_perm1, h_inv;
     // scratch
-    DevBuf<int> rows, perms, cols; DevBuf<FitJob> jobs; DevBuf<double> dbl, dbl2; DevBuf<float> xs, v, gat;
+    DevBuf<int> rows, perms, cols; DevBuf<FitJob> jobs; DevBuf<double> dbl, dbl2; DevBuf<float> xs, v, gat, wsd;
+    std::vector<float> h_ws;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     explicit Scan(uint32_t seed) : rng(seed) {}
 };
@@ -649,6 +674,25 @@ void sdh_dense_destroy(sdh_dense * W) {
 
 int64_t sdh_dense_bytes(const sdh_dense * W) { return W ? ((const DeviceDense *) W)->stored_bytes : -1; }
 
+int sdh_imatrix_scale(const float * imatrix, int64_t n_in, float eps, float power, float * scale_out) {
+    if (!imatrix || !scale_out || n_in <= 0) { set_error("sdh_imatrix_scale: bad argument"); return SDH_ERR_INVALID; }
+    eps = std::max(eps, 0.0f);
+    power = std::max(power, 0.0f);
+    double sum = 0.0;
+    for (int64_t i = 0; i < n_in; ++i) {
+        float sc = std::pow(std::max(imatrix[i], eps), 0.5f * power);
+        if (std::isnan(sc) || std::isinf(sc)) sc = 1.0f;
+        scale_out[i] = sc;
+        sum += (double) sc;
+    }
+    const double mean = sum / std::max<double>(1.0, (double) n_in);
+    if (mean > 0.0) {
+        const float inv_mean = (float) (1.0 / mean);
+        for (int64_t i = 0; i < n_in; ++i) scale_out[i] *= inv_mean;
+    }
+    return SDH_OK;
+}
+
 int sdh_scan_create(uint32_t seed, sdh_scan ** out) {
     if (!out) { set_error("sdh_scan_create: null argument"); return SDH_ERR_INVALID; }
     if (!lib().inited) { set_error("sdh_init() has not been called"); return SDH_ERR_NO_DEVICE; }
@@ -676,11 +720,12 @@ int sdh_scan_skip(sdh_scan * h, int64_t n_in, int64_t n_out, const sdh_scan_para
         fit_dims(n_in, n_out, &L, &B);
         (void) plan_fit(s.rng, n_in, n_out, L, B, p->base_max_samples, p->base_perm_trials);
     }
-    if (p->eval_cols > 0) (void) draw_rows(s.rng, n_out, p->eval_cols);
-    if (p->eval_cols > 0 && p->eval_x > 0) {
+    const int passes = p->w_scale ? 2 : 1;               // the _w / _x_w passes draw their own samples
+    for (int k = 0; k < passes && p->eval_cols > 0; ++k) (void) draw_rows(s.rng, n_out, p->eval_cols);
+    for (int k = 0; k < passes && p->eval_cols > 0 && p->eval_x > 0; ++k) {
         (void) draw_rows(s.rng, n_out, p->eval_cols);
         std::normal_distribution<float> nd(0.0f, 1.0f);
-        for (int64_t k = 0; k < p->eval_x * n_in; ++k) (void) nd(s.rng);
+        for (int64_t j = 0; j < p->eval_x * n_in; ++j) (void) nd(s.rng);
     }
     return SDH_OK;
 }
@@ -705,6 +750,12 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
     out->K_eff = K_eff; out->n_blocks = keep;
     int rc;
     SDH_HIP_CHECK(hipEventRecord(s.ev0, st));
+    const float * ws_dev = nullptr;
+    if (p.w_scale) {
+        s.h_ws.assign(p.w_scale, p.w_scale + n_in);
+        if ((rc = s.wsd.put(s.h_ws, st))) return rc;
+        ws_dev = s.wsd.p;
+    }
 
     // ---- base fit -------------------------------------------------------------------------------------
     int64_t L = 0, B = 0;
@@ -719,7 +770,7 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
         const int threads = 256;
         if (L < threads) { set_error("scan: base block length %lld < 256 not supported on the GPU path", (long long) L); return SDH_ERR_UNSUPPORTED; }
         hipLaunchKernelGGL(scan_fit_kernel, dim3((unsigned) (L / threads), (unsigned) n_jobs), dim3(threads),
-                           (size_t) L * sizeof(int), st, W, (int) L, tall ? 1 : 0, s.jobs.p, s.rows.p, s.perms.p, s.dbl.p);
+                           (size_t) L * sizeof(int), st, W, (int) L, tall ? 1 : 0, s.jobs.p, s.rows.p, s.perms.p, ws_dev, s.dbl.p);
         SDH_HIP_CHECK(hipGetLastError());
         std::vector<double> sums((size_t) n_jobs * 3 * L);
         SDH_HIP_CHECK(hipMemcpyAsync(sums.data(), s.dbl.p, sums.size() * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -781,7 +832,7 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
         }
         SDH_HIP_CHECK(hipFuncSetAttribute((const void *) scan_select_coo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         hipLaunchKernelGGL(scan_select_coo_kernel, dim3((unsigned) n_out), dim3(256), lds, st, W, bv, p.write_base ? 1 : 0,
-                           (int) K_eff, Kpad, p.write_row_scale ? 1 : 0, s.idx.p, s.val.p, s.rs.p);
+                           (int) K_eff, Kpad, p.write_row_scale ? 1 : 0, ws_dev, s.idx.p, s.val.p, s.rs.p);
     } else {
         const int64_t n_blocks = (n_in + p.block - 1) / p.block;
         int NBpad = 2;
@@ -793,7 +844,7 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
         }
         SDH_HIP_CHECK(hipFuncSetAttribute((const void *) scan_select_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         hipLaunchKernelGGL(scan_select_block_kernel, dim3((unsigned) n_out), dim3(256), lds, st, W, bv, p.write_base ? 1 : 0,
-                           (int) p.block, (int) keep, (int) n_blocks, NBpad, p.write_row_scale ? 1 : 0, s.idx.p, s.val.p, s.rs.p);
+                           (int) p.block, (int) keep, (int) n_blocks, NBpad, p.write_row_scale ? 1 : 0, ws_dev, s.idx.p, s.val.p, s.rs.p);
     }
     SDH_HIP_CHECK(hipGetLastError());
     const float * rs_dev = p.write_row_scale ? s.rs.p : nullptr;
@@ -813,37 +864,42 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
         c[7] = c[2] > 0.0 ? c[6] / c[2] : 0.0;
     }
 
-    // ---- weight-space metrics -----------------------------------------------------------------------
-    if (p.eval_cols > 0) {
+    // ---- metrics: em, [em_w], em_x, [em_x_w] — the order run_trial draws their samples in (:735-795) ----
+    auto eval_w = [&](const float * ws, double * o5) -> int {
         std::vector<int> rows = draw_rows(s.rng, n_out, p.eval_cols);
         const int nr = (int) rows.size();
-        if ((rc = s.rows.put(rows, st)) || (rc = s.dbl.ensure((size_t) nr * 3))) return rc;
+        int rc2;
+        if ((rc2 = s.rows.put(rows, st)) || (rc2 = s.dbl.ensure((size_t) nr * 3))) return rc2;
         hipLaunchKernelGGL(scan_evalw_kernel, dim3((unsigned) nr), dim3(256), 0, st, W, bv, p.write_base ? 1 : 0, p.scheme,
-                           (int) Ksel, (int) s.block, s.idx.p, s.val.p, rs_dev, s.rows.p, s.dbl.p);
+                           (int) Ksel, (int) s.block, s.idx.p, s.val.p, rs_dev, ws, s.rows.p, s.dbl.p);
         SDH_HIP_CHECK(hipGetLastError());
         std::vector<double> tr((size_t) nr * 3);
         SDH_HIP_CHECK(hipMemcpyAsync(tr.data(), s.dbl.p, tr.size() * sizeof(double), hipMemcpyDeviceToHost, st));
         SDH_HIP_CHECK(hipStreamSynchronize(st));
         std::vector<double> rel((size_t) nr), cs((size_t) nr), nrm((size_t) nr);
         for (int i = 0; i < nr; ++i) triple_metrics(tr[(size_t) i * 3], tr[(size_t) i * 3 + 1], tr[(size_t) i * 3 + 2], &rel[(size_t) i], &cs[(size_t) i], &nrm[(size_t) i]);
-        summarise(rel, cs, nrm, out->em);
-    }
-
-    // ---- activation-space metrics ---------------------------------------------------------------------
-    if (p.eval_cols > 0 && p.eval_x > 0) {
+        summarise(rel, cs, nrm, o5);
+        return SDH_OK;
+    };
+    auto eval_x = [&](const float * x_scale_host, double * o5) -> int {
         std::vector<int> rows = draw_rows(s.rng, n_out, p.eval_cols);
         const int nr = (int) rows.size();
         const int nx = (int) p.eval_x;
         std::vector<float> xs((size_t) nx * (size_t) n_in);
         std::normal_distribution<float> nd(0.0f, 1.0f);
-        for (float & x : xs) x = nd(s.rng);
-        if ((rc = s.rows.put(rows, st)) || (rc = s.xs.put(xs, st)) || (rc = s.dbl.ensure((size_t) nr * nx)) ||
-            (rc = s.dbl2.ensure((size_t) nr * nx))) return rc;
+        for (int xi = 0; xi < nx; ++xi)
+            for (int64_t i = 0; i < n_in; ++i) {
+                const float sc = x_scale_host ? x_scale_host[i] : 1.0f;
+                xs[(size_t) xi * (size_t) n_in + (size_t) i] = nd(s.rng) * sc;           // sd_eval.cpp:1084-1087
+            }
+        int rc2;
+        if ((rc2 = s.rows.put(rows, st)) || (rc2 = s.xs.put(xs, st)) || (rc2 = s.dbl.ensure((size_t) nr * nx)) ||
+            (rc2 = s.dbl2.ensure((size_t) nr * nx))) return rc2;
         const float * vdev = nullptr;
         if (p.write_base) {
-            if ((rc = s.v.ensure((size_t) nx * (size_t) B * (size_t) L))) return rc;
-            if ((rc = launch_base_apply_generic(s.xs.p, n_in, (int) n_in, (int) L, (int) B, tall, s.d1.p, s.d2.p, nullptr,
-                                                s.perm1.p, nullptr, nx, s.v.p, st))) return rc;
+            if ((rc2 = s.v.ensure((size_t) nx * (size_t) B * (size_t) L))) return rc2;
+            if ((rc2 = launch_base_apply_generic(s.xs.p, n_in, (int) n_in, (int) L, (int) B, tall, s.d1.p, s.d2.p, nullptr,
+                                                 s.perm1.p, nullptr, nx, s.v.p, st))) return rc2;
             vdev = s.v.p;
         }
         hipLaunchKernelGGL(scan_dense_dot_kernel, dim3((unsigned) nr, (unsigned) nx), dim3(256), 0, st, W, s.rows.p, nr, s.xs.p, s.dbl.p);
@@ -864,8 +920,18 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
             }
             triple_metrics(n1, n2, dot, &rel[(size_t) xi], &cs[(size_t) xi], &nrm[(size_t) xi]);
         }
-        summarise(rel, cs, nrm, out->em_x);
+        summarise(rel, cs, nrm, o5);
+        return SDH_OK;
+    };
+    out->has_w = ws_dev ? 1 : 0;
+    if (p.eval_cols > 0) {
+        if ((rc = eval_w(nullptr, out->em))) return rc;
+        if (ws_dev && (rc = eval_w(ws_dev, out->em_w))) return rc;
+    }
+    if (p.eval_cols > 0 && p.eval_x > 0) {
+        if ((rc = eval_x(nullptr, out->em_x))) return rc;
         out->has_x = 1;
+        if (ws_dev && (rc = eval_x(p.w_scale, out->em_x_w))) return rc;
     }
 
     // ---- FFN proxy (sd_ffn_proxy.cpp:20-247): COO, no base, gate/up only ------------------------------

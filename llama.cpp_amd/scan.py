@@ -83,6 +83,7 @@ class ScanParams:
     eval_x: int = 32               # --eval-x
     seed: int = 1234               # --seed
     metric: str = "cos"            # policy gating metric
+    w_scale: Optional[np.ndarray] = None   # imatrix scale for this tensor (imatrix_scale()); None = no imatrix
 
     def c_struct(self, kind: str, layer: int) -> sd.SdhScanParams:
         p = sd.SdhScanParams()
@@ -94,6 +95,9 @@ class ScanParams:
         p.want_proxy = 1
         p.eval_cols, p.eval_x = self.eval_cols, self.eval_x
         p.proxy_seed = self.seed + layer * 101 + KIND_ID[kind] + 1        # sd_build.cpp:1032
+        if self.w_scale is not None:
+            self._ws = np.ascontiguousarray(self.w_scale, dtype=np.float32)   # kept alive for the call
+            p.w_scale = self._ws.ctypes.data
         return p
 
 
@@ -128,8 +132,9 @@ class ScanSession:
         sd._check(lib.sdh_scan_tensor(self._h, W._h, g, u, d, C.byref(p), C.byref(r)), "sdh_scan_tensor")
         self._last = (W.n_in, W.n_out, params, int(r.K_eff), int(r.n_blocks), int(r.L), int(r.B))
         return {"K_eff": int(r.K_eff), "n_blocks": int(r.n_blocks), "L": int(r.L), "B": int(r.B),
-                "has_x": bool(r.has_x), "proxy_available": bool(r.proxy_available),
-                "em": np.array(r.em[:]), "em_x": np.array(r.em_x[:]), "cost": np.array(r.cost[:]),
+                "has_x": bool(r.has_x), "has_w": bool(r.has_w), "proxy_available": bool(r.proxy_available),
+                "em": np.array(r.em[:]), "em_x": np.array(r.em_x[:]), "em_w": np.array(r.em_w[:]),
+                "em_x_w": np.array(r.em_x_w[:]), "cost": np.array(r.cost[:]),
                 "proxy": np.array(r.proxy[:]), "gpu_ms": float(r.gpu_ms)}
 
     def skip(self, n_in: int, n_out: int, params: ScanParams, kind: str = "ffn_gate", layer: int = 0):
@@ -158,26 +163,28 @@ class ScanSession:
 
 # ---- report entry (sd_report.cpp:163-281; gating of sd_build.cpp:810-913 for a one-K schedule) -----------
 def ffn_score(entry: dict) -> float:
-    """sd_report.cpp:76-88 with has_w = False: prefer the x metrics, else the plain ones."""
-    if entry["has_x"] and (entry["cos_mean_x"] != 0.0 or entry["cos_p05_x"] != 0.0):
-        return min(entry["cos_mean_x"], entry["cos_p05_x"])
+    """sd_report.cpp:72-88: min(cos_mean, cos_p05) of the first available of x_w, x, w, plain."""
+    for need_x, need_w, sfx in ((True, True, "_x_w"), (True, False, "_x"), (False, True, "_w")):
+        if (not need_x or entry["has_x"]) and (not need_w or entry["has_w"]) and \
+                (entry["cos_mean" + sfx] != 0.0 or entry["cos_p05" + sfx] != 0.0):
+            return min(entry["cos_mean" + sfx], entry["cos_p05" + sfx])
     return min(entry["cos_mean"], entry["cos_p05"])
 
 
 def report_entry(layer: int, kind: str, n_in: int, n_out: int, params: ScanParams, res: dict,
                  min_mean: float = 0.0, min_p05: float = 0.0, gating_enabled: bool = True) -> dict:
     e = {"layer": layer, "kind": kind, "n_in": n_in, "n_out": n_out, "K_budget": params.K, "K": res["K_eff"],
-         "block": params.block, "n_blocks": res["n_blocks"], "has_w": False, "has_x": res["has_x"]}
+         "block": params.block, "n_blocks": res["n_blocks"], "has_w": bool(res.get("has_w", False)), "has_x": res["has_x"]}
     e.update({n: (int(v) if i < 2 else float(v)) for i, (n, v) in enumerate(zip(COST_NAMES, res["cost"]))})
     e.update({n: float(v) for n, v in zip(METRIC_NAMES, res["em"])})
-    for suffix, vec in (("_w", np.zeros(5)), ("_x", res["em_x"]), ("_x_w", np.zeros(5))):
+    for suffix, vec in (("_w", res.get("em_w", np.zeros(5))), ("_x", res["em_x"]), ("_x_w", res.get("em_x_w", np.zeros(5)))):
         e.update({n + suffix: float(v) for n, v in zip(METRIC_NAMES, vec)})
     e["ffn_score"] = ffn_score(e)
     # gate/up prefer the FFN score when x metrics exist (sd_build.cpp:810-816)
     metric = "ffn_score" if (kind in ("ffn_gate", "ffn_up") and res["has_x"]) else params.metric
     needs_x = metric in ("cos_x", "cos_x_w", "ffn_score")
     needs_w = metric in ("cos_w", "cos_x_w")
-    available = not (gating_enabled and ((needs_x and not res["has_x"]) or needs_w))
+    available = not (gating_enabled and ((needs_x and not res["has_x"]) or (needs_w and not e["has_w"])))
     pick = {"cos": ("cos_mean", "cos_p05"), "cos_x": ("cos_mean_x", "cos_p05_x"), "cos_w": ("cos_mean_w", "cos_p05_w"),
             "cos_x_w": ("cos_mean_x_w", "cos_p05_x_w")}
     val, p05 = (e["ffn_score"], e["ffn_score"]) if metric == "ffn_score" else (e[pick[metric][0]], e[pick[metric][1]])
@@ -201,6 +208,40 @@ def report_entry(layer: int, kind: str, n_in: int, n_out: int, params: ScanParam
         e["ffn_proxy_reason"] = (("proxy_kind_not_supported" if kind == "ffn_down" else "proxy_unavailable") if coo_nobase
                                  else "proxy_requires_eval_x" if params.eval_x <= 0 else "proxy_requires_coo")
     return e
+
+
+def imatrix_scale(imatrix_row: np.ndarray, n_in: int, eps: float = 1e-8, power: float = 1.0) -> Optional[np.ndarray]:
+    """Per-input weighting from one importance-matrix entry (sd_make_imatrix_sqrt_scale,
+    tools/seeddelta-build/sd_utils.cpp:254-295): max(v, eps)^(power/2) normalised to mean 1; None if the
+    entry is shorter than n_in. Computed by the library with the same libm call the reference makes."""
+    row = np.ascontiguousarray(imatrix_row, dtype=np.float32)
+    if row.size < n_in:
+        return None
+    out = np.empty(n_in, dtype=np.float32)
+    sd._check(sd.load_library().sdh_imatrix_scale(row.ctypes.data, n_in, eps, power, out.ctypes.data), "sdh_imatrix_scale")
+    return out
+
+
+def load_imatrix(path: str) -> Dict[str, np.ndarray]:
+    """An imatrix GGUF -> {weight name: mean squared activation per input} (sd_utils.cpp:154-228: tensors
+    <name>.in_sum2 divided by <name>.counts per row; rows with count 0 become 1)."""
+    from .gguf_io import GGUFReader
+    out = {}
+    with GGUFReader(path) as r:
+        for name in r.names():
+            if not name.endswith(".in_sum2"):
+                continue
+            base = name[:-len(".in_sum2")]
+            if base + ".counts" not in r.infos:
+                raise ValueError(f"mismatched sums and counts for {base}")
+            sums = np.array(r.tensor(name), dtype=np.float32)
+            sums = sums.reshape(-1, sums.shape[-1])
+            counts = np.array(r.tensor(base + ".counts"), dtype=np.float32).reshape(-1)
+            vals = np.ones_like(sums)
+            ok = counts > 0
+            vals[ok] = sums[ok] / counts[ok, None]
+            out[base] = vals.reshape(-1)
+    return out
 
 
 def round_like_report(v):

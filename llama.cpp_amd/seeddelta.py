@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "sdh_forward", "sdh_nonfinite_count", "sdh_w0_tile",
     "sdh_profile_enable", "sdh_profile_read", "sdh_profile_span_begin", "sdh_profile_span_end",
     "sdh_dense_create", "sdh_dense_destroy", "sdh_dense_bytes",
-    "sdh_scan_create", "sdh_scan_destroy", "sdh_scan_tensor", "sdh_scan_skip", "sdh_scan_fetch",
+    "sdh_scan_create", "sdh_scan_destroy", "sdh_scan_tensor", "sdh_scan_skip", "sdh_scan_fetch", "sdh_imatrix_scale",
 ]
 
 
@@ -54,14 +54,15 @@ class SdhScanParams(C.Structure):
     _fields_ = [("scheme", C.c_int32), ("kind", C.c_int32), ("K", C.c_int64), ("block", C.c_int64),
                 ("write_base", C.c_int32), ("write_row_scale", C.c_int32), ("base_max_samples", C.c_int64),
                 ("base_perm_trials", C.c_int32), ("want_proxy", C.c_int32), ("eval_cols", C.c_int64),
-                ("eval_x", C.c_int64), ("proxy_seed", C.c_int32), ("reserved", C.c_int32)]
+                ("eval_x", C.c_int64), ("proxy_seed", C.c_int32), ("reserved", C.c_int32), ("w_scale", C.c_void_p)]
 
 
 class SdhScanResult(C.Structure):
     _fields_ = [("K_eff", C.c_int64), ("n_blocks", C.c_int64), ("L", C.c_int64), ("B", C.c_int64),
                 ("has_x", C.c_int32), ("proxy_available", C.c_int32), ("em", C.c_double * 5),
                 ("em_x", C.c_double * 5), ("cost", C.c_double * 8), ("proxy", C.c_double * 8),
-                ("gpu_ms", C.c_double)]
+                ("gpu_ms", C.c_double), ("has_w", C.c_int32), ("reserved", C.c_int32),
+                ("em_w", C.c_double * 5), ("em_x_w", C.c_double * 5)]
 
 
 class SeedDeltaError(RuntimeError):
@@ -137,6 +138,7 @@ def load_library(path: str = LIB_PATH):
                                     C.POINTER(SdhScanParams), C.POINTER(SdhScanResult)]
     lib.sdh_scan_skip.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(SdhScanParams)]
     lib.sdh_scan_fetch.argtypes = [C.c_void_p] + [C.c_void_p] * 7
+    lib.sdh_imatrix_scale.argtypes = [C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p]
     _lib = lib
     return lib
 

@@ -14,6 +14,7 @@
 #include "sd_cost.h"
 #include "sd_eval.h"
 #include "sd_ffn_proxy.h"
+#include "sd_utils.h"
 
 #include <algorithm>
 #include <cstring>
@@ -212,6 +213,16 @@ int sdbref_ffn_proxy(int kind /*0 gate,1 up,2 down*/, const sdo_tensor * Wg, con
     out8[0] = m.cos_mean; out8[1] = m.cos_p05; out8[2] = m.l2_mean; out8[3] = m.l2_p95;
     out8[4] = m.log_norm_ratio_mean; out8[5] = m.log_norm_ratio_p95; out8[6] = (double) m.eval_x; out8[7] = (double) m.eval_out;
     return ok ? 1 : 0;
+}
+
+// sd_make_imatrix_sqrt_scale (sd_utils.cpp:254-295) on one importance-matrix row
+int sdbref_imatrix_scale(const float * imatrix, int64_t n, int64_t n_in, float eps, float power, float * out) {
+    std::unordered_map<std::string, std::vector<float>> data;
+    data["w"] = std::vector<float>(imatrix, imatrix + n);
+    std::vector<float> sc;
+    if (!sd_make_imatrix_sqrt_scale(data, "w", n_in, eps, power, sc)) return 0;
+    std::memcpy(out, sc.data(), sc.size() * sizeof(float));
+    return 1;
 }
 
 // out8 = L, B, ops_dense, ops_base, ops_delta, ops_row_scale, ops_total, ops_ratio

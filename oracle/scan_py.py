@@ -226,6 +226,16 @@ class Engine:
         return out
 
 
+def ref_imatrix_scale(imatrix: np.ndarray, n_in: int, eps: float, power: float):
+    """The reference's sd_make_imatrix_sqrt_scale (needs libsdbuildref.so)."""
+    lib = _reflib()
+    row = np.ascontiguousarray(imatrix, dtype=np.float32)
+    out = np.empty(n_in, dtype=np.float32)
+    lib.sdbref_imatrix_scale.restype = C.c_int
+    ok = lib.sdbref_imatrix_scale(_p(row), C.c_int64(row.size), C.c_int64(n_in), C.c_float(eps), C.c_float(power), _p(out))
+    return out if ok else None
+
+
 # ---- oracle-only entry points (no compiled-reference counterpart) --------------------------------------
 def select_rows(W, fit: Optional[Fit], scheme: int, K_or_keep: int, block: int, row_scale: bool, w_scale=None,
                 nth: int = 8):

@@ -231,3 +231,46 @@ def test_scan_to_gguf_to_forward(hip, tmp_path, scheme, K, block):
     assert abs(cos.mean() - res["em_x"][2]) < 0.03, (cos.mean(), res["em_x"][2])
     assert cos.mean() > 0.7
     reader.close()
+
+
+@pytest.mark.parametrize("scheme,K,block", [("coo", 48, 32), ("block", 64, 16)])
+@pytest.mark.parametrize("dims", [(512, 1408), (1408, 512)])
+def test_imatrix_weighted_candidate(hip, scheme, K, block, dims):
+    """With an imatrix scale the fit, the scores and the row scale are weighted and the _w / _x_w
+    passes run (sd_build.cpp:421-422, :753-794); same bars as the unweighted candidate."""
+    n_in, n_out = dims
+    W = make_dense(n_in, n_out, "q8_0", seed=7, structure=0.4)
+    imat = (np.random.default_rng(1).random(n_in).astype(np.float32) + 0.05) ** 2
+    ws = SC.imatrix_scale(imat, n_in, eps=1e-8, power=1.0)
+    if S.buildref_available():
+        assert np.array_equal(ws.view(np.uint32), S.ref_imatrix_scale(imat, n_in, 1e-8, 1.0).view(np.uint32))
+    assert abs(ws.mean() - 1.0) < 1e-5
+    sch = 1 if scheme == "block" else 0
+    p = SC.ScanParams(scheme=scheme, K=K, block=block, base=True, row_scale=True, base_max_samples=128, base_perm_trials=3,
+                      eval_cols=32, eval_x=5, seed=11, w_scale=ws)
+    s = SC.ScanSession(11)
+    res = s.tensor(SC.DenseWeight(W), p)
+    out = s.fetch()
+    o = S.Engine("oracle", 11)
+    fit = o.fit_base(W, 128, 3, ws)
+    assert np.array_equal(out["h2"].view(np.uint32), fit.h2.view(np.uint32)) and np.array_equal(out["perm1"], fit.perm1)
+    Ksel = res["n_blocks"] if sch else res["K_eff"]
+    idx, val, rs = S.select_rows(W, fit, sch, Ksel, block, True, w_scale=ws)
+    assert np.array_equal(out["idx"], idx) and np.array_equal(out["val"].view(np.uint32), val.view(np.uint32))
+    assert ulp_close(out["row_scale"], rs)
+    args = (W, fit, sch, out["idx"], out["val"], Ksel, block, out["row_scale"])
+    em = o.eval_w(*args, 32)
+    em_w = o.eval_w(*args, 32, ws)
+    em_x = o.eval_x(*args, 32, 5)
+    em_x_w = o.eval_x(*args, 32, 5, ws)
+    assert res["has_w"] and res["has_x"]
+    for k, want in (("em", em), ("em_w", em_w), ("em_x", em_x), ("em_x_w", em_x_w)):
+        assert np.allclose(res[k], want, rtol=1e-9, atol=1e-14), k
+    # skip() with the same params leaves the stream where the evaluation did
+    t = SC.ScanSession(11)
+    t.skip(n_in, n_out, p)
+    r2 = t.tensor(SC.DenseWeight(W), SC.ScanParams(K=4, eval_cols=8, eval_x=0, seed=11))
+    r3 = s.tensor(SC.DenseWeight(W), SC.ScanParams(K=4, eval_cols=8, eval_x=0, seed=11))
+    assert np.array_equal(r2["em"], r3["em"])
+    e = SC.report_entry(0, "ffn_gate", n_in, n_out, p, res)
+    assert e["has_w"] and e["cos_mean_x_w"] == res["em_x_w"][2] and e["ffn_score"] == min(res["em_x_w"][2], res["em_x_w"][3])

@@ -104,3 +104,16 @@ def test_gguf_round_trip(tmp_path):
         assert {t.name for t in rr.tensors} == set(tensors)
         t = next(t for t in rr.tensors if t.name == "blk.7.ffn_up.b_val")
         assert t.shape.tolist() == [16, 2, 40] and np.array_equal(np.asarray(t.data).reshape(40, 2, 16), p.b_val)
+
+
+def test_load_imatrix_gguf(tmp_path):
+    """<name>.in_sum2 / <name>.counts pairs -> mean squared activation per input (sd_utils.cpp:176-226)."""
+    from llama_cpp_amd.scan import load_imatrix
+    sums = np.arange(12, dtype=np.float32).reshape(1, 12) + 1
+    path = str(tmp_path / "imatrix.gguf")
+    G.write_gguf(path, {"general.type": "imatrix", "imatrix.chunk_count": 4, "imatrix.chunk_size": 512, "imatrix.datasets": ["wiki"]},
+                 {"blk.0.ffn_gate.weight.in_sum2": sums, "blk.0.ffn_gate.weight.counts": np.array([4.0], np.float32),
+                  "blk.0.ffn_up.weight.in_sum2": sums, "blk.0.ffn_up.weight.counts": np.array([0.0], np.float32)})
+    im = load_imatrix(path)
+    assert np.array_equal(im["blk.0.ffn_gate.weight"], (sums / 4.0).reshape(-1))
+    assert np.all(im["blk.0.ffn_up.weight"] == 1.0)
