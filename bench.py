@@ -54,7 +54,7 @@ def parse_args():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-scan", action="store_true", help="skip the scan (candidates/s) leg")
     ap.add_argument("--scan-layers", type=int, default=8, help="synthetic Mistral-7B layers in the scan job")
-    ap.add_argument("--scan-threads", type=int, default=8, help="host threads preparing candidates per rank")
+    ap.add_argument("--scan-threads", type=int, default=16, help="host threads preparing candidates per rank")
     ap.add_argument("--host-io", action="store_true",
                     help="also time the PCIe-inclusive boundary (host x in, host y out, one sync per call: what "
                          "the shim pays per graph node); reported as a separate field, never as value")

@@ -185,7 +185,12 @@ typedef struct sdh_scan_params {
     int64_t eval_cols;          /* (--eval-cols)                                                        */
     int64_t eval_x;             /* (--eval-x)                                                           */
     int32_t proxy_seed;         /* seed + 101*layer + {1,2,3}             (sd_build.cpp:1032)            */
-    int32_t reserved;
+    int32_t base_mode;          /* with write_base: 0 = draw and fit (a builder run reaching this tensor);
+                                   1 = keep the fit of the previous call, draw nothing (the next K of an
+                                       autotune schedule: the builder fits once per tensor, sd_build.cpp:444-451,
+                                       then runs trials, :843-913);
+                                   2 = replay the fit's draws but keep the previous fit (another builder run
+                                       with the same seed on the same tensor: the fit would come out identical) */
     const float * w_scale;      /* host, n_in floats or NULL: the imatrix scale of sdh_imatrix_scale(); when
                                    set the fit, the selection scores and the row scale are weighted and the
                                    _w / _x_w metric passes run as well (sd_build.cpp:421-422, :753-794)      */
@@ -220,6 +225,8 @@ int  sdh_imatrix_scale(const float * imatrix, int64_t n_in, float eps, float pow
 
 int  sdh_scan_create(uint32_t seed, sdh_scan ** out);
 void sdh_scan_destroy(sdh_scan * s);
+/* Start a new builder run on the same handle: re-seed the RNG, keep the device buffers and the last fit. */
+int  sdh_scan_reseed(sdh_scan * s, uint32_t seed);
 /* Evaluate one candidate on W. Wg/Wu/Wd (the layer's three dense weights) are only read by the FFN
  * proxy and may be NULL. Draws from the scan's RNG exactly as the builder does (base fit, then the
  * eval row sample, then the eval-x row sample and Gaussian activations). Blocks until done. */

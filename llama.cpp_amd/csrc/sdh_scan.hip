@@ -491,6 +491,7 @@ struct Scan {
     // last candidate
     int64_t n_in = 0, n_out = 0, K = 0, block = 0, L = 0, B = 0;
     int scheme = 0; bool has_base = false, has_rs = false;
+    const void * fit_of = nullptr;      // the dense handle the current fit belongs to
     DevBuf<int> idx; DevBuf<float> val; DevBuf<float> rs;
     DevBuf<float> h2, d2, d1; DevBuf<int> inv, perm1;
     std::vector<float> h_h2, h_d2, h_ones; std::vector<int> h_perm1, h_inv;
@@ -704,6 +705,12 @@ int sdh_scan_create(uint32_t seed, sdh_scan ** out) {
     return SDH_OK;
 }
 
+int sdh_scan_reseed(sdh_scan * h, uint32_t seed) {
+    if (!h) { set_error("sdh_scan_reseed: null handle"); return SDH_ERR_INVALID; }
+    ((Scan *) h)->rng.seed(seed);
+    return SDH_OK;
+}
+
 void sdh_scan_destroy(sdh_scan * h) {
     if (!h) return;
     Scan * s = (Scan *) h;
@@ -760,7 +767,15 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
     // ---- base fit -------------------------------------------------------------------------------------
     int64_t L = 0, B = 0;
     BaseView bv{};
-    if (p.write_base) {
+    if (p.write_base && p.base_mode != 0) {
+        fit_dims(n_in, n_out, &L, &B);
+        if (!s.has_base || s.fit_of != (const void *) Wh || s.L != L || s.B != B) {
+            set_error("scan: base_mode %d needs a previous fit of the same tensor on this handle", p.base_mode);
+            return SDH_ERR_INVALID;
+        }
+        if (p.base_mode == 2) (void) plan_fit(s.rng, n_in, n_out, L, B, p.base_max_samples, p.base_perm_trials);
+        bv.h2 = s.h2.p; bv.inv = s.inv.p; bv.L = (int) L; bv.B = (int) B; bv.tall = tall ? 1 : 0;
+    } else if (p.write_base) {
         fit_dims(n_in, n_out, &L, &B);
         if (L > 16384) { set_error("scan: base block length %lld too large", (long long) L); return SDH_ERR_UNSUPPORTED; }
         FitPlan pl = plan_fit(s.rng, n_in, n_out, L, B, p.base_max_samples, p.base_perm_trials);
@@ -813,10 +828,12 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
         s.h_ones.assign((size_t) (L * B), 1.0f);               // D1 = I in the fit (sd_eval.cpp:450)
         if ((rc = s.d1.put(s.h_ones, st))) return rc;
         bv.h2 = s.h2.p; bv.inv = s.inv.p; bv.L = (int) L; bv.B = (int) B; bv.tall = tall ? 1 : 0;
+        s.fit_of = (const void *) Wh;
     }
     out->L = L; out->B = B;
     s.n_in = n_in; s.n_out = n_out; s.K = Ksel; s.block = p.scheme == 1 ? p.block : 1; s.scheme = p.scheme;
     s.L = L; s.B = B; s.has_base = p.write_base != 0; s.has_rs = p.write_row_scale != 0;
+    if (!p.write_base) s.fit_of = nullptr;
 
     // ---- selection ------------------------------------------------------------------------------------
     const size_t n_val = (size_t) n_out * (size_t) K_eff;

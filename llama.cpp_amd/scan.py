@@ -84,6 +84,7 @@ class ScanParams:
     seed: int = 1234               # --seed
     metric: str = "cos"            # policy gating metric
     w_scale: Optional[np.ndarray] = None   # imatrix scale for this tensor (imatrix_scale()); None = no imatrix
+    base_mode: int = 0             # 0 fit; 1 reuse the previous fit, no draws; 2 reuse it, replay its draws
 
     def c_struct(self, kind: str, layer: int) -> sd.SdhScanParams:
         p = sd.SdhScanParams()
@@ -95,6 +96,7 @@ class ScanParams:
         p.want_proxy = 1
         p.eval_cols, p.eval_x = self.eval_cols, self.eval_x
         p.proxy_seed = self.seed + layer * 101 + KIND_ID[kind] + 1        # sd_build.cpp:1032
+        p.base_mode = self.base_mode if self.base else 0
         if self.w_scale is not None:
             self._ws = np.ascontiguousarray(self.w_scale, dtype=np.float32)   # kept alive for the call
             p.w_scale = self._ws.ctypes.data
@@ -136,6 +138,10 @@ class ScanSession:
                 "em": np.array(r.em[:]), "em_x": np.array(r.em_x[:]), "em_w": np.array(r.em_w[:]),
                 "em_x_w": np.array(r.em_x_w[:]), "cost": np.array(r.cost[:]),
                 "proxy": np.array(r.proxy[:]), "gpu_ms": float(r.gpu_ms)}
+
+    def reseed(self, seed: int):
+        """A new builder run on this handle (fresh mt19937), keeping device buffers and the last fit."""
+        sd._check(sd.load_library().sdh_scan_reseed(self._h, C.c_uint32(seed & 0xFFFFFFFF)), "sdh_scan_reseed")
 
     def skip(self, n_in: int, n_out: int, params: ScanParams, kind: str = "ffn_gate", layer: int = 0):
         """Advance the RNG as evaluating a tensor of these dims would (no GPU work)."""
@@ -208,6 +214,42 @@ def report_entry(layer: int, kind: str, n_in: int, n_out: int, params: ScanParam
         e["ffn_proxy_reason"] = (("proxy_kind_not_supported" if kind == "ffn_down" else "proxy_unavailable") if coo_nobase
                                  else "proxy_requires_eval_x" if params.eval_x <= 0 else "proxy_requires_coo")
     return e
+
+
+def autotune(session: "ScanSession", W: DenseWeight, params: ScanParams, schedule: Sequence[int], kind: str, layer: int,
+             ffn=None, min_mean: float = 0.0, min_p05: float = 0.0, max_iters: int = 0) -> dict:
+    """The K schedule of one tensor inside one builder run (sd_build.cpp:802-948): the base is fitted
+    once, then one trial per distinct positive K in schedule order, each drawing its eval samples from
+    the running stream; the first K whose gating passes is emitted. If none passes, the trial with the
+    best gating value is reported with emit = False and decision 'autotune_failed_keep_dense'."""
+    seen, ks = set(), []
+    for k in schedule:
+        if k > 0 and k not in seen:
+            seen.add(k)
+            ks.append(k)
+    if max_iters > 0:
+        ks = ks[:max_iters]
+    attempts, best, best_score, chosen = [], None, -1e30, None
+    for n, k in enumerate(ks):
+        p = ScanParams(**{**params.__dict__, "K": k, "base_mode": (1 if n > 0 else params.base_mode)})
+        res = session.tensor(W, p, kind, layer, ffn)
+        e = report_entry(layer, kind, W.n_in, W.n_out, p, res, min_mean, min_p05)
+        attempts.append({"K_budget": k, "K_eff": res["K_eff"], "n_blocks": res["n_blocks"], "metric_value": e["gating_value"],
+                         "metric_p05": e["gating_p05"], "pass": e["emit"], "seconds": res["gpu_ms"] / 1e3})
+        if e["decision"] != "metric_unavailable" and e["gating_value"] > best_score:
+            best_score, best = e["gating_value"], e
+        if e["emit"]:
+            chosen = e
+            break
+    if chosen is None:
+        chosen = dict(best) if best is not None else {"layer": layer, "kind": kind, "n_in": W.n_in, "n_out": W.n_out,
+                                                      "decision": "metric_unavailable", "gating_pass": False}
+        chosen.update(emit=False, strip_dense=False, decision="autotune_failed_keep_dense",
+                      reject_reason="autotune_failed_keep_dense", autotune_selected_budget=0)
+    else:
+        chosen["autotune_selected_budget"] = chosen["K_budget"]
+    chosen.update(autotune_enabled=True, autotune_attempts=attempts)
+    return chosen
 
 
 def imatrix_scale(imatrix_row: np.ndarray, n_in: int, eps: float = 1e-8, power: float = 1.0) -> Optional[np.ndarray]:
@@ -392,19 +434,44 @@ class Evaluator:
         candidate, so several are prepared concurrently while the GPU works through their kernels in
         stream order. Dense tensors are uploaded by the calling thread before the pool touches them."""
         from concurrent.futures import ThreadPoolExecutor
-        out: Dict[tuple, dict] = {}
+        out: Dict[int, dict] = {}
         layers: Dict[int, List[Candidate]] = {}
         for c in cands:
             layers.setdefault(c.layer, []).append(c)
+
+        def needed(layer, group):
+            proxy = any(c.kind != "ffn_down" for c in group)          # the FFN proxy reads all three tensors
+            return [(layer, k) for k in KINDS if proxy or any(c.kind == k for c in group) or self.dims_of is None]
+
+        def groups_of(group):                                         # one handle per (tensor, parameter set)
+            gs: Dict[tuple, List[Candidate]] = {}
+            for c in group:
+                gs.setdefault((c.layer, c.kind, id(params_of(c)) if params_of else 0), []).append(c)
+            return list(gs.values())
+
+        fn = lambda g: self.run_group(g, params_of(g[0]) if params_of else None)      # noqa: E731
+        want = [key for layer, group in layers.items() for key in needed(layer, group)]
         with ThreadPoolExecutor(max_workers=max(1, threads)) as pool:
-            for layer, group in layers.items():
-                proxy = any(c.kind != "ffn_down" for c in group)      # the FFN proxy reads all three tensors
-                for k in KINDS:
-                    if proxy or any(c.kind == k for c in group) or self.dims_of is None:
-                        self.dense(layer, k)
-                fn = self.run if params_of is None else (lambda c: self.run(c, params_of(c)))
-                for c, r in zip(group, pool.map(fn, group)):
-                    out[id(c)] = r
+            if len(set(want)) <= self.max_resident:                   # everything fits: one wave of work
+                for key in want:
+                    self.dense(*key)
+                batches = [groups_of(list(cands))]
+            else:                                                     # layer by layer, evicting as we go
+                batches = []
+                for layer, group in layers.items():
+                    batches.append((layer, group))
+            for batch in batches:
+                if isinstance(batch, tuple):
+                    layer, group = batch
+                    for key in needed(layer, group):
+                        self.dense(*key)
+                    gs = groups_of(group)
+                else:
+                    gs = batch
+                gs.sort(key=lambda g: -sum(1.0 + c.K / 1536.0 for c in g))       # longest first
+                for g, rs in zip(gs, pool.map(fn, gs)):
+                    for c, r in zip(g, rs):
+                        out[id(c)] = r
         return [out[id(c)] for c in cands]
 
     def dense(self, layer: int, kind: str) -> DenseWeight:
@@ -436,6 +503,31 @@ class Evaluator:
             return s.tensor(self.dense(c.layer, c.kind), p, c.kind, c.layer, ffn)
         finally:
             s.close()
+
+    def run_group(self, group: Sequence[Candidate], params: Optional[ScanParams] = None) -> List[dict]:
+        """All K of one (layer, tensor) on one handle. Every K is its own builder run (fresh RNG), but with
+        the same seed the base fit of the tensor comes out the same each time, so it is computed for the
+        first K and reused (its draws replayed) for the others."""
+        out = []
+        s = ScanSession((params or self.params).seed)
+        try:
+            for n, c in enumerate(group):
+                assert (c.layer, c.kind) == (group[0].layer, group[0].kind)
+                p = ScanParams(**{**(params or self.params).__dict__, "K": c.K})
+                p.base_mode = 2 if (n > 0 and p.base) else 0
+                s.reseed(p.seed)
+                for t in self.tensors:
+                    if t == c.kind:
+                        break
+                    n_in, n_out = self.dims_of(c.layer, t) if self.dims_of is not None else \
+                        (self.dense(c.layer, t).n_in, self.dense(c.layer, t).n_out)
+                    s.skip(n_in, n_out, p, t, c.layer)
+                need_proxy = p.scheme == "coo" and not p.base and p.eval_x > 0 and c.kind != "ffn_down"
+                ffn = tuple(self.dense(c.layer, k) for k in KINDS) if need_proxy else None
+                out.append(s.tensor(self.dense(c.layer, c.kind), p, c.kind, c.layer, ffn))
+        finally:
+            s.close()
+        return out
 
     def close(self):
         for w in self._cache.values():

@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "sdh_forward", "sdh_nonfinite_count", "sdh_w0_tile",
     "sdh_profile_enable", "sdh_profile_read", "sdh_profile_span_begin", "sdh_profile_span_end",
     "sdh_dense_create", "sdh_dense_destroy", "sdh_dense_bytes",
-    "sdh_scan_create", "sdh_scan_destroy", "sdh_scan_tensor", "sdh_scan_skip", "sdh_scan_fetch", "sdh_imatrix_scale",
+    "sdh_scan_create", "sdh_scan_destroy", "sdh_scan_reseed", "sdh_scan_tensor", "sdh_scan_skip", "sdh_scan_fetch", "sdh_imatrix_scale",
 ]
 
 
@@ -54,7 +54,7 @@ class SdhScanParams(C.Structure):
     _fields_ = [("scheme", C.c_int32), ("kind", C.c_int32), ("K", C.c_int64), ("block", C.c_int64),
                 ("write_base", C.c_int32), ("write_row_scale", C.c_int32), ("base_max_samples", C.c_int64),
                 ("base_perm_trials", C.c_int32), ("want_proxy", C.c_int32), ("eval_cols", C.c_int64),
-                ("eval_x", C.c_int64), ("proxy_seed", C.c_int32), ("reserved", C.c_int32), ("w_scale", C.c_void_p)]
+                ("eval_x", C.c_int64), ("proxy_seed", C.c_int32), ("base_mode", C.c_int32), ("w_scale", C.c_void_p)]
 
 
 class SdhScanResult(C.Structure):
@@ -132,6 +132,7 @@ def load_library(path: str = LIB_PATH):
     lib.sdh_dense_bytes.argtypes = [C.c_void_p]
     lib.sdh_dense_bytes.restype = C.c_int64
     lib.sdh_scan_create.argtypes = [C.c_uint32, C.POINTER(C.c_void_p)]
+    lib.sdh_scan_reseed.argtypes = [C.c_void_p, C.c_uint32]
     lib.sdh_scan_destroy.argtypes = [C.c_void_p]
     lib.sdh_scan_destroy.restype = None
     lib.sdh_scan_tensor.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -274,3 +274,42 @@ def test_imatrix_weighted_candidate(hip, scheme, K, block, dims):
     assert np.array_equal(r2["em"], r3["em"])
     e = SC.report_entry(0, "ffn_gate", n_in, n_out, p, res)
     assert e["has_w"] and e["cos_mean_x_w"] == res["em_x_w"][2] and e["ffn_score"] == min(res["em_x_w"][2], res["em_x_w"][3])
+
+
+def test_k_grid_reuses_the_fit_and_autotune_schedule(hip):
+    """(a) run_group: each K is a fresh builder run, the fit is computed once and its draws replayed —
+    results identical to evaluating every K from scratch. (b) autotune(): fit once, trials in schedule
+    order on one running stream, first passing K wins (sd_build.cpp:802-948)."""
+    def model(layer, kind):
+        n_in, n_out = (800, 320) if kind == "ffn_down" else (320, 800)
+        return make_dense(n_in, n_out, "q8_0", seed=10 * layer + SC.KIND_ID[kind], structure=0.4)
+    p = SC.ScanParams(base=True, row_scale=True, base_max_samples=100, base_perm_trials=2, eval_cols=16, eval_x=4)
+    ev = SC.Evaluator(model, p)
+    group = [SC.Candidate(1, "ffn_up", k) for k in (8, 24, 64)]
+    shared = ev.run_group(group)
+    for c, r in zip(group, shared):
+        fresh = ev.run(c)
+        for key in ("em", "em_x", "cost"):
+            assert np.array_equal(r[key], fresh[key]), (c.K, key)
+    many = ev.run_many(group + [SC.Candidate(1, "ffn_down", 16)], threads=2)
+    assert all(np.array_equal(a["em"], b["em"]) for a, b in zip(many[:3], shared))
+
+    W = ev.dense(1, "ffn_up")
+    s = SC.ScanSession(p.seed)
+    e = SC.autotune(s, W, p, [8, 8, 0, 24, 64], "ffn_up", 1, min_mean=0.9, min_p05=0.0)
+    ks = [a["K_budget"] for a in e["autotune_attempts"]]
+    assert ks[0] == 8 and len(ks) == len(set(ks)) and e["autotune_enabled"]
+    if e["emit"]:
+        assert e["autotune_selected_budget"] == ks[-1] and e["gating_value"] >= 0.9
+    else:
+        assert e["decision"] == "autotune_failed_keep_dense" and e["autotune_selected_budget"] == 0 and ks == [8, 24, 64]
+    # the oracle on one running stream: fit, then per K (eval_w draw, eval_x draws)
+    o = S.Engine("oracle", p.seed)
+    Wnp = model(1, "ffn_up")
+    fit = o.fit_base(Wnp, 100, 2)
+    for a in e["autotune_attempts"]:
+        idx, val, rs = S.select_rows(Wnp, fit, 0, a["K_eff"], 32, True)
+        o.eval_w(Wnp, fit, 0, idx, val, a["K_eff"], 32, rs, 16)
+        em_x = o.eval_x(Wnp, fit, 0, idx, val, a["K_eff"], 32, rs, 16, 4)
+        assert a["metric_value"] == pytest.approx(min(em_x[2], em_x[3]), rel=2e-6)       # gate/up gate on the FFN score
+    ev.close()
