@@ -117,16 +117,21 @@ void scan_fit_kernel(DenseView W, int L, int tall, const FitJob * __restrict__ j
     const int u = blockIdx.x * 256 + threadIdx.x;
     const int64_t in0 = tall ? 0 : (int64_t) job.b * L;
     const int64_t in1 = tall ? W.n_in : min((int64_t) W.n_in, in0 + L);
+    // Branch-free so that the compiler keeps several rows' gathers in flight: an out-of-range source
+    // contributes +0.0, which leaves every partial sum bit-for-bit unchanged (x + 0.0 == x, and the sums
+    // start at +0.0), so the bin still accumulates its valid samples in sample order.
     double s = 0.0, s2 = 0.0, n = 0.0;
+#pragma unroll 8
     for (int si = 0; si < job.n_rows; ++si) {
         const int row = rows[job.rows_off + si];
         const int p = tall ? row - job.b * L : row;
         const int j = (u ^ p) & (L - 1);
         const int64_t src = in0 + perm_s[j];
-        if (src < in0 || src >= in1) continue;
-        const double v = (double) dense_at(W, row, src);
+        const bool ok = src >= in0 && src < in1;
+        const int64_t srcc = ok ? src : in0;
+        const double v = ok ? (double) dense_at(W, row, srcc) : 0.0;
         if (ws) {
-            const double w1 = (double) ws[src];
+            const double w1 = ok ? (double) ws[srcc] : 0.0;
             const double ww = w1 * w1;
             s  += ww * v;
             s2 += ww * v * v;
@@ -134,7 +139,7 @@ void scan_fit_kernel(DenseView W, int L, int tall, const FitJob * __restrict__ j
         } else {            // ww == 1: ww*v == v, ww*v*v == v*v exactly
             s  += v;
             s2 += v * v;
-            n  += 1.0;
+            n  += ok ? 1.0 : 0.0;
         }
     }
     double * o = out + (size_t) blockIdx.y * 3 * L;
@@ -204,14 +209,21 @@ void scan_select_coo_kernel(DenseView W, BaseView base, int has_base, int K, int
             if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-            int cum = 0, d = 255;
-            for (; d > 0; --d) {
-                if (cum + (int) hist[d] >= need) break;
-                cum += (int) hist[d];
+        {   // digit = the largest d with (count of keys in bins > d) < need <= (count in bins >= d):
+            // suffix sums over the 256 bins, one bin per thread
+            const int mine = (int) hist[tid];
+            int suf = mine;                               // inclusive suffix sum within the wave
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_down(suf, o, 64);
+                if ((tid & 63) + o < 64) suf += t;
             }
-            isc[0] = d;
-            isc[1] = need - cum;
+            if ((tid & 63) == 0) isc[2 + (tid >> 6)] = suf;          // wave totals
+            __syncthreads();
+            int above = 0;                                // bins of higher waves
+            for (int w = (tid >> 6) + 1; w < 4; ++w) above += isc[2 + w];
+            const int ge = suf + above, gt = ge - mine;   // keys in bins >= tid, > tid
+            if (gt < need && need <= ge) { isc[0] = tid; isc[1] = need - gt; }
         }
         __syncthreads();
         prefix = (prefix << 8) | (uint32_t) isc[0];
@@ -499,6 +511,7 @@ struct Scan {
     DevBuf<int> rows, perms, cols; DevBuf<FitJob> jobs; DevBuf<double> dbl, dbl2; DevBuf<float> xs, v, gat, wsd;
     std::vector<float> h_ws;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t stream = nullptr;       // one stream per handle: candidates prepared by different host threads overlap on the GPU
     explicit Scan(uint32_t seed) : rng(seed) {}
 };
 
@@ -698,8 +711,9 @@ int sdh_scan_create(uint32_t seed, sdh_scan ** out) {
     if (!out) { set_error("sdh_scan_create: null argument"); return SDH_ERR_INVALID; }
     if (!lib().inited) { set_error("sdh_init() has not been called"); return SDH_ERR_NO_DEVICE; }
     Scan * s = new Scan(seed);
-    if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) {
-        set_error("hipEventCreate failed"); delete s; return SDH_ERR_HIP;
+    if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess ||
+        hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
+        set_error("hipEventCreate / hipStreamCreate failed"); delete s; return SDH_ERR_HIP;
     }
     *out = (sdh_scan *) s;
     return SDH_OK;
@@ -716,6 +730,7 @@ void sdh_scan_destroy(sdh_scan * h) {
     Scan * s = (Scan *) h;
     if (s->ev0) (void) hipEventDestroy(s->ev0);
     if (s->ev1) (void) hipEventDestroy(s->ev1);
+    if (s->stream) { (void) hipStreamSynchronize(s->stream); (void) hipStreamDestroy(s->stream); }
     delete s;
 }
 
@@ -742,8 +757,7 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
     if (!h || !Wh || !pp || !out) { set_error("sdh_scan_tensor: null argument"); return SDH_ERR_INVALID; }
     Scan & s = *(Scan *) h;
     const sdh_scan_params & p = *pp;
-    LibState & ls = lib();
-    hipStream_t st = ls.stream;
+    hipStream_t st = s.stream;
     const DenseView W = ((const DeviceDense *) Wh)->v;
     const int64_t n_in = W.n_in, n_out = W.n_out;
     const bool tall = n_out >= n_in;
@@ -1026,7 +1040,7 @@ int sdh_scan_fetch(sdh_scan * h, int32_t * idx, float * val, float * row_scale,
     if (!h) { set_error("sdh_scan_fetch: null handle"); return SDH_ERR_INVALID; }
     Scan & s = *(Scan *) h;
     if (s.n_out <= 0) { set_error("sdh_scan_fetch: no candidate evaluated yet"); return SDH_ERR_INVALID; }
-    hipStream_t st = lib().stream;
+    hipStream_t st = s.stream;
     const size_t n_idx = (size_t) s.n_out * (size_t) s.K;
     if (idx) SDH_HIP_CHECK(hipMemcpyAsync(idx, s.idx.p, n_idx * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     if (val) SDH_HIP_CHECK(hipMemcpyAsync(val, s.val.p, n_idx * (size_t) s.block * sizeof(float), hipMemcpyDeviceToHost, st));
