@@ -217,7 +217,7 @@ def report_entry(layer: int, kind: str, n_in: int, n_out: int, params: ScanParam
 
 
 def autotune(session: "ScanSession", W: DenseWeight, params: ScanParams, schedule: Sequence[int], kind: str, layer: int,
-             ffn=None, min_mean: float = 0.0, min_p05: float = 0.0, max_iters: int = 0) -> dict:
+             ffn=None, min_mean: float = 0.0, min_p05: float = 0.0, max_iters: int = 0, gating_enabled: bool = True) -> dict:
     """The K schedule of one tensor inside one builder run (sd_build.cpp:802-948): the base is fitted
     once, then one trial per distinct positive K in schedule order, each drawing its eval samples from
     the running stream; the first K whose gating passes is emitted. If none passes, the trial with the
@@ -233,7 +233,7 @@ def autotune(session: "ScanSession", W: DenseWeight, params: ScanParams, schedul
     for n, k in enumerate(ks):
         p = ScanParams(**{**params.__dict__, "K": k, "base_mode": (1 if n > 0 else params.base_mode)})
         res = session.tensor(W, p, kind, layer, ffn)
-        e = report_entry(layer, kind, W.n_in, W.n_out, p, res, min_mean, min_p05)
+        e = report_entry(layer, kind, W.n_in, W.n_out, p, res, min_mean, min_p05, gating_enabled)
         attempts.append({"K_budget": k, "K_eff": res["K_eff"], "n_blocks": res["n_blocks"], "metric_value": e["gating_value"],
                          "metric_p05": e["gating_p05"], "pass": e["emit"], "seconds": res["gpu_ms"] / 1e3})
         if e["decision"] != "metric_unavailable" and e["gating_value"] > best_score:
@@ -244,6 +244,7 @@ def autotune(session: "ScanSession", W: DenseWeight, params: ScanParams, schedul
     if chosen is None:
         chosen = dict(best) if best is not None else {"layer": layer, "kind": kind, "n_in": W.n_in, "n_out": W.n_out,
                                                       "decision": "metric_unavailable", "gating_pass": False}
+        chosen["_trial_decision"] = chosen.get("decision")
         chosen.update(emit=False, strip_dense=False, decision="autotune_failed_keep_dense",
                       reject_reason="autotune_failed_keep_dense", autotune_selected_budget=0)
     else:
@@ -639,3 +640,123 @@ def report_document(entries: Sequence[dict], params: ScanParams, input_name: str
         return round_like_report(v)
     doc["weights"] = [rnd(complete_entry(e)) for e in entries]
     return doc
+
+
+# ---- one builder run over layers and tensors (sd_build.cpp:245-1102) ---------------------------------------
+class StackSafetyTracker:
+    """include/sd_build.h:22-50: thresholds tighten as more tensors of a kind have been emitted."""
+
+    def __init__(self):
+        self.gate_up_pass = 0
+        self.down_pass = 0
+
+    def adjust(self, kind: str, min_mean: float, min_p05: float) -> Tuple[float, float]:
+        f32 = np.float32
+        down = kind == "ffn_down"
+        passed = self.down_pass if down else self.gate_up_pass
+        if passed >= 8:
+            lo = (0.35, 0.25) if down else (0.60, 0.45)
+            return float(max(f32(min_mean), f32(lo[0]))), float(max(f32(min_p05), f32(lo[1])))
+        if passed >= 3:
+            return float(f32(min_mean) + f32(0.05)), float(f32(min_p05) + f32(0.05))
+        return min_mean, min_p05
+
+    def record_pass(self, kind: str):
+        if kind == "ffn_down":
+            self.down_pass += 1
+        else:
+            self.gate_up_pass += 1
+
+
+def build_run(model: ModelFn, layers: Sequence[int], params: ScanParams, policy=None, imatrix: Optional[Dict[str, np.ndarray]] = None,
+              imatrix_eps: float = 1e-8, imatrix_power: float = 1.0, stack_cost_cap: float = 0.0, strip_dense: bool = False,
+              have_tensor: Optional[Callable[[int, str], bool]] = None, keep_staging: bool = True) -> dict:
+    """What one `llama-seeddelta-build --layers ... [--policy p.json]` process decides, tensor by tensor,
+    on ONE running RNG stream: resolve the policy, adjust thresholds by the stack guard, fit / trial /
+    autotune on the GPU, FFN proxy, stack cost accounting and cap. Returns the report entries and, for
+    emitted tensors, their staging arrays (ScanSession.fetch) ready for pack.pack_candidate.
+
+    `policy` is a llama_cpp_amd.policy.Policy or None (no policy: everything enabled, no gating)."""
+    from . import policy as PL
+    if policy is not None and params.eval_cols <= 0:
+        raise ValueError("--policy requires --eval-cols > 0 for gating/autotune")        # sd_build.cpp:287-292
+    session = ScanSession(params.seed)
+    guard = StackSafetyTracker()
+    entries, emitted, cost_running = [], {}, 0.0
+    cache: Dict[Tuple[int, str], DenseWeight] = {}
+
+    def dense(layer, kind):
+        if (layer, kind) not in cache:
+            cache[(layer, kind)] = DenseWeight(model(layer, kind))
+        return cache[(layer, kind)]
+
+    try:
+        for layer in layers:
+            for kind in KINDS:
+                base_cfg = PL.Resolved(block=params.block, K_gate=params.K, K_up=params.K, K_down=params.K, strip_dense=strip_dense,
+                                       enabled=True, metric="cos_x_w", gating_enabled=policy is not None)
+                base_cfg.min_mean, base_cfg.min_p05 = (0.25, 0.15) if kind == "ffn_down" else (0.45, 0.30)     # :304-311
+                cfg = PL.resolve(policy, layer, kind, base_cfg)
+                min_mean, min_p05 = cfg.min_mean, cfg.min_p05
+                if cfg.gating_enabled:
+                    min_mean, min_p05 = guard.adjust(kind, min_mean, min_p05)
+                if cfg.require_eval_x and (params.eval_x <= 0 or params.eval_cols <= 0):
+                    raise ValueError(f"gating metric requires --eval-x and --eval-cols > 0 for blk.{layer}.{kind}.weight")
+                if cfg.require_imatrix and imatrix is None:
+                    raise ValueError(f"gating metric requires imatrix for blk.{layer}.{kind}.weight")
+
+                def stub(decision, n_in=0, n_out=0):
+                    return {"layer": layer, "kind": kind, "n_in": n_in, "n_out": n_out, "emit": False, "strip_dense": False,
+                            "gating_enabled": policy is not None, "gating_pass": False, "decision": decision,
+                            "reject_reason": decision, "gating_metric": cfg.metric, "metric_used": cfg.metric,
+                            "gating_min_mean": min_mean, "gating_min_p05": min_p05,
+                            "targets_used": {"tau_mean": min_mean, "tau_p05": min_p05}}
+                if have_tensor is not None and not have_tensor(layer, kind):
+                    entries.append(stub("missing_tensor"))
+                    continue
+                W = dense(layer, kind)
+                if not cfg.enabled:
+                    entries.append(stub("disabled", W.n_in, W.n_out))
+                    continue
+                ws = None
+                if imatrix is not None and f"blk.{layer}.{kind}.weight" in imatrix:
+                    ws = imatrix_scale(imatrix[f"blk.{layer}.{kind}.weight"], W.n_in, imatrix_eps, imatrix_power)
+                if cfg.require_imatrix and ws is None:
+                    entries.append(stub("missing_imatrix", W.n_in, W.n_out))
+                    continue
+                K_budget = max(1, min(cfg.K_of(kind), W.n_in))
+                p = ScanParams(**{**params.__dict__, "K": K_budget, "block": cfg.block if params.scheme == "block" else params.block,
+                                  "metric": cfg.metric, "w_scale": ws, "base_mode": 0})
+                schedule = []
+                if cfg.autotune.enabled:
+                    schedule = cfg.autotune.schedule_down if kind == "ffn_down" else cfg.autotune.schedule_gate_up
+                schedule = list(schedule) or [K_budget]
+                proxy = p.scheme == "coo" and not p.base and p.eval_x > 0 and kind != "ffn_down"
+                ffn = tuple(dense(layer, k) for k in KINDS) if proxy else None
+                e = autotune(session, W, p, schedule, kind, layer, ffn, min_mean, min_p05,
+                             cfg.autotune.max_iters if cfg.autotune.enabled else 0, gating_enabled=cfg.gating_enabled)
+                if not cfg.autotune.enabled:                      # a one-K run reports like the plain trial
+                    e["autotune_enabled"], e["autotune_attempts"] = False, []
+                    if not e["emit"]:
+                        e["decision"] = e["reject_reason"] = e.pop("_trial_decision", e["decision"])
+                e.pop("_trial_decision", None)
+                e["strip_dense"] = bool(e["emit"] and cfg.strip_dense)
+                delta = 0.0
+                if e["emit"] and math.isfinite(e["gating_value"]) and math.isfinite(e["gating_p05"]):
+                    delta = max(0.0, min_mean - e["gating_value"]) + max(0.0, min_p05 - e["gating_p05"])        # :1060-1076
+                e["stack_cost_delta"] = delta
+                e["stack_cost_total"] = cost_running + (delta if e["emit"] else 0.0)
+                if e["emit"]:
+                    cost_running = e["stack_cost_total"]
+                    if cost_running > stack_cost_cap:                                                          # :1084-1092 (cap 0 => any cost)
+                        e.update(emit=False, strip_dense=False, decision="stack_cost_cap", reject_reason="stack_cost_cap")
+                    else:
+                        guard.record_pass(kind)
+                        if keep_staging:
+                            emitted[(layer, kind)] = (p, e["K"], session.fetch())
+                entries.append(e)
+    finally:
+        session.close()
+        for w in cache.values():
+            w.close()
+    return {"entries": entries, "emitted": emitted, "stack_pass_gate_up": guard.gate_up_pass, "stack_pass_down": guard.down_pass}

@@ -313,3 +313,48 @@ def test_k_grid_reuses_the_fit_and_autotune_schedule(hip):
         em_x = o.eval_x(Wnp, fit, 0, idx, val, a["K_eff"], 32, rs, 16, 4)
         assert a["metric_value"] == pytest.approx(min(em_x[2], em_x[3]), rel=2e-6)       # gate/up gate on the FFN score
     ev.close()
+
+
+def test_build_run_follows_the_builder_control_flow(hip):
+    """One builder process over several layers on one RNG stream (sd_build.cpp:296-1102): policy
+    resolution, disabled tensors, per-kind K, autotune, stack guard bookkeeping — and the metrics of
+    every tensor equal the oracle's when it walks the same stream tensor after tensor."""
+    from llama_cpp_amd import pack as PK, policy as PL
+
+    def model(layer, kind):
+        n_in, n_out = (704, 288) if kind == "ffn_down" else (288, 704)
+        return make_dense(n_in, n_out, "q8_0", seed=7 * layer + SC.KIND_ID[kind], structure=0.5)
+    pol = PL.load_policy({
+        "version": 1,
+        "defaults": {"enabled": True, "K": {"gate": 16, "up": 24, "down": 32},
+                     "gating": {"metric": "cos", "min_mean": {"gate": 0.1, "up": 0.1, "down": 0.99}, "min_p05": 0.0}},
+        "ranges": [{"layers": "0", "enabled": False}],
+        "layers": {"2": {"tensors": {"ffn_up": {"autotune": {"enabled": True, "schedule_gate_up": [8, 40, 200], "max_iters": 3},
+                                                "gating": {"min_mean": 0.8}}}}}}, strict=True)
+    p = SC.ScanParams(base=True, row_scale=True, base_max_samples=64, base_perm_trials=2, eval_cols=16, eval_x=4, K=32)
+    out = SC.build_run(model, [0, 1, 2], p, policy=pol)
+    es = out["entries"]
+    assert [(e["layer"], e["kind"]) for e in es] == [(l, k) for l in (0, 1, 2) for k in SC.KINDS]
+    assert all(e["decision"] == "disabled" and not e["emit"] for e in es[:3])
+    assert [e["K"] for e in es[3:6]] == [16, 24, 32]
+    assert es[3]["emit"] and es[3]["gating_metric"] == "ffn_score" and es[3]["decision"] == "pass_gating"
+    assert not es[5]["emit"] and es[5]["decision"] == "gating_fail" and es[5]["gating_metric"] == "cos"      # down needs 0.99
+    up2 = es[7]
+    assert up2["autotune_enabled"] and [a["K_budget"] for a in up2["autotune_attempts"]][0] == 8
+    assert up2["emit"] == any(a["pass"] for a in up2["autotune_attempts"])
+    assert out["stack_pass_gate_up"] == sum(e["emit"] for e in es if e["kind"] != "ffn_down") and out["stack_pass_down"] == 0
+    # emitted tensors can be packed into payloads the FFN op accepts
+    (layer, kind), (pp, K, staging) = next(iter(out["emitted"].items()))
+    payload = PK.pack_candidate(staging, *SC.dense_dims(model(layer, kind)), "coo")
+    assert hip.SeedDeltaWeight(payload).kind == 2
+
+    # the oracle walking the same stream: disabled tensors draw nothing; each trial = [fit] select eval_w eval_x
+    o = S.Engine("oracle", p.seed)
+    for e in es[3:6]:
+        Wnp = model(e["layer"], e["kind"])
+        fit = o.fit_base(Wnp, 64, 2)
+        idx, val, rs = S.select_rows(Wnp, fit, 0, e["K"], 32, True)
+        em = o.eval_w(Wnp, fit, 0, idx, val, e["K"], 32, rs, 16)
+        em_x = o.eval_x(Wnp, fit, 0, idx, val, e["K"], 32, rs, 16, 4)
+        assert e["cos_mean"] == pytest.approx(em[2], rel=2e-6) and e["rel_l2_p95"] == pytest.approx(em[1], rel=2e-6)
+        assert e["cos_p05_x"] == pytest.approx(em_x[3], rel=2e-6)
