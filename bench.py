@@ -159,7 +159,7 @@ def run_scan(args, rank, world, dev):
     t0 = time.perf_counter()
     res = ev.run_many(mine, threads=args.scan_threads, params_of=lambda c: variants[c.variant])
     local = np.stack([SC.to_record(c, r) for c, r in zip(mine, res)]) if mine else np.zeros((0, SC.RECORD_LEN))
-    allr = SC.gather_records(local, counts, device=dev)
+    allr = SC.gather_records(local, counts, device=None if os.environ.get("SDH_BENCH_ONE_DEVICE") == "1" else dev)
     torch.cuda.synchronize()
     if world > 1:
         import torch.distributed as dist
@@ -167,7 +167,7 @@ def run_scan(args, rank, world, dev):
     elapsed = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if os.environ.get("SDH_BENCH_ONE_DEVICE") == "1" else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ev.close()
@@ -221,10 +221,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal on a one-GPU box: SDH_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and uses gloo (RCCL refuses
+    # two ranks on one device); the driver's real multi-GPU runs take the default nccl (= RCCL) path
+    rehearsal = os.environ.get("SDH_BENCH_ONE_DEVICE") == "1"
+    if rehearsal:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     seeddelta.init(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -295,7 +303,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
