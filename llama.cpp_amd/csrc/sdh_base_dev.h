@@ -28,11 +28,14 @@ __device__ unsigned long long * sdh_diag_buf;
     do {                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                        \
         if (threadIdx.x == 0)                                                                     \
-            sdh_diag_buf[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+            sdh_diag_buf[(blockIdx.y * gridDim.x + blockIdx.x) * 32 + (k)] = __builtin_amdgcn_s_memrealtime(); \
         __builtin_amdgcn_sched_barrier(0);                                                        \
     } while (0)
+#define SDH_DIAG_VAL(k, v)                                                                        \
+    do { if (threadIdx.x == 0) sdh_diag_buf[(blockIdx.y * gridDim.x + blockIdx.x) * 32 + (k)] = (v); } while (0)
 #else
 #define SDH_STAMP(k) do { } while (0)
+#define SDH_DIAG_VAL(k, v) do { } while (0)
 #endif
 
 namespace sdh {

@@ -22,7 +22,7 @@ import numpy as np
 from .payload import Payload
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libseeddelta_hip.so")
+LIB_PATH = os.environ.get("SEEDDELTA_HIP_LIB") or os.path.join(HERE, "csrc", "libseeddelta_hip.so")   # env: dev A/B builds
 
 SDH_TYPE = {np.dtype(np.float32): 0, np.dtype(np.float16): 1, np.dtype(np.int16): 25, np.dtype(np.int32): 26}
 
