@@ -394,10 +394,10 @@ int sdh_weight_create(const sdh_weight_desc * desc, sdh_weight ** out) {
             if ((rc = upload(slab, &w->pack_dev)) != SDH_OK) return fail(rc);
             pd.pack = w->pack_dev;
         }
-        // hand-off buffer of the fused decode kernel: [B][L] base granules, then [n_out] residual
-        // granules, each {value, epoch} (tag 0 = never written; epochs start at 1)
+        // hand-off buffer of the fused decode kernel: [B][L] granules {value, epoch} (tag 0 = never
+        // written; epochs start at 1)
         {
-            const size_t gb = ((size_t) L * (size_t) B + (size_t) n_out) * sizeof(unsigned long long);
+            const size_t gb = (size_t) L * (size_t) B * sizeof(unsigned long long);
             hipError_t e = hipMalloc((void **) &w->handoff, gb);
             if (e == hipSuccess) e = hipMemset(w->handoff, 0, gb);
             if (e != hipSuccess) { set_error("hand-off alloc failed: %s", hipGetErrorString(e)); return fail(SDH_ERR_HIP); }

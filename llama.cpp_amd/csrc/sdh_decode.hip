@@ -4,29 +4,25 @@
 // (2 FWHTs per block behind a cold parameter fetch) takes ~5 us on its own, and a dependent kernel
 // boundary costs another ~1.5-2.5 us. Running the two as separate launches serialises them. Here
 // the first B workgroups of the grid compute the base blocks while all the others stream the
-// residual rows; a residual wave publishes its row sums and LEAVES, and the base workgroups, which
-// are the last to finish anyway, add them to the base term, scale and store the outputs.
-//   tall: base workgroup b owns rows [bL, bL + L): y[o] = (v_b[o - bL] + r[o]) * s[o]
-//   wide: y[o] = (sum_b v_b[o] + r[o]) * s[o]; workgroup b owns a 1/B slice of the outputs and the
-//         base workgroups exchange the other slices of their v_b.
+// residual; a residual wave picks up the base term of its row at the very end.
 //
-// Hand-off (cdna_hip_programming.md Guideline 16, form R2 "the data IS the flag"): every value
-// that crosses workgroups is a naturally aligned 8-byte {value, epoch} granule written by ONE
-// agent-scope (sc1, write-through) store; the consumer reads it with an agent-scope 8-byte load
-// and accepts it only when the tag equals this launch's epoch. A granule is written by one store
-// and read by one load, so no flag, fence or ordering between different addresses is involved, and
-// every polling lane has addresses of its own (a single shared flag word measured 3 us slower:
-// every poll of the launch lands on one line). The epoch is a host counter bumped per launch, so
-// granules of earlier launches are never accepted (which is also why this path is not used under
-// stream capture: a replayed launch would replay its epoch).
+// Hand-off (cdna_hip_programming.md Guideline 16, form R2 "the data IS the flag"): the base
+// workgroups publish every output element as a naturally aligned 8-byte {value, epoch} granule
+// written by ONE agent-scope (sc1, write-through) store; a consumer lane reads the granules of its
+// row with agent-scope (sc1) 8-byte
+// loads and accepts them only when the tag equals this launch's epoch. A granule is written by one
+// store and read by one load, so no flag, fence or ordering between different addresses is
+// involved, nothing depends on workgroup placement or dispatch order, and the 4096 polling lanes
+// touch 4096 different addresses (a single shared flag word measured 3 us slower: every poll of the
+// launch lands on one line). The epoch is a host counter bumped per launch, so granules of earlier
+// launches are never accepted (which is also why this path is not used under stream capture: a
+// replayed launch would replay its epoch).
 //
-// Progress: only the B base workgroups ever wait. The residual workgroups never do, so they drain
-// whatever the dispatch order or the occupancy, and the base workgroups only need each other (B <= 8
-// workgroups) to become resident at some point. No residency assumption on the grid is made (the
-// first version of this kernel had the ~1000 residual workgroups poll for the base values instead:
-// it needed the whole grid co-resident, a census launch to prove it, and was 10-25 % slower).
-// All spins are bounded by the real-time counter; a workgroup that gives up writes NaN, which the
-// non-finite counter reports.
+// Safety: the consumers spin, so every workgroup of the grid must be resident together. The host
+// only takes this path when grid <= occupancy x CUs, and verifies that once per kernel with a
+// census launch (every workgroup checks in and waits, bounded, for all the others) — on gfx950 the
+// occupancy API can over-report by one workgroup per CU. All spins are bounded by the real-time
+// counter; a consumer that gives up writes NaN, which the non-finite counter reports.
 #include "sdh_internal.h"
 #include "sdh_base_dev.h"
 #include "sdh_delta_dev.h"
@@ -44,16 +40,14 @@ constexpr unsigned long long SPIN_TICKS = 50000;      // 100 MHz ticks = 500 us
 #endif
 
 struct FusedArgs {
-    unsigned long long * vg;      // [B][L] base granules {value, epoch}: the exchange between base workgroups (wide)
-    unsigned long long * ag;      // [n_out] residual granules {row sum, epoch}
+    unsigned long long * vg;      // [B][L] granules {value, epoch}
     unsigned   epoch;
-    int        chunk;             // wide, B >= 2: outputs finished by each base workgroup
-    int        ko;                // ceil(chunk / 256): outputs per thread of a base workgroup
+    int        census;            // 1: census launch (no computation)
+    unsigned * census_ctr;        // [0] arrivals, [1] failures
 };
 
-// Element i of a buffer as (uniform base + 32-bit byte offset): the addressing form that keeps the
-// base in scalar registers, so a lane holds one dword per pending access instead of a 64-bit
-// address (the buffers here are far below 4 GiB).
+// Element i of a buffer as (uniform base + 32-bit byte offset): keeps the base in scalar registers
+// and the access a global (not flat) one; the buffers here are far below 4 GiB.
 template <typename T>
 __device__ __forceinline__ T * at32(T * base, int i) {
     using Byte = std::conditional_t<std::is_const_v<T>, const char, char>;
@@ -62,197 +56,166 @@ __device__ __forceinline__ T * at32(T * base, int i) {
 __device__ __forceinline__ unsigned long long granule_load(const unsigned long long * base, int i) {
     return __hip_atomic_load(at32(base, i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void granule_store(unsigned long long * base, int i, unsigned epoch, float v) {
-    __hip_atomic_store(at32(base, i), ((unsigned long long) epoch << 32) | (unsigned long long) __float_as_uint(v),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
-// slots of the wide gather: per finished output B base granules and the residual granule; the host
-// checks (B + 1) * ko <= slots (true for every B <= 8 when n_out <= L)
-template <int LOG_E> struct FusedSlots { static constexpr int N = (1 << LOG_E) + 8; };
-
-template <bool BLOCK, int STEPS, int LOG_E>
-__global__ __launch_bounds__(256, 4)
-void decode_fused_kernel(const DeltaParams p, const BasePackDesc pd, const FusedArgs fa) {
-#pragma clang fp contract(off)
-    using Ly = BaseLay<LOG_E>;
-    constexpr int L = Ly::L;
-    constexpr int E = Ly::E;
-    constexpr int JL = Ly::J - 1;
-    __shared__ __align__(16) float lds[L];             // one transpose buffer
-
-    if ((int) blockIdx.x >= p.B) {
-        // ---- residual role: stream the rows, publish each row sum, leave ------------------------
-#ifdef SDH_RESID_DELAY
-        __builtin_amdgcn_s_sleep(SDH_RESID_DELAY);     // experiment: let the base blocks' loads reach the memory system first
-#endif
-        const int lane = threadIdx.x & 63;
-        const int wave = threadIdx.x >> 6;
-        const int G = p.G;
-        const int l = lane & (G - 1);
-        const int o = (((int) blockIdx.x - p.B) * 4 + wave) * (64 / G) + (lane / G);
-        const bool row_ok = o < p.n_out;
-        SDH_STAMP(10);
-        float acc = delta_row_partial<uint16_t, uint16_t, BLOCK, STEPS>(p, p.x, row_ok ? o : 0, row_ok, l, G);
-        acc = group_reduce(acc, G);
-        SDH_STAMP(11);
-        if (row_ok && l == 0) granule_store(fa.ag, o, fa.epoch, acc);
-        return;
-    }
-
-    // ---- base role: one block of the base transform, then the outputs it owns ---------------------
-    const int b = blockIdx.x;
-    const int tid = threadIdx.x;
-    __builtin_amdgcn_s_setprio(SDH_BASE_PRIO);         // the base blocks are the critical path of the launch
-    const float qnan = __uint_as_float(0x7FC00000u);
-    float y[E];
-
-    if (p.tall || p.B == 1) {
-        // Every output of rows [o0, o0 + L) needs only this block's base value: finish them straight
-        // from the last layout (consecutive lanes, consecutive rows).
-        const int o0 = p.tall ? b * L : 0;
-        float sc[E];
-#pragma unroll
-        for (int r = 0; r < E; ++r) {
-            const int o = o0 + Ly::idx(JL, tid, r);
-            sc[r] = (p.rs && o < p.n_out) ? *at32(p.rs, o) : 1.0f;
-        }
-        base_transform<LOG_E, false, true>(p.x, p.n_in, p.tall ? 0 : b * L, p.x_vec_ok != 0, pd, b, lds, tid, y);
-        SDH_STAMP(6);
-        // One pass = every granule load of the thread issued back to back from clamped (always valid)
-        // addresses, then the tags: a branch around a load would make hipcc wait for each load in
-        // turn (measured: 20 dependent round trips, 7.4 us, instead of one).
-        float a[E];
-        bool ok;
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        do {
-            unsigned long long g[E];
-#pragma unroll
-            for (int r = 0; r < E; ++r) {
-                const int o = o0 + Ly::idx(JL, tid, r);
-                g[r] = granule_load(fa.ag, o < p.n_out ? o : o0);
-            }
-            ok = true;
-#pragma unroll
-            for (int r = 0; r < E; ++r) {
-                const int o = o0 + Ly::idx(JL, tid, r);
-                ok = ok & (((unsigned) (g[r] >> 32) == fa.epoch) | (o >= p.n_out));
-                a[r] = __uint_as_float((unsigned) g[r]);
-            }
-            if (ok) break;
-            __builtin_amdgcn_s_sleep(SDH_POLL_SLEEP);
-        } while (__builtin_amdgcn_s_memrealtime() - t0 < SPIN_TICKS);
-        SDH_STAMP(12);
-#pragma unroll
-        for (int r = 0; r < E; ++r) {
-            const int o = o0 + Ly::idx(JL, tid, r);
-            if (o < p.n_out) {
-                const float yh = p.tall ? y[r] : 0.0f + y[r];       // wide: the sum over blocks starts from 0.0f
-                float out = yh + a[r];
-                if (!ok) out = qnan;                                 // a row sum never arrived: surface it as a NaN
-                store_output(p, o, 0, out, sc[r]);
-            }
-        }
-        return;
-    }
-
-    // wide, B >= 2: output o is sum_b v_b[o]. Workgroup b finishes outputs [own0, own1). Every base
-    // workgroup publishes all of its values as granules and gathers, per output it owns, the B base
-    // values (its own included: the round trip is hidden behind the wait for the others and keeps
-    // the gather uniform) and the residual sum.
-    constexpr int SL = FusedSlots<LOG_E>::N;
-    constexpr int KMAX = E / 2;                        // B >= 2: at most L / 2 outputs per workgroup
-    const int own0 = b * fa.chunk;
-    const int own1 = min(own0 + fa.chunk, p.n_out);
-    float rsv[KMAX];
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-        const int o = own0 + tid + 256 * k;
-        rsv[k] = (p.rs && k < fa.ko && o < own1) ? *at32(p.rs, o) : 1.0f;
-    }
-    base_transform<LOG_E, false, true>(p.x, p.n_in, b * L, p.x_vec_ok != 0, pd, b, lds, tid, y);
-#ifdef SDH_DIAG_TWICE
-    // diagnostic: the same transform again, now with warm parameters and a warm instruction cache
-    if (threadIdx.x == 0) {
-        unsigned long long * d = sdh_diag_buf + (size_t) blockIdx.x * 32;
-        for (int k = 1; k <= 5; ++k) d[16 + k] = d[k];
-    }
-    __syncthreads();
-    SDH_STAMP(7);
-    base_transform<LOG_E, false, true>(p.x, p.n_in, b * L, p.x_vec_ok != 0, pd, b, lds, tid, y);
-    SDH_STAMP(8);
-#endif
-#pragma unroll
-    for (int r = 0; r < E; ++r) {
-        const int pos = Ly::idx(JL, tid, r);
-        if (pos < p.n_out) granule_store(fa.vg, b * L + pos, fa.epoch, y[r]);
-    }
-    SDH_STAMP(6);
-    __syncthreads();                                   // the transform's last LDS readers
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) lds[tid + 256 * k] = rsv[k];   // private to this thread from here on
-
-    float val[SL];
-    bool ok;
-    [[maybe_unused]] unsigned long long polls = 0;
+// Wait for the nbase <= N base granules of output o. One poll = all N loads issued back to back,
+// then the tags. The loads are branch-free (slots past nbase re-read block 0): with a branch around
+// each load hipcc waits for every load in turn, one memory-side round trip per base block.
+template <int N>
+__device__ __forceinline__ bool poll_granules(const FusedArgs & fa, int o, int L, int nbase, float (&vals)[8]) {
+    bool ok = false;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     do {
-        ++polls;
-        unsigned long long g[SL];
-        unsigned dead = 0;                             // bit s: slot s is not in use
-        int k = 0, bb = 0;                             // slot -> (output k of this thread, source bb); uniform
+        unsigned long long g[N];
 #pragma unroll
-        for (int s = 0; s < SL; ++s) {                 // loads first, branch-free (see the tall path)
-            const int o = own0 + tid + 256 * k;
-            const bool live = (k < fa.ko) & (o < own1);
-            g[s] = granule_load(fa.vg, live ? bb * L + o : b * L);   // ag follows vg: source B is the residual
-            dead |= live ? 0u : (1u << s);
-            const bool wrap = bb == p.B;
-            bb = wrap ? 0 : bb + 1;
-            k += wrap ? 1 : 0;
-        }
+        for (int b = 0; b < N; ++b) g[b] = granule_load(fa.vg, (b < nbase ? b * L : 0) + o);
         ok = true;
 #pragma unroll
-        for (int s = 0; s < SL; ++s) {
-            ok = ok & (((unsigned) (g[s] >> 32) == fa.epoch) | ((dead >> s) & 1u));
-            val[s] = __uint_as_float((unsigned) g[s]);
+        for (int b = 0; b < 8; ++b) {
+            vals[b] = 0.0f;
+            if (b < N) {
+                ok = ok & (((unsigned) (g[b] >> 32) == fa.epoch) | (b >= nbase));
+                vals[b] = (b < nbase) ? __uint_as_float((unsigned) g[b]) : 0.0f;
+            }
         }
         if (ok) break;
         __builtin_amdgcn_s_sleep(SDH_POLL_SLEEP);
     } while (__builtin_amdgcn_s_memrealtime() - t0 < SPIN_TICKS);
-    SDH_STAMP(12);
-    {
-        int k = 0, bb = 0;
-        float yh = 0.0f;                               // block order from 0.0f, then the residual (:1140-1150)
-#pragma unroll
-        for (int s = 0; s < SL; ++s) {
-            if (k < fa.ko) {
-                if (bb < p.B) yh += val[s];
-                else {
-                    const int o = own0 + tid + 256 * k;
-                    if (o < own1) store_output(p, o, 0, ok ? yh + val[s] : qnan, lds[tid + 256 * k]);
-                    yh = 0.0f;
-                }
+    return ok;
+}
+
+template <bool BLOCK, int STEPS, int LOG_E>
+__global__ __launch_bounds__(256)
+void decode_fused_kernel(const DeltaParams p, const BasePackDesc pd, const FusedArgs fa) {
+    constexpr int L = BaseLay<LOG_E>::L;
+    constexpr int E = BaseLay<LOG_E>::E;
+    __shared__ __align__(16) float lds[L];             // one transpose buffer: occupancy over barriers
+
+    if (fa.census) {                                   // residency self-test, see header comment
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(&fa.census_ctr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            bool all = false;
+            while (__builtin_amdgcn_s_memrealtime() - t0 < 2 * SPIN_TICKS) {
+                if (__hip_atomic_load(&fa.census_ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= gridDim.x) { all = true; break; }
+                __builtin_amdgcn_s_sleep(8);
             }
-            if (++bb > p.B) { bb = 0; ++k; }
+            if (!all) __hip_atomic_fetch_add(&fa.census_ctr[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        return;
     }
-    SDH_DIAG_VAL(14, polls);
-    SDH_STAMP(13);
+
+    if ((int) blockIdx.x < p.B) {
+        // ---- base role: one block of the base transform, published write-through + flag --------
+        const int b = blockIdx.x;
+        const int tid = threadIdx.x;
+        __builtin_amdgcn_s_setprio(SDH_BASE_PRIO);     // the base blocks are the critical path of the launch
+        float y[E];
+        base_transform<LOG_E, false, true>(p.x, p.n_in, p.tall ? 0 : b * L, p.x_vec_ok != 0, pd, b, lds, tid, y);
+        // Publish as {value, epoch} granules, one agent-scope (sc1, write-through) 8-byte store each,
+        // straight from the last layout (consecutive lanes write consecutive granules). Measured
+        // alternatives, all slower end to end on the cfg3 shape: two granules per 16-byte sc1 store
+        // after an LDS re-order (+5 us: the stores collide with the pollers of the same lines), plain
+        // f32 values + one flag per block (+2.5 us: 4096 pollers on one line).
+        unsigned long long * out = fa.vg + (size_t) b * L;
+        const unsigned long long tag = (unsigned long long) fa.epoch << 32;
+#pragma unroll
+        for (int r = 0; r < E; ++r)
+            __hip_atomic_store(out + BaseLay<LOG_E>::idx(BaseLay<LOG_E>::J - 1, tid, r),
+                               tag | (unsigned long long) __float_as_uint(y[r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        SDH_STAMP(6);
+        return;
+    }
+
+    // ---- residual role ------------------------------------------------------------------------
+#ifdef SDH_RESID_DELAY
+    __builtin_amdgcn_s_sleep(SDH_RESID_DELAY);         // build variant (A/B): within 2 % for any value tried
+#endif
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int G = p.G;
+    const int l = lane & (G - 1);
+    const int o = (((int) blockIdx.x - p.B) * 4 + wave) * (64 / G) + (lane / G);
+    const bool row_ok = o < p.n_out;
+    const int orow = row_ok ? o : 0;
+    const bool leader = row_ok && l == 0;
+    float scale = 1.0f;
+    if (leader && p.rs) scale = p.rs[o];
+
+    SDH_STAMP(10);
+    float acc = delta_row_partial<uint16_t, uint16_t, BLOCK, STEPS>(p, p.x, orow, row_ok, l, G);
+    acc = group_reduce(acc, G);
+    SDH_STAMP(11);
+
+    if (leader) {
+        // base term: tall v_b[o - bL] with b = o / L (buffer index b*L + (o - b*L) == o);
+        // wide sum_b v_b[o], accumulated from 0.0f in block order
+        const int nbase = p.tall ? 1 : p.B;             // host guarantees nbase <= 8
+        float vals[8];
+        bool ok;
+        if (nbase == 1)      ok = poll_granules<1>(fa, o, L, nbase, vals);
+        else if (nbase <= 4) ok = poll_granules<4>(fa, o, L, nbase, vals);
+        else                 ok = poll_granules<8>(fa, o, L, nbase, vals);
+        SDH_STAMP(12);
+        float yh;
+        if (p.tall) yh = vals[0];
+        else {
+            yh = 0.0f;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) if (b < nbase) yh += vals[b];
+        }
+        float y = yh + acc;
+        if (!ok) y = __uint_as_float(0x7FC00000u);       // base never arrived: surface it as a NaN
+        store_output(p, o, 0, y, scale);
+    }
 }
 
 // ---- host side ----------------------------------------------------------------------------------
+struct FusedKernelInfo {
+    int occ = -1;                 // resident workgroups per CU (occupancy API)
+    unsigned census_ok_grid = 0;  // largest grid the census has confirmed
+    bool census_failed = false;
+};
+
+template <bool BLOCK, int STEPS, int LOG_E>
+static FusedKernelInfo & kernel_info() {
+    static FusedKernelInfo info;
+    return info;
+}
+
 template <bool BLOCK, int STEPS, int LOG_E>
 static int launch_inst(const DeltaParams & p, const BasePackDesc & pd, FusedArgs fa, unsigned grid, hipStream_t s) {
-    static const bool dbg = getenv("SDH_DEBUG") != nullptr;
-    if (!p.tall && p.B >= 2) {
-        fa.chunk = (p.n_out + p.B - 1) / p.B;
-        fa.ko = (fa.chunk + 255) / 256;
-        if ((p.B + 1) * fa.ko > FusedSlots<LOG_E>::N || fa.ko > (1 << LOG_E) / 2) {
-            if (dbg) fprintf(stderr, "[sdh] fused decode declined: B=%d ko=%d exceeds the gather slots\n", p.B, fa.ko);
-            return 1;
-        }
+    FusedKernelInfo & ki = kernel_info<BLOCK, STEPS, LOG_E>();
+    LibState & ls = lib();
+    if (ki.occ < 0) {
+        int occ = 0;
+        SDH_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, decode_fused_kernel<BLOCK, STEPS, LOG_E>, 256, 0));
+        ki.occ = occ;
     }
+    static const bool dbg = getenv("SDH_DEBUG") != nullptr;
+    if (ki.census_failed || (long long) grid > (long long) ki.occ * ls.num_cu) {   // not all resident: caller falls back
+        if (dbg) fprintf(stderr, "[sdh] fused decode declined: grid=%u occ=%d cus=%d census_failed=%d\n", grid, ki.occ, ls.num_cu, (int) ki.census_failed);
+        return 1;
+    }
+    if (grid > ki.census_ok_grid) {
+        // one-time residency census for this kernel at this grid size
+        if (!ls.census_ctr) {
+            SDH_HIP_CHECK(hipMalloc((void **) &ls.census_ctr, 16));
+        }
+        SDH_HIP_CHECK(hipMemsetAsync(ls.census_ctr, 0, 16, s));
+        FusedArgs ca = fa;
+        ca.census = 1;
+        ca.census_ctr = ls.census_ctr;
+        hipLaunchKernelGGL((decode_fused_kernel<BLOCK, STEPS, LOG_E>), dim3(grid), dim3(256), 0, s, p, pd, ca);
+        SDH_HIP_CHECK(hipGetLastError());
+        unsigned h[2] = {0, 0};
+        SDH_HIP_CHECK(hipMemcpyAsync(h, ls.census_ctr, sizeof(h), hipMemcpyDeviceToHost, s));
+        SDH_HIP_CHECK(hipStreamSynchronize(s));
+        if (dbg) fprintf(stderr, "[sdh] fused decode census: grid=%u arrived=%u failures=%u\n", grid, h[0], h[1]);
+        if (h[0] != grid || h[1] != 0) { ki.census_failed = true; return 1; }
+        ki.census_ok_grid = grid;
+    }
+    fa.census = 0;
+    fa.census_ctr = nullptr;
     hipLaunchKernelGGL((decode_fused_kernel<BLOCK, STEPS, LOG_E>), dim3(grid), dim3(256), 0, s, p, pd, fa);
     SDH_HIP_CHECK(hipGetLastError());
     return SDH_OK;
@@ -295,7 +258,6 @@ int launch_decode_fused(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s) 
     if (++w.epoch == 0) w.epoch = 1;
     FusedArgs fa{};
     fa.vg = reinterpret_cast<unsigned long long *>(w.handoff);
-    fa.ag = fa.vg + (size_t) w.B * (size_t) w.L;
     fa.epoch = w.epoch;
     switch (w.L) {
         case 1024: return is_block ? launch_steps<true, 2>(steps, p, w.pack, fa, grid, s) : launch_steps<false, 2>(steps, p, w.pack, fa, grid, s);

@@ -86,6 +86,7 @@ struct LibState {
     // staging for host-IO forwards
     float * hx = nullptr; size_t hx_bytes = 0;
     float * hy = nullptr; size_t hy_bytes = 0;
+    unsigned * census_ctr = nullptr;    // residency census of the fused decode kernel (sdh_decode.hip)
     // measurement hooks (sdh_profile_*): event pairs around the dominant kernel
     bool   prof_on = false;
     static constexpr int PROF_PAIRS = 4096;

@@ -64,45 +64,39 @@ int main() {
     CK(hipMalloc((void **) &dbg, DB));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(sdh_diag_buf), &dbg, sizeof(dbg)));
     std::vector<unsigned long long> h((size_t) GRID * 32);
-    double acc[16] = {0};
+    double a_base_pub = 0, a_base_done = 0, a_base_x = 0, a_red_mean = 0, a_red_max = 0, a_wait_mean = 0, a_end_max = 0, a_start_max = 0;
     int n = 0;
     for (int it = 0; it < ITERS; ++it) {
         const int p = it % NPAY;
         CK(hipMemsetAsync(dbg, 0, DB, s));
         if (sdh_forward(ws[p], xs[p], NIN, 1, y, NOUT, 0, s) != 0) { fprintf(stderr, "fwd: %s\n", sdh_last_error()); return 1; }
         CK(hipStreamSynchronize(s));
-        if (it < 64) continue;       // warm-up
+        if (it < 64) continue;       // census + warm-up
         CK(hipMemcpy(h.data(), dbg, DB, hipMemcpyDeviceToHost));
         unsigned long long t0 = ~0ull;
-        for (int g = B; g < GRID; ++g) { unsigned long long st = h[(size_t) g * 32 + 10]; if (st && st < t0) t0 = st; }
-        auto us = [&](int g, int k) { return (double) (long long) (h[(size_t) g * 32 + k] - t0) * 0.01; };
-        double bx = 0, bd = 0, bp = 0, bg = 0, be = 0, polls = 0, rs = 0, rm = 0, rx = 0;
+        for (int g = 0; g < GRID; ++g) { unsigned long long st = h[(size_t) g * 32 + (g < B ? 1 : 10)]; if (g >= B && st && st < t0) t0 = st; }
+        double base_pub = 0, base_done = 0, base_x = 0, red_mean = 0, red_max = 0, wait_mean = 0, end_max = 0, start_max = 0;
         for (int b = 0; b < B; ++b) {
-            bx = std::max(bx, us(b, 1)); bd = std::max(bd, us(b, 5)); bp = std::max(bp, us(b, 6));
-            bg = std::max(bg, us(b, 12)); be = std::max(be, us(b, 13)); polls = std::max(polls, (double) h[(size_t) b * 32 + 14]);
+            base_done = std::max(base_done, (double) (h[(size_t) b * 32 + 5] - t0) * 0.01);
+            base_pub = std::max(base_pub, (double) (h[(size_t) b * 32 + 6] - t0) * 0.01);
+            base_x = std::max(base_x, (double) (h[(size_t) b * 32 + 1] - t0) * 0.01);
         }
-        for (int g = B; g < GRID; ++g) { rs = std::max(rs, us(g, 10)); rm += us(g, 11); rx = std::max(rx, us(g, 11)); }
-        rm /= (GRID - B);
-        const double v[9] = {rs, bx, bd, bp, bg, be, polls, rm, rx};
-        for (int k = 0; k < 9; ++k) acc[k] += v[k];
+        for (int g = B; g < GRID; ++g) {
+            const double st = (double) (h[(size_t) g * 32 + 10] - t0) * 0.01, r = (double) (h[(size_t) g * 32 + 11] - t0) * 0.01,
+                         e = (double) (h[(size_t) g * 32 + 12] - t0) * 0.01;
+            red_mean += r; red_max = std::max(red_max, r); wait_mean += e - r; end_max = std::max(end_max, e); start_max = std::max(start_max, st);
+        }
+        red_mean /= (GRID - B); wait_mean /= (GRID - B);
+        a_base_pub += base_pub; a_base_done += base_done; a_base_x += base_x; a_red_mean += red_mean; a_red_max += red_max; a_wait_mean += wait_mean; a_end_max += end_max; a_start_max += start_max;
         ++n;
     }
     printf("fused decode kernel, cfg3 shape, us since the first residual workgroup started (mean over %d launches)\n", n);
-    printf("  last residual workgroup starts          %6.2f\n", acc[0] / n);
-    printf("  residual: row sums reduced, mean / max  %6.2f / %6.2f\n", acc[7] / n, acc[8] / n);
-    printf("  base: x landed (slowest block)          %6.2f\n", acc[1] / n);
-    printf("  base: second FWHT done (slowest)        %6.2f\n", acc[2] / n);
-    printf("  base: granules stored (slowest)         %6.2f\n", acc[3] / n);
-    printf("  base: gather complete (slowest)         %6.2f   polls (max over blocks) %.1f\n", acc[4] / n, acc[6] / n);
-    printf("  base: outputs stored (slowest)          %6.2f\n", acc[5] / n);
-#ifdef SDH_DIAG_TWICE
-    printf("  base block 0 phases, cold run then warm re-run (last launch):\n");
-    {
-        auto u0 = [&](int k) { return (double) (long long) (h[k] - h[16 + 1]) * 0.01; };
-        printf("    cold: loads landed %.2f  P1 %.2f  FWHT1 %.2f  D2/P2/back %.2f  FWHT2 %.2f (us after loads landed)\n", 0.0, u0(16 + 2), u0(16 + 3), u0(16 + 4), u0(16 + 5));
-        auto u1 = [&](int k) { return (double) (long long) (h[k] - h[7]) * 0.01; };
-        printf("    warm: loads landed %.2f  P1 %.2f  FWHT1 %.2f  D2/P2/back %.2f  FWHT2 %.2f  end %.2f (us after the re-run started)\n", u1(1), u1(2), u1(3), u1(4), u1(5), u1(8));
-    }
-#endif
+    printf("  last residual workgroup starts        %6.2f\n", a_start_max / n);
+    printf("  base: x landed (slowest block)        %6.2f\n", a_base_x / n);
+    printf("  base: second FWHT done (slowest)      %6.2f\n", a_base_done / n);
+    printf("  base: published, flag stored (slowest) %6.2f\n", a_base_pub / n);
+    printf("  residual: own sum reduced, mean / max %6.2f / %6.2f\n", a_red_mean / n, a_red_max / n);
+    printf("  residual: wait for the base, mean     %6.2f\n", a_wait_mean / n);
+    printf("  last residual wave has its base term  %6.2f\n", a_end_max / n);
     return 0;
 }
