@@ -53,6 +53,24 @@ struct BaseLay {
         const int s = shift(j);
         return (tid & ((1 << s) - 1)) | (r << s) | ((tid >> s) << (s + LOG_E));
     }
+    // LDS position of block element i. The 4-byte LDS accesses bank on (word % 32) per 32-lane half
+    // (cdna_hip_programming.md §2); in the middle layouts the lanes of a half differ in a few low
+    // index bits and a few bits above bit 5, which alias (E=16: 2-way, E=8 and E=4: 4-way). XOR-ing
+    // those upper bits into free bank bits makes every middle layout's accesses conflict-free. Only
+    // bits >= LOG_E change, so a thread's E consecutive elements stay consecutive (vector accesses).
+    // Build variant only (-DSDH_BASE_SWIZZLE): measured within +-1.5 % of the plain layout on every
+    // decode shape (the conflicted reads are ~10 % of the transform's LDS cycles, and the permutation
+    // gathers pay three more VALU ops per element), so the plain layout stays the default.
+#ifdef SDH_BASE_SWIZZLE
+    static __device__ __forceinline__ int phys(int i) {
+        if constexpr (LOG_E == 4) return i ^ (((i >> 8) & 3) << 4);
+        else if constexpr (LOG_E == 3) return i ^ (((i >> 6) & 3) << 3);
+        else if constexpr (LOG_E == 2) return i ^ (((i >> 5) & 3) << 2) ^ (((i >> 6) & 1) << 4);
+        else return i;
+    }
+#else
+    static __device__ __forceinline__ int phys(int i) { return i; }
+#endif
 };
 
 template <int LOG_E, int JJ>
@@ -83,10 +101,10 @@ __device__ __forceinline__ void base_lds_write(float * lds, const float (&y)[1 <
     if constexpr (Ly::shift(JJ) == 0 && E >= 4) {
 #pragma unroll
         for (int k = 0; k < E; k += 4)
-            *reinterpret_cast<float4 *>(lds + E * tid + k) = make_float4(y[k], y[k + 1], y[k + 2], y[k + 3]);
+            *reinterpret_cast<float4 *>(lds + Ly::phys(E * tid + k)) = make_float4(y[k], y[k + 1], y[k + 2], y[k + 3]);
     } else {
 #pragma unroll
-        for (int r = 0; r < E; ++r) lds[Ly::idx(JJ, tid, r)] = y[r];
+        for (int r = 0; r < E; ++r) lds[Ly::phys(Ly::idx(JJ, tid, r))] = y[r];
     }
 }
 
@@ -97,12 +115,12 @@ __device__ __forceinline__ void base_lds_read(float (&y)[1 << LOG_E], const floa
     if constexpr (Ly::shift(JJ) == 0 && E >= 4) {
 #pragma unroll
         for (int k = 0; k < E; k += 4) {
-            const float4 q = *reinterpret_cast<const float4 *>(lds + E * tid + k);
+            const float4 q = *reinterpret_cast<const float4 *>(lds + Ly::phys(E * tid + k));
             y[k] = q.x; y[k + 1] = q.y; y[k + 2] = q.z; y[k + 3] = q.w;
         }
     } else {
 #pragma unroll
-        for (int r = 0; r < E; ++r) y[r] = lds[Ly::idx(JJ, tid, r)];
+        for (int r = 0; r < E; ++r) y[r] = lds[Ly::phys(Ly::idx(JJ, tid, r))];
     }
 }
 
@@ -190,7 +208,7 @@ __device__ __forceinline__ void base_transform(const float * __restrict__ xt, in
         base_lds_write<LOG_E, 0>(lds0, y, tid);
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < E; ++r) y[r] = lds0[g1[r]];
+        for (int r = 0; r < E; ++r) y[r] = lds0[Ly::phys(g1[r])];
     }
     SDH_STAMP(2);
     // ---- H ----------------------------------------------------------------------------------------
@@ -217,7 +235,7 @@ __device__ __forceinline__ void base_transform(const float * __restrict__ xt, in
     __syncthreads();
     if (has_p2) {
 #pragma unroll
-        for (int r = 0; r < E; ++r) y[r] = back[base_param_i<P32>(pk + pd.off_p2, E * tid + r)];
+        for (int r = 0; r < E; ++r) y[r] = back[Ly::phys(base_param_i<P32>(pk + pd.off_p2, E * tid + r))];
     } else {
         base_lds_read<LOG_E, 0>(y, back, tid);
     }
