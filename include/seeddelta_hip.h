@@ -147,6 +147,46 @@ int sdh_forward(sdh_weight * w,
  * Waits for that forward to finish. */
 int64_t sdh_nonfinite_count(sdh_weight * w);
 
+/* ---- gated FFN block (the caller either side of the op) ----------------------
+ * sdh_ffn_forward — the three SeedDelta nodes and the gate activation that build_ffn emits for a
+ * parallel-gated FFN (src/llama-graph.cpp:811-953 with type_gate == LLM_FFN_PAR: ffn_up :826,
+ * ffn_gate :848, ggml_swiglu_split :870 / ggml_geglu_split :879, ffn_down :932), kept on the device:
+ *   y = down( act(gate(x)) * up(x) )
+ * gate/up: [n_embd -> n_ff] handles, down: [n_ff -> n_embd]; x: F32 [n_embd, n_tokens], y: F32
+ * [n_embd, n_tokens]. The two intermediate activations never leave HBM (with SDH_FWD_HOST_IO only x
+ * goes up and y comes down). At n_tokens == 1, when gate and up are tall base payloads of one shape,
+ * they run as ONE launch whose residual waves compute row o of both and write act(g)*u directly.
+ * act: SDH_ACT_SILU = ggml_silu_f32 (ggml/src/ggml-cpu/vec.h:1061), x/(1+expf(-x));
+ *      SDH_ACT_GELU = ggml's table form (vec.h:1430-1443): 0 below -10, g*u above 10, else the f16
+ *      table entry f16(gelu_f32(f16(g))) (ggml-cpu.c:3665), built on the host with the same libm.
+ * Non-finite outputs of each node are counted on that node's handle (sdh_nonfinite_count) and, with
+ * SDH_FWD_ZERO_NONFINITE, zeroed before the activation, as the reference's guard does per node. A
+ * caller that wants the dense repair (src/llama-seeddelta.cpp:294-361) re-runs the layer node by
+ * node when a count is non-zero. Other flags as sdh_forward (SDH_FWD_NO_FUSE also disables the
+ * gate|up launch). */
+#define SDH_ACT_SILU 0
+#define SDH_ACT_GELU 1
+int sdh_ffn_forward(sdh_weight * gate, sdh_weight * up, sdh_weight * down, int act,
+                    const float * x, int64_t ldx, int64_t n_tokens,
+                    float * y, int64_t ldy,
+                    int flags, void * stream);
+
+/* The first half of the block on its own: h[:, t] = act(gate(x[:, t])) * up(x[:, t]), h: F32
+ * [n_ff, n_tokens] with column stride ldh (what build_ffn hands to ffn_down, :926-932). */
+int sdh_ffn_gate_up(sdh_weight * gate, sdh_weight * up, int act,
+                    const float * x, int64_t ldx, int64_t n_tokens,
+                    float * h, int64_t ldh,
+                    int flags, void * stream);
+
+/* 1 if the most recent sdh_ffn_gate_up / sdh_ffn_forward evaluated gate and up as the single
+ * gate|up launch, 0 if node by node (no counterpart in the reference; tests and bench.py use it to
+ * state which path they measured). */
+int sdh_ffn_last_fused(void);
+
+/* The gate activation alone: y[i] = act(g[i]) * u[i] over n device elements (the op of
+ * ggml_swiglu_split / ggml_geglu_split on F32, ggml/src/ggml-cpu/vec.cpp:416, vec.h:1430). */
+int sdh_glu(int act, const float * g, const float * u, float * y, int64_t n, void * stream);
+
 /* Regenerate a tile of the dense base W0 (bit-exact integer XOR indexing into the per-block
  * table G_b = FWHT(d2_b)): out[(o-o0) + (i-i0)*(o1-o0)] = W0[o,i] for o in [o0,o1), i in [i0,i1).
  * `out` is a device or host pointer according to `flags` (SDH_FWD_HOST_IO). Used by the

@@ -50,6 +50,31 @@ static float half_to_float(uint16_t h) {
     return f;
 }
 
+// f32 -> f16 bits, round to nearest even, NaN -> 0x7E00 (the result of ggml's GGML_FP32_TO_FP16)
+static uint16_t float_to_half(float fl) {
+    uint32_t f;
+    memcpy(&f, &fl, 4);
+    const uint32_t f32infty = 255u << 23, f16max = (127u + 16u) << 23, denorm_magic_u = ((127u - 15u) + (23u - 10u) + 1u) << 23;
+    const uint32_t sign = f & 0x80000000u;
+    uint16_t o;
+    f ^= sign;
+    if (f >= f16max) o = (f > f32infty) ? 0x7E00 : 0x7C00;
+    else if (f < (113u << 23)) {                       // f16 subnormal: let the float adder do the rounding
+        float t, dm;
+        memcpy(&t, &f, 4); memcpy(&dm, &denorm_magic_u, 4);
+        t += dm;
+        uint32_t tb;
+        memcpy(&tb, &t, 4);
+        o = (uint16_t) (tb - denorm_magic_u);
+    } else {
+        const uint32_t mant_odd = (f >> 13) & 1u;
+        f += ((uint32_t) (15 - 127) << 23) + 0xFFFu;
+        f += mant_odd;
+        o = (uint16_t) (f >> 13);
+    }
+    return (uint16_t) (o | (sign >> 16));
+}
+
 static inline size_t type_size(int type) {
     switch (type) {
         case SDH_TYPE_F32: case SDH_TYPE_I32: return 4;
@@ -428,6 +453,18 @@ int64_t sdh_weight_payload_bytes(const sdh_weight * h) {
     return reinterpret_cast<const DeviceWeight *>(h)->payload_bytes;
 }
 
+// per-call non-finite counter: ring slot, the second half of the ring is re-zeroed while the
+// first half is in use (one small memset every NF_SLOTS/2 calls, none on the other calls)
+static int nf_slot(DeviceWeight * w, hipStream_t s, int * slot_out) {
+    constexpr int NS = DeviceWeight::NF_SLOTS;
+    const int slot = (int) (w->seq % NS);
+    if (w->seq > 0 && slot % (NS / 2) == 0) {
+        SDH_HIP_CHECK(hipMemsetAsync(w->nf_ring + slot, 0, (NS / 2) * sizeof(int), s));
+    }
+    *slot_out = slot;
+    return SDH_OK;
+}
+
 int sdh_forward(sdh_weight * h, const float * x, int64_t ldx, int64_t n_tokens,
                 float * y, int64_t ldy, int flags, void * stream) {
     if (!h || !x || !y) { set_error("null argument"); return SDH_ERR_INVALID; }
@@ -464,13 +501,8 @@ int sdh_forward(sdh_weight * h, const float * x, int64_t ldx, int64_t n_tokens,
         dx = L.hx; dy = L.hy; dldx = w->n_in; dldy = w->n_out;
     }
 
-    // per-call non-finite counter: ring slot, the second half of the ring is re-zeroed while the
-    // first half is in use (one small memset every NF_SLOTS/2 calls, none on the other calls)
-    constexpr int NS = DeviceWeight::NF_SLOTS;
-    const int slot = (int) (w->seq % NS);
-    if (w->seq > 0 && slot % (NS / 2) == 0) {
-        SDH_HIP_CHECK(hipMemsetAsync(w->nf_ring + slot, 0, (NS / 2) * sizeof(int), s));
-    }
+    int slot = 0;
+    { int rc = nf_slot(w, s, &slot); if (rc != SDH_OK) return rc; }
 
     // token chunking bounds the base-term workspace of the two-kernel path
     int64_t chunk = n_tokens;
@@ -550,6 +582,164 @@ int sdh_forward(sdh_weight * h, const float * x, int64_t ldx, int64_t n_tokens,
     if (host_io) {
         SDH_HIP_CHECK(hipMemcpy2DAsync(y, (size_t) ldy * 4, dy, (size_t) w->n_out * 4, (size_t) w->n_out * 4,
                                        (size_t) n_tokens, hipMemcpyDeviceToHost, s));
+        SDH_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    return SDH_OK;
+}
+
+// ---- gated FFN block ----------------------------------------------------------------------------------
+// f16 GELU table exactly as ggml builds it (ggml/src/ggml-cpu/ggml-cpu.c:3660-3667 with
+// ggml_gelu_f32, vec.h:976): entry i = f16( 0.5*x*(1 + tanhf(sqrt(2/pi)*x*(1 + 0.044715*x*x))) ),
+// x = f32(f16 bits i), evaluated on the host in float with this machine's libm, as the reference does.
+static int ensure_gelu_table(LibState & ls) {
+    if (ls.gelu_tab) return SDH_OK;
+    std::vector<uint16_t> tab(1 << 16);
+    const float GELU_COEF_A = 0.044715f, SQRT_2_OVER_PI = 0.79788456080286535587989211986876f;
+    for (uint32_t i = 0; i < (1u << 16); ++i) {
+        const float f = half_to_float((uint16_t) i);
+        const float v = 0.5f * f * (1.0f + tanhf(SQRT_2_OVER_PI * f * (1.0f + GELU_COEF_A * f * f)));
+        tab[i] = float_to_half(v);
+    }
+    SDH_HIP_CHECK(hipMalloc((void **) &ls.gelu_tab, tab.size() * 2));
+    SDH_HIP_CHECK(hipMemcpy(ls.gelu_tab, tab.data(), tab.size() * 2, hipMemcpyHostToDevice));
+    return SDH_OK;
+}
+
+int sdh_glu(int act, const float * g, const float * u, float * y, int64_t n, void * stream) {
+    LibState & ls = lib();
+    if (!ls.inited) { set_error("sdh_init not called"); return SDH_ERR_NO_DEVICE; }
+    if (!g || !u || !y || n < 0 || (act != SDH_ACT_SILU && act != SDH_ACT_GELU)) { set_error("sdh_glu: bad argument"); return SDH_ERR_INVALID; }
+    if (act == SDH_ACT_GELU) { int rc = ensure_gelu_table(ls); if (rc != SDH_OK) return rc; }
+    return launch_glu(act, ls.gelu_tab, g, u, y, n, stream ? (hipStream_t) stream : ls.stream);
+}
+
+// FFN workspace: sections of `floats` each, 16-byte aligned, grown on demand
+static int ffn_workspace(LibState & ls, hipStream_t s, const size_t * floats, int n, float ** out) {
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) total += (floats[i] + 3) & ~(size_t) 3;
+    const size_t need = total * sizeof(float) + 64;
+    if (ls.ffn_ws_bytes < need) {
+        if (ls.ffn_ws) { SDH_HIP_CHECK(hipStreamSynchronize(s)); SDH_HIP_CHECK(hipFree(ls.ffn_ws)); }
+        ls.ffn_ws = nullptr; ls.ffn_ws_bytes = 0;
+        SDH_HIP_CHECK(hipMalloc((void **) &ls.ffn_ws, need)); ls.ffn_ws_bytes = need;
+    }
+    float * p = ls.ffn_ws;
+    for (int i = 0; i < n; ++i) { out[i] = p; p += (floats[i] + 3) & ~(size_t) 3; }
+    return SDH_OK;
+}
+
+static int ffn_check(sdh_weight * hg, sdh_weight * hu, int act, const void * x, const void * y) {
+    if (!hg || !hu || !x || !y) { set_error("null argument"); return SDH_ERR_INVALID; }
+    if (!lib().inited) { set_error("sdh_init not called"); return SDH_ERR_NO_DEVICE; }
+    if (act != SDH_ACT_SILU && act != SDH_ACT_GELU) { set_error("unknown activation %d", act); return SDH_ERR_INVALID; }
+    const DeviceWeight * g = reinterpret_cast<const DeviceWeight *>(hg);
+    const DeviceWeight * u = reinterpret_cast<const DeviceWeight *>(hu);
+    if (u->n_in != g->n_in || u->n_out != g->n_out) {
+        set_error("gate %lldx%lld and up %lldx%lld differ in shape", (long long) g->n_out, (long long) g->n_in,
+                  (long long) u->n_out, (long long) u->n_in);
+        return SDH_ERR_INVALID;
+    }
+    return SDH_OK;
+}
+
+// h[t] = act(gate(x[t])) * up(x[t]) on device buffers; gbuf / ubuf: [T][n_ff] scratch for the node-by-node path
+static int ffn_gate_up(sdh_weight * hg, sdh_weight * hu, int act, const float * dx, int64_t dldx, int64_t T,
+                       float * hbuf, float * gbuf, float * ubuf, int flags, hipStream_t s) {
+    LibState & ls = lib();
+    DeviceWeight * g = reinterpret_cast<DeviceWeight *>(hg);
+    DeviceWeight * u = reinterpret_cast<DeviceWeight *>(hu);
+    const int64_t n_ff = g->n_out;
+    if (act == SDH_ACT_GELU) { int rc = ensure_gelu_table(ls); if (rc != SDH_OK) return rc; }
+    ls.ffn_last_fused = 0;
+    int rc = 1;
+    if (T == 1 && !(flags & (SDH_FWD_NO_FUSE | SDH_FWD_EXACT_ORDER))) {
+        int sg = 0, su = 0;
+        if ((rc = nf_slot(g, s, &sg)) != SDH_OK) return rc;
+        if ((rc = nf_slot(u, s, &su)) != SDH_OK) return rc;
+        rc = launch_decode_pair(*g, *u, act, ls.gelu_tab, dx, hbuf, g->nf_ring + sg, u->nf_ring + su,
+                                (flags & SDH_FWD_ZERO_NONFINITE) != 0, s);
+        if (rc < 0) return rc;
+        if (rc == SDH_OK) {
+            g->seq++; u->seq++;
+            g->last_stream = u->last_stream = s;
+            ls.span_forwards += 2;
+            ls.ffn_last_fused = 1;
+            return SDH_OK;
+        }
+    }
+    // node by node on the device
+    if ((rc = sdh_forward(hg, dx, dldx, T, gbuf, n_ff, flags, s)) != SDH_OK) return rc;
+    if ((rc = sdh_forward(hu, dx, dldx, T, ubuf, n_ff, flags, s)) != SDH_OK) return rc;
+    return launch_glu(act, ls.gelu_tab, gbuf, ubuf, hbuf, T * n_ff, s);
+}
+
+int sdh_ffn_last_fused(void) { return lib().ffn_last_fused; }
+
+int sdh_ffn_gate_up(sdh_weight * hg, sdh_weight * hu, int act, const float * x, int64_t ldx, int64_t n_tokens,
+                    float * h, int64_t ldh, int flags, void * stream) {
+    int rc = ffn_check(hg, hu, act, x, h);
+    if (rc != SDH_OK) return rc;
+    LibState & ls = lib();
+    DeviceWeight * g = reinterpret_cast<DeviceWeight *>(hg);
+    const int64_t n_embd = g->n_in, n_ff = g->n_out;
+    if (n_tokens < 0 || ldx < n_embd || ldh < n_ff) { set_error("bad shape"); return SDH_ERR_INVALID; }
+    if (n_tokens == 0) return SDH_OK;
+    hipStream_t s = stream ? (hipStream_t) stream : ls.stream;
+    const bool host_io = (flags & SDH_FWD_HOST_IO) != 0;
+    const size_t T = (size_t) n_tokens;
+    const bool dense_h = !host_io && ldh == n_ff;                // h can be written in place
+    const size_t sec[4] = {host_io ? T * (size_t) n_embd : 0, dense_h ? 0 : T * (size_t) n_ff, T * (size_t) n_ff, T * (size_t) n_ff};
+    float * ws[4];
+    if ((rc = ffn_workspace(ls, s, sec, 4, ws)) != SDH_OK) return rc;
+    const float * dx = x; int64_t dldx = ldx;
+    if (host_io) {
+        SDH_HIP_CHECK(hipMemcpy2DAsync(ws[0], (size_t) n_embd * 4, x, (size_t) ldx * 4, (size_t) n_embd * 4, T, hipMemcpyHostToDevice, s));
+        dx = ws[0]; dldx = n_embd;
+    }
+    float * hbuf = dense_h ? h : ws[1];
+    if ((rc = ffn_gate_up(hg, hu, act, dx, dldx, n_tokens, hbuf, ws[2], ws[3], flags & ~SDH_FWD_HOST_IO, s)) != SDH_OK) return rc;
+    if (!dense_h) {
+        SDH_HIP_CHECK(hipMemcpy2DAsync(h, (size_t) ldh * 4, hbuf, (size_t) n_ff * 4, (size_t) n_ff * 4, T,
+                                       host_io ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, s));
+    }
+    if (host_io) SDH_HIP_CHECK(hipStreamSynchronize(s));
+    return SDH_OK;
+}
+
+int sdh_ffn_forward(sdh_weight * hg, sdh_weight * hu, sdh_weight * hd, int act,
+                    const float * x, int64_t ldx, int64_t n_tokens, float * y, int64_t ldy,
+                    int flags, void * stream) {
+    int rc = ffn_check(hg, hu, act, x, y);
+    if (rc != SDH_OK) return rc;
+    if (!hd) { set_error("null argument"); return SDH_ERR_INVALID; }
+    LibState & ls = lib();
+    DeviceWeight * g = reinterpret_cast<DeviceWeight *>(hg);
+    DeviceWeight * d = reinterpret_cast<DeviceWeight *>(hd);
+    const int64_t n_embd = g->n_in, n_ff = g->n_out;
+    if (d->n_in != n_ff) {
+        set_error("down %lldx%lld does not take the gate/up output (%lld)", (long long) d->n_out, (long long) d->n_in, (long long) n_ff);
+        return SDH_ERR_INVALID;
+    }
+    if (n_tokens < 0 || ldx < n_embd || ldy < d->n_out) { set_error("bad shape"); return SDH_ERR_INVALID; }
+    if (n_tokens == 0) return SDH_OK;
+    hipStream_t s = stream ? (hipStream_t) stream : ls.stream;
+    const bool host_io = (flags & SDH_FWD_HOST_IO) != 0;
+    const size_t T = (size_t) n_tokens;
+    const size_t sec[5] = {host_io ? T * (size_t) n_embd : 0, host_io ? T * (size_t) d->n_out : 0,
+                           T * (size_t) n_ff, T * (size_t) n_ff, T * (size_t) n_ff};
+    float * ws[5];
+    if ((rc = ffn_workspace(ls, s, sec, 5, ws)) != SDH_OK) return rc;
+    const float * dx = x; int64_t dldx = ldx;
+    float * dy = y; int64_t dldy = ldy;
+    if (host_io) {
+        SDH_HIP_CHECK(hipMemcpy2DAsync(ws[0], (size_t) n_embd * 4, x, (size_t) ldx * 4, (size_t) n_embd * 4, T, hipMemcpyHostToDevice, s));
+        dx = ws[0]; dldx = n_embd; dy = ws[1]; dldy = d->n_out;
+    }
+    const int sub = flags & ~SDH_FWD_HOST_IO;
+    if ((rc = ffn_gate_up(hg, hu, act, dx, dldx, n_tokens, ws[2], ws[3], ws[4], sub, s)) != SDH_OK) return rc;
+    if ((rc = sdh_forward(hd, ws[2], n_ff, n_tokens, dy, dldy, sub, s)) != SDH_OK) return rc;
+    if (host_io) {
+        SDH_HIP_CHECK(hipMemcpy2DAsync(y, (size_t) ldy * 4, dy, (size_t) d->n_out * 4, (size_t) d->n_out * 4, T, hipMemcpyDeviceToHost, s));
         SDH_HIP_CHECK(hipStreamSynchronize(s));
     }
     return SDH_OK;

@@ -169,6 +169,101 @@ void decode_fused_kernel(const DeltaParams p, const BasePackDesc pd, const Fused
     }
 }
 
+// ---- gate | up in one launch (gated FFN block, T = 1) ----------------------------------------------
+// Both tensors are tall base payloads of one shape (same n_in, n_out, L, B, row shape). The first 2B
+// workgroups run the base blocks of the gate, then of the up tensor; a residual wave computes row o
+// of BOTH tensors (all loads of the two rows in flight together), its leader picks up the two base
+// terms and writes h[o] = act(gate[o]) * up[o]: the two node outputs are never materialised.
+struct PairArgs {
+    DeltaParams  p[2];            // [0] gate, [1] up; p[t].y is unused, p[t].nf is the node's counter
+    BasePackDesc pd[2];
+    unsigned long long * vg[2];
+    unsigned     epoch[2];
+    int          act;
+    const uint16_t * gelu_tab;
+    float *      h;
+    int          census;
+    unsigned *   census_ctr;
+};
+
+template <bool BLOCK, int STEPS, int LOG_E>
+__global__ __launch_bounds__(256)
+void decode_pair_kernel(const PairArgs a) {
+    constexpr int L = BaseLay<LOG_E>::L;
+    constexpr int E = BaseLay<LOG_E>::E;
+    __shared__ __align__(16) float lds[L];
+
+    if (a.census) {
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(&a.census_ctr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            bool all = false;
+            while (__builtin_amdgcn_s_memrealtime() - t0 < 2 * SPIN_TICKS) {
+                if (__hip_atomic_load(&a.census_ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= gridDim.x) { all = true; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (!all) __hip_atomic_fetch_add(&a.census_ctr[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+
+    const int B = a.p[0].B;
+    if ((int) blockIdx.x < 2 * B) {
+        const bool second = (int) blockIdx.x >= B;
+        const int b = (int) blockIdx.x - (second ? B : 0);
+        const int tid = threadIdx.x;
+        __builtin_amdgcn_s_setprio(SDH_BASE_PRIO);
+        float y[E];
+        const BasePackDesc & pd = second ? a.pd[1] : a.pd[0];
+        base_transform<LOG_E, false, true>(a.p[0].x, a.p[0].n_in, 0, a.p[0].x_vec_ok != 0, pd, b, lds, tid, y);
+        unsigned long long * out = (second ? a.vg[1] : a.vg[0]) + (size_t) b * L;
+        const unsigned long long tag = (unsigned long long) (second ? a.epoch[1] : a.epoch[0]) << 32;
+#pragma unroll
+        for (int r = 0; r < E; ++r)
+            __hip_atomic_store(out + BaseLay<LOG_E>::idx(BaseLay<LOG_E>::J - 1, tid, r),
+                               tag | (unsigned long long) __float_as_uint(y[r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int G = a.p[0].G;
+    const int l = lane & (G - 1);
+    const int o = (((int) blockIdx.x - 2 * B) * 4 + wave) * (64 / G) + (lane / G);
+    const bool row_ok = o < a.p[0].n_out;
+    const int orow = row_ok ? o : 0;
+    const bool leader = row_ok && l == 0;
+    float sg = 1.0f, su = 1.0f;
+    if (leader && a.p[0].rs) sg = a.p[0].rs[o];
+    if (leader && a.p[1].rs) su = a.p[1].rs[o];
+
+    float accg = delta_row_partial<uint16_t, uint16_t, BLOCK, STEPS>(a.p[0], a.p[0].x, orow, row_ok, l, G);
+    float accu = delta_row_partial<uint16_t, uint16_t, BLOCK, STEPS>(a.p[1], a.p[0].x, orow, row_ok, l, G);
+    accg = group_reduce(accg, G);
+    accu = group_reduce(accu, G);
+
+    if (leader) {
+        // tall: the base term of row o is granule o of its tensor (block o / L, element o % L)
+        bool ok = false;
+        float vg = 0.0f, vu = 0.0f;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        do {
+            const unsigned long long g0 = granule_load(a.vg[0], o);
+            const unsigned long long g1 = granule_load(a.vg[1], o);
+            ok = ((unsigned) (g0 >> 32) == a.epoch[0]) & ((unsigned) (g1 >> 32) == a.epoch[1]);
+            vg = __uint_as_float((unsigned) g0);
+            vu = __uint_as_float((unsigned) g1);
+            if (ok) break;
+            __builtin_amdgcn_s_sleep(SDH_POLL_SLEEP);
+        } while (__builtin_amdgcn_s_memrealtime() - t0 < SPIN_TICKS);
+        float yg = vg + accg, yu = vu + accu;
+        if (!ok) yg = yu = __uint_as_float(0x7FC00000u);
+        yg = finish_output(a.p[0], yg, sg);
+        yu = finish_output(a.p[1], yu, su);
+        a.h[o] = glu_value(a.act, yg, yu, a.gelu_tab);
+    }
+}
+
 // ---- host side ----------------------------------------------------------------------------------
 struct FusedKernelInfo {
     int occ = -1;                 // resident workgroups per CU (occupancy API)
@@ -264,6 +359,118 @@ int launch_decode_fused(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s) 
         case 2048: return is_block ? launch_steps<true, 3>(steps, p, w.pack, fa, grid, s) : launch_steps<false, 3>(steps, p, w.pack, fa, grid, s);
         default:   return is_block ? launch_steps<true, 4>(steps, p, w.pack, fa, grid, s) : launch_steps<false, 4>(steps, p, w.pack, fa, grid, s);
     }
+}
+
+
+// ---- gate | up pair ---------------------------------------------------------------------------------
+template <bool BLOCK, int STEPS, int LOG_E>
+static int launch_pair_inst(PairArgs & a, unsigned grid, hipStream_t s) {
+    static FusedKernelInfo ki;
+    LibState & ls = lib();
+    if (ki.occ < 0) {
+        int occ = 0;
+        SDH_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, decode_pair_kernel<BLOCK, STEPS, LOG_E>, 256, 0));
+        ki.occ = occ;
+    }
+    static const bool dbg = getenv("SDH_DEBUG") != nullptr;
+    if (ki.census_failed || (long long) grid > (long long) ki.occ * ls.num_cu) {
+        if (dbg) fprintf(stderr, "[sdh] gate|up launch declined: grid=%u occ=%d cus=%d census_failed=%d\n", grid, ki.occ, ls.num_cu, (int) ki.census_failed);
+        return 1;
+    }
+    if (grid > ki.census_ok_grid) {
+        if (!ls.census_ctr) SDH_HIP_CHECK(hipMalloc((void **) &ls.census_ctr, 16));
+        SDH_HIP_CHECK(hipMemsetAsync(ls.census_ctr, 0, 16, s));
+        PairArgs ca = a;
+        ca.census = 1;
+        ca.census_ctr = ls.census_ctr;
+        hipLaunchKernelGGL((decode_pair_kernel<BLOCK, STEPS, LOG_E>), dim3(grid), dim3(256), 0, s, ca);
+        SDH_HIP_CHECK(hipGetLastError());
+        unsigned h[2] = {0, 0};
+        SDH_HIP_CHECK(hipMemcpyAsync(h, ls.census_ctr, sizeof(h), hipMemcpyDeviceToHost, s));
+        SDH_HIP_CHECK(hipStreamSynchronize(s));
+        if (dbg) fprintf(stderr, "[sdh] gate|up census: grid=%u arrived=%u failures=%u\n", grid, h[0], h[1]);
+        if (h[0] != grid || h[1] != 0) { ki.census_failed = true; return 1; }
+        ki.census_ok_grid = grid;
+    }
+    a.census = 0;
+    a.census_ctr = nullptr;
+    hipLaunchKernelGGL((decode_pair_kernel<BLOCK, STEPS, LOG_E>), dim3(grid), dim3(256), 0, s, a);
+    SDH_HIP_CHECK(hipGetLastError());
+    return SDH_OK;
+}
+
+template <bool BLOCK, int LOG_E>
+static int launch_pair_steps(int steps, PairArgs & a, unsigned grid, hipStream_t s) {
+    switch (steps) {                                   // two rows per wave: rows of up to 2 steps per lane
+        case 1: return launch_pair_inst<BLOCK, 1, LOG_E>(a, grid, s);
+        case 2: return launch_pair_inst<BLOCK, 2, LOG_E>(a, grid, s);
+        default: return 1;
+    }
+}
+
+int launch_decode_pair(DeviceWeight & g, DeviceWeight & u, int act, const uint16_t * gelu_tab,
+                       const float * x, float * h, int * nf_g, int * nf_u, bool zero_nonfinite, hipStream_t s) {
+    static const bool dbg = getenv("SDH_DEBUG") != nullptr;
+#define SDH_DECLINE(why) do { if (dbg) fprintf(stderr, "[sdh] gate|up launch declined: %s\n", why); return 1; } while (0)
+    if (g.kind != u.kind || (g.kind != SDH_OP_BASE_BLOCK && g.kind != SDH_OP_BASE_COO)) SDH_DECLINE("not two base payloads of one kind");
+    if (!g.tall || !u.tall) SDH_DECLINE("not tall");
+    if (g.n_in != u.n_in || g.n_out != u.n_out || g.L != u.L || g.B != u.B) SDH_DECLINE("shapes differ");
+    if (g.idx_type != SDH_TYPE_I16 || g.val_type != SDH_TYPE_F16 || u.idx_type != SDH_TYPE_I16 || u.val_type != SDH_TYPE_F16) SDH_DECLINE("payload is not I16/F16");
+    if (g.pack.wide32 || u.pack.wide32 || !g.handoff || !u.handoff) SDH_DECLINE("base parameters are 32-bit");
+    if (!(g.L == 1024 || g.L == 2048 || g.L == 4096)) SDH_DECLINE("L not in {1024,2048,4096}");
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) SDH_DECLINE("stream is capturing");
+
+    const bool is_block = (g.kind == SDH_OP_BASE_BLOCK);
+    DeltaLaunch dl{};
+    dl.x = x; dl.ldx = g.n_in; dl.T = 1; dl.y = h; dl.ldy = g.n_out; dl.v = nullptr;
+    dl.zero_nonfinite = zero_nonfinite; dl.exact_order = false;
+    PairArgs a{};
+    dl.nf_counter = nf_g; a.p[0] = make_delta_params(g, dl);
+    dl.nf_counter = nf_u; a.p[1] = make_delta_params(u, dl);
+    int G0 = 1, G1 = 1, st0 = 0, st1 = 0;
+    if (!delta_vector_shape(a.p[0], is_block, &G0, &st0) || !delta_vector_shape(a.p[1], is_block, &G1, &st1)) SDH_DECLINE("row shape needs the scalar or looped kernel");
+    if (G0 != G1 || st0 != st1 || st0 < 1 || st0 > 2) SDH_DECLINE("row shapes differ or are too long for two rows per wave");
+#undef SDH_DECLINE
+    a.p[0].G = a.p[1].G = G0;
+    a.pd[0] = g.pack; a.pd[1] = u.pack;
+    const int rows_per_block = 4 * (64 / G0);
+    const unsigned grid = 2u * (unsigned) g.B + (unsigned) ((a.p[0].n_out + rows_per_block - 1) / rows_per_block);
+    if (++g.epoch == 0) g.epoch = 1;
+    if (++u.epoch == 0) u.epoch = 1;
+    a.vg[0] = reinterpret_cast<unsigned long long *>(g.handoff);
+    a.vg[1] = reinterpret_cast<unsigned long long *>(u.handoff);
+    a.epoch[0] = g.epoch; a.epoch[1] = u.epoch;
+    a.act = act; a.gelu_tab = gelu_tab; a.h = h;
+    switch (g.L) {
+        case 1024: return is_block ? launch_pair_steps<true, 2>(st0, a, grid, s) : launch_pair_steps<false, 2>(st0, a, grid, s);
+        case 2048: return is_block ? launch_pair_steps<true, 3>(st0, a, grid, s) : launch_pair_steps<false, 3>(st0, a, grid, s);
+        default:   return is_block ? launch_pair_steps<true, 4>(st0, a, grid, s) : launch_pair_steps<false, 4>(st0, a, grid, s);
+    }
+}
+
+// ---- gate activation over a buffer (many-token path of the FFN block) --------------------------------
+__global__ __launch_bounds__(256)
+void glu_kernel(int act, const uint16_t * __restrict__ tab, const float * __restrict__ g, const float * __restrict__ u,
+                float * __restrict__ y, int64_t n) {
+    const int64_t i0 = ((int64_t) blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 + 4 <= n) {
+        const float4 a = *reinterpret_cast<const float4 *>(g + i0), b = *reinterpret_cast<const float4 *>(u + i0);
+        *reinterpret_cast<float4 *>(y + i0) = make_float4(glu_value(act, a.x, b.x, tab), glu_value(act, a.y, b.y, tab),
+                                                          glu_value(act, a.z, b.z, tab), glu_value(act, a.w, b.w, tab));
+    } else {
+        for (int64_t i = i0; i < n; ++i) y[i] = glu_value(act, g[i], u[i], tab);
+    }
+}
+
+int launch_glu(int act, const uint16_t * gelu_tab, const float * g, const float * u, float * y, int64_t n, hipStream_t s) {
+    if (n <= 0) return SDH_OK;
+    const bool vec = ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+    if (!vec) { set_error("sdh_glu: buffers must be 16-byte aligned"); return SDH_ERR_INVALID; }
+    const unsigned grid = (unsigned) ((n + 1023) / 1024);
+    hipLaunchKernelGGL(glu_kernel, dim3(grid), dim3(256), 0, s, act, gelu_tab, g, u, y, n);
+    SDH_HIP_CHECK(hipGetLastError());
+    return SDH_OK;
 }
 
 } // namespace sdh

@@ -172,14 +172,28 @@ __device__ __forceinline__ float group_reduce(float acc, int G) {
     return acc;
 }
 
-// scale (only if != 1, :645), count / optionally zero non-finite outputs (:363-392), store
-__device__ __forceinline__ void store_output(const DeltaParams & p, int o, int64_t t, float y, float scale) {
+// scale (only if != 1, :645), count / optionally zero non-finite outputs (:363-392)
+__device__ __forceinline__ float finish_output(const DeltaParams & p, float y, float scale) {
     float out = (scale != 1.0f) ? (y * scale) : y;
     if (!isfinite(out)) {
         atomicAdd(p.nf, 1);
         if (p.zero_nf) out = 0.0f;
     }
-    p.y[o + t * p.ldy] = out;
+    return out;
+}
+__device__ __forceinline__ void store_output(const DeltaParams & p, int o, int64_t t, float y, float scale) {
+    p.y[o + t * p.ldy] = finish_output(p, y, scale);
+}
+
+// act(g) * u: the gate activation of a parallel-gated FFN as ggml's CPU ops compute it on F32
+// (ggml_vec_swiglu_f32, ggml/src/ggml-cpu/vec.cpp:416 with ggml_silu_f32, vec.h:1061;
+// ggml_vec_geglu_f32, vec.h:1430-1443: thresholds at +-10, f16 table in between).
+// act: 0 = SiLU, 1 = GELU; tab: the 65536-entry f16 GELU table (GELU only).
+__device__ __forceinline__ float glu_value(int act, float g, float u, const uint16_t * __restrict__ tab) {
+    if (act == 0) return (g / (1.0f + expf(-g))) * u;
+    if (g <= -10.0f) return 0.0f;
+    if (g >= 10.0f) return g * u;
+    return h2f(tab[__half_as_ushort(__float2half_rn(g))]) * u;
 }
 
 } // namespace sdh

@@ -87,6 +87,10 @@ struct LibState {
     float * hx = nullptr; size_t hx_bytes = 0;
     float * hy = nullptr; size_t hy_bytes = 0;
     unsigned * census_ctr = nullptr;    // residency census of the fused decode kernel (sdh_decode.hip)
+    // gated FFN block (sdh_ffn.hip): f16 GELU table as ggml builds it, intermediate activations
+    uint16_t * gelu_tab = nullptr;      // [65536] device
+    float * ffn_ws = nullptr; size_t ffn_ws_bytes = 0;
+    int ffn_last_fused = 0;             // the last gate/up evaluation ran as the single gate|up launch
     // measurement hooks (sdh_profile_*): event pairs around the dominant kernel
     bool   prof_on = false;
     static constexpr int PROF_PAIRS = 4096;
@@ -129,6 +133,11 @@ int launch_delta_spmm(const DeviceWeight & w, const DeltaLaunch & a, hipStream_t
 // Batch-1 decode with a base as ONE launch (sdh_decode.hip). Returns SDH_OK if launched, 1 if the
 // payload / call does not qualify (caller runs base + delta kernels instead), <0 on error.
 int launch_decode_fused(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s);
+// T = 1, gate and up tall base payloads of one shape: h[o] = act(gate(x)[o]) * up(x)[o] in one launch.
+// Returns SDH_OK, 1 if the pair does not qualify, <0 on error. nf_g / nf_u: the two nodes' counters.
+int launch_decode_pair(DeviceWeight & g, DeviceWeight & u, int act, const uint16_t * gelu_tab,
+                       const float * x, float * h, int * nf_g, int * nf_u, bool zero_nonfinite, hipStream_t s);
+int launch_glu(int act, const uint16_t * gelu_tab, const float * g, const float * u, float * y, int64_t n, hipStream_t s);
 
 int launch_w0_tile(const DeviceWeight & w, int64_t o0, int64_t o1, int64_t i0, int64_t i1,
                    float * out_dev, hipStream_t s);

@@ -32,7 +32,7 @@ FWD_DEVICE_IO, FWD_HOST_IO, FWD_ZERO_NONFINITE, FWD_EXACT_ORDER, FWD_W0_MFMA, FW
 ABI_SYMBOLS = [
     "sdh_init", "sdh_abi_version", "sdh_last_error", "sdh_device_synchronize",
     "sdh_weight_create", "sdh_weight_destroy", "sdh_weight_op_kind", "sdh_weight_payload_bytes",
-    "sdh_forward", "sdh_nonfinite_count", "sdh_w0_tile",
+    "sdh_forward", "sdh_nonfinite_count", "sdh_w0_tile", "sdh_ffn_forward", "sdh_ffn_gate_up", "sdh_ffn_last_fused", "sdh_glu",
     "sdh_profile_enable", "sdh_profile_read", "sdh_profile_span_begin", "sdh_profile_span_end",
     "sdh_dense_create", "sdh_dense_destroy", "sdh_dense_bytes",
     "sdh_scan_create", "sdh_scan_destroy", "sdh_scan_reseed", "sdh_scan_tensor", "sdh_scan_skip", "sdh_scan_fetch", "sdh_imatrix_scale",
@@ -118,6 +118,11 @@ def load_library(path: str = LIB_PATH):
     lib.sdh_weight_payload_bytes.restype = C.c_int64
     lib.sdh_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
                                 C.c_int, C.c_void_p]
+    lib.sdh_ffn_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64,
+                                    C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+    lib.sdh_ffn_gate_up.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64,
+                                    C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+    lib.sdh_glu.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.sdh_nonfinite_count.argtypes = [C.c_void_p]
     lib.sdh_nonfinite_count.restype = C.c_int64
     lib.sdh_w0_tile.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
@@ -247,6 +252,53 @@ class SeedDeltaWeight:
         rc = load_library().sdh_w0_tile(self._h, o0, o1, i0, i1, out.ctypes.data, FWD_HOST_IO, None)
         _check(rc, "sdh_w0_tile")
         return np.ascontiguousarray(out.T)
+
+
+# ---- gated FFN block: build_ffn's three SeedDelta nodes + gate activation (src/llama-graph.cpp:811-953)
+ACT_SILU, ACT_GELU = 0, 1          # LLM_FFN_SILU / LLM_FFN_GELU with LLM_FFN_PAR gating
+
+
+def ffn_forward_host(gate: SeedDeltaWeight, up: SeedDeltaWeight, down: SeedDeltaWeight, x: np.ndarray,
+                     act: int = ACT_SILU, flags: int = 0) -> np.ndarray:
+    """y = down( act(gate(x)) * up(x) ) with x (T, n_embd) and y (T, n_embd) float32 on the host; the
+    intermediate activations stay on the device."""
+    assert x.dtype == np.float32 and x.ndim == 2 and x.shape[1] == gate.n_in
+    assert x.strides[1] == 4 and x.strides[0] % 4 == 0
+    T = x.shape[0]
+    y = np.empty((T, down.n_out), dtype=np.float32)
+    rc = load_library().sdh_ffn_forward(gate._h, up._h, down._h, act, x.ctypes.data, x.strides[0] // 4, T,
+                                        y.ctypes.data, down.n_out, flags | FWD_HOST_IO, None)
+    _check(rc, "sdh_ffn_forward")
+    return y
+
+
+def ffn_gate_up_host(gate: SeedDeltaWeight, up: SeedDeltaWeight, x: np.ndarray, act: int = ACT_SILU,
+                     flags: int = 0) -> np.ndarray:
+    """h = act(gate(x)) * up(x): x (T, n_embd) -> h (T, n_ff), float32 on the host."""
+    assert x.dtype == np.float32 and x.ndim == 2 and x.shape[1] == gate.n_in
+    assert x.strides[1] == 4 and x.strides[0] % 4 == 0
+    T = x.shape[0]
+    h = np.empty((T, gate.n_out), dtype=np.float32)
+    rc = load_library().sdh_ffn_gate_up(gate._h, up._h, act, x.ctypes.data, x.strides[0] // 4, T,
+                                        h.ctypes.data, gate.n_out, flags | FWD_HOST_IO, None)
+    _check(rc, "sdh_ffn_gate_up")
+    return h
+
+
+def ffn_forward_device(gate: SeedDeltaWeight, up: SeedDeltaWeight, down: SeedDeltaWeight, act: int,
+                       x_ptr: int, ldx: int, T: int, y_ptr: int, ldy: int, flags: int = 0, stream: int = 0):
+    rc = load_library().sdh_ffn_forward(gate._h, up._h, down._h, act, x_ptr, ldx, T, y_ptr, ldy,
+                                        flags & ~FWD_HOST_IO, C.c_void_p(stream) if stream else None)
+    _check(rc, "sdh_ffn_forward")
+
+
+def ffn_last_fused() -> bool:
+    return bool(load_library().sdh_ffn_last_fused())
+
+
+def glu_device(act: int, g_ptr: int, u_ptr: int, y_ptr: int, n: int, stream: int = 0):
+    """y = act(g) * u over n device floats (ggml_swiglu_split / ggml_geglu_split)."""
+    _check(load_library().sdh_glu(act, g_ptr, u_ptr, y_ptr, n, C.c_void_p(stream) if stream else None), "sdh_glu")
 
 
 # ---- the reference's four constructors, same argument order (src/llama-seeddelta.h:41-84) ----

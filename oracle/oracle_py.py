@@ -98,6 +98,8 @@ def oracle_lib():
                                      C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64]
         _lib.sdo_w0_elem.restype = C.c_float
         _lib.sdo_dequant_row_q8_0.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        _lib.sdo_gelu_table.argtypes = [C.c_void_p]
+        _lib.sdo_glu.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     return _lib
 
 
@@ -115,7 +117,16 @@ def ref_lib():
         _ref.sdref_fp16_to_fp32.restype = C.c_float
         _ref.sdref_fp32_to_fp16.argtypes = [C.c_float]
         _ref.sdref_fp32_to_fp16.restype = C.c_uint16
+        _bind_ffn(_ref)
     return _ref
+
+
+def _bind_ffn(lib):
+    lib.sdref_glu.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.sdref_glu.restype = C.c_int
+    lib.sdref_ffn.argtypes = [C.POINTER(C.c_int), C.POINTER(SdoOpArgs), C.POINTER(SdoOpArgs), C.POINTER(SdoOpArgs),
+                              C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.sdref_ffn.restype = C.c_int
 
 
 _shim = None
@@ -135,6 +146,7 @@ def shim_lib():
         _shim.sdref_run.restype = C.c_int
         _shim.llama_seeddelta_hip_release_all.restype = None
         _shim.llama_seeddelta_hip_nonfinite_total.restype = C.c_int64
+        _bind_ffn(_shim)
     return _shim
 
 
@@ -216,3 +228,65 @@ def w0_tile(payload, o0: int, o1: int, i0: int, i1: int) -> np.ndarray:
     b, p, q = np.broadcast_arrays(b, p, q)
     g = G[b, (p ^ inv[b, q]) & (L - 1)]
     return ((d3[b, p] * g).astype(np.float32) * d1[b, q]).astype(np.float32)
+
+
+# ---- gated FFN block: the gate activation between the nodes and the three-node composition ----------
+ACT_SILU, ACT_GELU = 0, 1
+_gelu_table = None
+
+
+def gelu_table() -> np.ndarray:
+    """The 65536-entry f16 GELU table (oracle restatement of ggml-cpu.c:3657-3667)."""
+    global _gelu_table
+    if _gelu_table is None:
+        t = np.empty(1 << 16, dtype=np.uint16)
+        oracle_lib().sdo_gelu_table(t.ctypes.data)
+        _gelu_table = t
+    return _gelu_table
+
+
+def glu(act: int, g: np.ndarray, u: np.ndarray, use_ref: bool = False) -> np.ndarray:
+    """y = act(g) * u elementwise on float32 (ggml_swiglu_split / ggml_geglu_split). use_ref: the
+    reference's own op computed by its CPU backend."""
+    g = np.ascontiguousarray(g, dtype=np.float32)
+    u = np.ascontiguousarray(u, dtype=np.float32)
+    assert g.shape == u.shape
+    y = np.empty_like(g)
+    if use_ref:
+        rc = ref_lib().sdref_glu(act, g.size, g.ctypes.data, u.ctypes.data, y.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"sdref_glu failed: {rc}")
+    else:
+        oracle_lib().sdo_glu(act, g.size, g.ctypes.data, u.ctypes.data, y.ctypes.data, gelu_table().ctypes.data)
+    return y
+
+
+def ffn_forward(gate, up, down, x: np.ndarray, act: int, nth: int = 1):
+    """Oracle: down( act(gate(x)) * up(x) ) node by node on the CPU -> (h, y)."""
+    g = forward(gate, x, nth=nth)
+    u = forward(up, x, nth=nth)
+    h = glu(act, g, u)
+    return h, forward(down, h, nth=nth)
+
+
+def ffn_forward_graph(gate, up, down, x: np.ndarray, act: int, nth: int = 1, shim: bool = False):
+    """The same block as ONE ggml graph computed by the reference's CPU backend: the reference's
+    constructors for the three nodes (its own op TU, or with shim=True the HIP drop-in TU) and its
+    ggml_swiglu_split / ggml_geglu_split between them (src/llama-graph.cpp:811-953) -> (h, y)."""
+    T = x.shape[0]
+    h = np.empty((T, gate.n_out), dtype=np.float32)
+    y = np.empty((T, down.n_out), dtype=np.float32)
+    dummy_g = np.empty((T, gate.n_out), dtype=np.float32)     # only their shapes are read
+    ga = _args(gate, x, dummy_g)
+    ua = _args(up, x, dummy_g)
+    da = _args(down, h, y)
+    kinds = (C.c_int * 3)(gate.kind, up.kind, down.kind)
+    lib = shim_lib() if shim else ref_lib()
+    try:
+        rc = lib.sdref_ffn(kinds, C.byref(ga), C.byref(ua), C.byref(da), act, nth, h.ctypes.data, y.ctypes.data)
+    finally:
+        if shim:
+            lib.llama_seeddelta_hip_release_all()
+    if rc != 0:
+        raise RuntimeError(f"sdref_ffn failed: {rc}")
+    return h, y

@@ -455,3 +455,27 @@ float sdo_w0_elem(const sdo_tensor * d1, const sdo_tensor * d3, const float * G,
     const float t  = s3 * g;
     return t * s1;
 }
+
+/* ---- gate activation (see sd_oracle.h) ------------------------------------------------------- */
+void sdo_gelu_table(uint16_t * table) {
+    static const float GELU_COEF_A = 0.044715f;
+    static const float SQRT_2_OVER_PI = 0.79788456080286535587989211986876f;
+    for (uint32_t i = 0; i < (1u << 16); ++i) {
+        const float x = sdo_fp16_to_fp32((uint16_t) i);
+        table[i] = sdo_fp32_to_fp16(0.5f*x*(1.0f + tanhf(SQRT_2_OVER_PI*x*(1.0f + GELU_COEF_A*x*x))));
+    }
+}
+
+void sdo_glu(int act, int64_t n, const float * g, const float * u, float * y, const uint16_t * gelu_table) {
+    for (int64_t i = 0; i < n; ++i) {
+        if (act == 0) {
+            y[i] = (g[i] / (1.0f + expf(-g[i]))) * u[i];
+        } else if (g[i] <= -10.0f) {
+            y[i] = 0.0f;
+        } else if (g[i] >= 10.0f) {
+            y[i] = g[i] * u[i];
+        } else {
+            y[i] = sdo_fp16_to_fp32(gelu_table[sdo_fp32_to_fp16(g[i])]) * u[i];
+        }
+    }
+}

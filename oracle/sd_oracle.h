@@ -55,6 +55,16 @@ typedef struct sdo_op_args {
 float    sdo_fp16_to_fp32(uint16_t h);
 uint16_t sdo_fp32_to_fp16(float f);
 
+/* Gate activation of a parallel-gated FFN, y[i] = act(g[i]) * u[i], as build_ffn emits it between the
+ * SeedDelta nodes (src/llama-graph.cpp:867-881: ggml_swiglu_split / ggml_geglu_split).
+ *   act 0: ggml_vec_swiglu_f32 scalar form (ggml/src/ggml-cpu/vec.cpp:447-449) with ggml_silu_f32
+ *          (vec.h:1061): g/(1+expf(-g)) * u. (The reference's x86 SIMD bodies use a polynomial expf:
+ *          equal to this within ~2e-7 relative; tests carry that tolerance.)
+ *   act 1: ggml_vec_geglu_f32, GGML_GELU_FP16 form (vec.h:1430-1443) over the f16 table of
+ *          ggml-cpu.c:3657-3667. sdo_gelu_table fills the 65536-entry table. */
+void sdo_gelu_table(uint16_t * table);
+void sdo_glu(int act, int64_t n, const float * g, const float * u, float * y, const uint16_t * gelu_table);
+
 /* hadamard_transform, scalar path (src/llama-seeddelta.cpp:484-493) */
 void sdo_hadamard(float * data, int64_t n);
 

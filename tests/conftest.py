@@ -23,12 +23,31 @@ def pytest_configure(config):
 
 def golden_names():
     """forward-op fixtures (reference TU outputs)"""
-    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and not f.startswith(("scan_", "gguf_")))
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and not f.startswith(("scan_", "gguf_", "ffn_")))
 
 
 def scan_golden_names():
     """builder-evaluation fixtures (reference sd_eval / sd_ffn_proxy / sd_cost outputs)"""
     return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f.startswith("scan_"))
+
+
+def ffn_golden_names():
+    """gated FFN block fixtures (the reference's ggml graph: three SeedDelta nodes + swiglu/geglu)"""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f.startswith("ffn_"))
+
+
+def load_ffn_golden(name):
+    """-> (gate, up, down payloads, x, act, h_ref, y_ref)"""
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    n_embd, n_ff = int(z["n_embd"]), int(z["n_ff"])
+    ps = []
+    for pre, (ni, no) in (("gate_", (n_embd, n_ff)), ("up_", (n_embd, n_ff)), ("down_", (n_ff, n_embd))):
+        p = Payload(n_in=ni, n_out=no)
+        for f in PAYLOAD_FIELDS:
+            if pre + f in z.files:
+                setattr(p, f, np.ascontiguousarray(z[pre + f]))
+        ps.append(p)
+    return ps[0], ps[1], ps[2], np.ascontiguousarray(z["x"]), int(z["act"]), z["h"], z["y"]
 
 
 def load_scan_golden(name):

@@ -1,0 +1,203 @@
+"""GPU parity tests of the gated FFN block (sdh_ffn_gate_up / sdh_ffn_forward / sdh_glu), called through
+the C ABI, against the reference's ggml-graph fixtures (tests/golden/ffn_*.npz) and the CPU oracle.
+
+Bars:
+  * verification mode (SDH_FWD_EXACT_ORDER), GELU form: h and y bit-identical to the reference graph
+    (nodes bit-exact, the f16 table is built with the host's tanhf exactly as ggml builds it);
+  * verification mode, SiLU form: h within 1e-6 relative (device expf / division vs the reference's
+    polynomial expf), y within that error pushed through |W_down|;
+  * fast path (incl. the single gate|up launch at T = 1): node outputs differ from the CPU's by the
+    summation-order tolerance of test_gpu_forward (2e-5 * sum|terms|); that error is pushed through
+    the activation's slope and |W_down|. The GELU form is a step function of f16(g): an element whose
+    g sits within the node tolerance of an f16 rounding boundary may land on the neighbouring table
+    entry (one f16 ulp of input and output); the bound allows that for every element and the test
+    also requires that at most 1 % of the elements need it.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_py as O
+from conftest import bits, ffn_golden_names, load_ffn_golden
+from llama_cpp_amd.payload import make_payload, make_x
+from test_gpu_forward import fast_tolerance
+
+pytestmark = pytest.mark.gpu
+
+F16_ULP = 2.0 ** -10
+
+
+def dense_abs(p):
+    eye = np.eye(p.n_in, dtype=np.float32)
+    return np.abs(O.forward(p, eye).astype(np.float64)).T            # (n_out, n_in)
+
+
+def h_bounds(gate, up, x, act):
+    """-> (smooth bound, full bound, h_ref) for h = act(g) * u given node tolerances on g and u."""
+    g = O.forward(gate, x).astype(np.float64)
+    u = O.forward(up, x).astype(np.float64)
+    tg, tu = fast_tolerance(gate, x, None), fast_tolerance(up, x, None)
+    h = O.glu(act, g.astype(np.float32), u.astype(np.float32)).astype(np.float64)
+    a = np.divide(h, u, out=np.zeros_like(h), where=u != 0)          # act(g)
+    slope = 1.13                                                      # max |silu'|, |gelu'| < 1.13
+    smooth = slope * tg * np.abs(u) + np.abs(a) * tu + 1e-6 * np.abs(h) + 1e-30
+    full = smooth
+    if act == O.ACT_GELU:
+        full = smooth + (slope * np.abs(g) * F16_ULP + np.abs(a) * F16_ULP) * np.abs(u)
+    return smooth, full, h
+
+
+def check_h(h_gpu, smooth, full, h_ref):
+    err = np.abs(h_gpu.astype(np.float64) - h_ref)
+    assert np.all(err <= full), f"max err/bound {np.max(err / full):.3g}"
+    assert np.mean(err > smooth) <= 0.01
+
+
+def check_y(y_gpu, y_ref, down, h_ref, h_bound):
+    t_down = fast_tolerance(down, h_ref.astype(np.float32), None)
+    bound = t_down + (dense_abs(down) @ h_bound.T).T
+    err = np.abs(y_gpu.astype(np.float64) - y_ref)
+    assert np.all(err <= bound), f"max err/bound {np.max(err / bound):.3g}"
+
+
+@pytest.mark.parametrize("name", ffn_golden_names())
+def test_ffn_exact_order_vs_reference_graph(hip, name):
+    gate, up, down, x, act, h_ref, y_ref = load_ffn_golden(name)
+    wg, wu, wd = hip.SeedDeltaWeight(gate), hip.SeedDeltaWeight(up), hip.SeedDeltaWeight(down)
+    h = hip.ffn_gate_up_host(wg, wu, x, act, hip.FWD_EXACT_ORDER)
+    y = hip.ffn_forward_host(wg, wu, wd, x, act, hip.FWD_EXACT_ORDER)
+    assert not hip.ffn_last_fused()
+    if act == O.ACT_GELU:
+        assert np.array_equal(bits(h), bits(h_ref))
+        assert np.array_equal(bits(y), bits(y_ref))
+    else:
+        hb = 1e-6 * np.abs(h_ref.astype(np.float64)) + 1e-37
+        assert np.all(np.abs(h.astype(np.float64) - h_ref) <= hb)
+        bound = (dense_abs(down) @ hb.T).T * 4.0 + 1e-30
+        assert np.all(np.abs(y.astype(np.float64) - y_ref) <= bound)
+
+
+@pytest.mark.parametrize("name", ffn_golden_names())
+def test_ffn_fast_path_vs_reference_graph(hip, name):
+    gate, up, down, x, act, h_ref, y_ref = load_ffn_golden(name)
+    wg, wu, wd = hip.SeedDeltaWeight(gate), hip.SeedDeltaWeight(up), hip.SeedDeltaWeight(down)
+    smooth, full, h_or = h_bounds(gate, up, x, act)
+    h = hip.ffn_gate_up_host(wg, wu, x, act)
+    # T = 1 with tall base gate/up of one shape and L >= 1024: the single gate|up launch must be taken
+    expect_fused = x.shape[0] == 1 and gate.base_d1 is not None and gate.base_d1.shape[1] >= 1024
+    assert hip.ffn_last_fused() == expect_fused
+    check_h(h, smooth, full, h_ref.astype(np.float64))
+    y = hip.ffn_forward_host(wg, wu, wd, x, act)
+    assert hip.ffn_last_fused() == expect_fused
+    check_y(y, y_ref.astype(np.float64), down, h_ref, full)
+    assert wg.nonfinite_count() == 0 and wu.nonfinite_count() == 0 and wd.nonfinite_count() == 0
+
+
+@pytest.mark.parametrize("act", [O.ACT_SILU, O.ACT_GELU])
+@pytest.mark.parametrize("scheme,K,block", [("coo", 32, 16), ("coo", 128, 16), ("block", 64, 16), ("block", 128, 32)])
+@pytest.mark.parametrize("dims", [(1024, 2816), (2048, 5632), (1152, 6912)])
+def test_gate_up_single_launch_matches_node_by_node(hip, act, scheme, K, block, dims):
+    """T = 1: the gate|up launch against the node-by-node device path (SDH_FWD_NO_FUSE) and the oracle."""
+    n_embd, n_ff = dims
+    kw = dict(scheme=scheme, K=K, block=block, base=True, d13_random=True)
+    gate, up = make_payload(n_embd, n_ff, seed=21, **kw), make_payload(n_embd, n_ff, seed=22, **kw)
+    wg, wu = hip.SeedDeltaWeight(gate), hip.SeedDeltaWeight(up)
+    x = (3.0 * make_x(n_embd, 1, seed=9)).astype(np.float32)
+    smooth, full, h_ref = h_bounds(gate, up, x, act)
+    for rep in range(3):                                  # epochs advance, granules are reused
+        h1 = hip.ffn_gate_up_host(wg, wu, x, act)
+        assert hip.ffn_last_fused()
+        check_h(h1, smooth, full, h_ref)
+    h2 = hip.ffn_gate_up_host(wg, wu, x, act, hip.FWD_NO_FUSE)
+    assert not hip.ffn_last_fused()
+    check_h(h2, smooth, full, h_ref)
+    # the plain ops on the same handles still work after the pair launches (shared granule buffers)
+    yg = wg.forward_host(x)
+    assert np.all(np.abs(yg - O.forward(gate, x)) <= fast_tolerance(gate, x, None))
+
+
+def test_gate_up_declines_gracefully(hip):
+    """shapes the single launch does not cover fall back to node by node and stay correct"""
+    x = make_x(512, 1, seed=2)
+    for kw_g, kw_u in [(dict(scheme="coo", K=32, base=True), dict(scheme="block", K=32, block=16, base=True)),   # kinds differ
+                       (dict(scheme="coo", K=32, base=False), dict(scheme="coo", K=32, base=False)),              # no base
+                       (dict(scheme="coo", K=32, base=True), dict(scheme="coo", K=64, base=True))]:               # row shapes differ
+        gate, up = make_payload(512, 1536, seed=1, **kw_g), make_payload(512, 1536, seed=2, **kw_u)
+        wg, wu = hip.SeedDeltaWeight(gate), hip.SeedDeltaWeight(up)
+        smooth, full, h_ref = h_bounds(gate, up, x, O.ACT_SILU)
+        h = hip.ffn_gate_up_host(wg, wu, x, O.ACT_SILU)
+        assert not hip.ffn_last_fused()
+        check_h(h, smooth, full, h_ref)
+
+
+def test_ffn_nonfinite_nodes_are_counted_and_zeroed(hip):
+    gate, up = make_payload(1024, 2048, seed=5, scheme="coo", K=16, base=True), make_payload(1024, 2048, seed=6, scheme="coo", K=16, base=True)
+    down = make_payload(2048, 1024, seed=7, scheme="coo", K=16, base=True)
+    gate.d_val[7, 0] = np.float16(np.inf)
+    gate.d_idx[7, 0] = 3
+    wg, wu, wd = hip.SeedDeltaWeight(gate), hip.SeedDeltaWeight(up), hip.SeedDeltaWeight(down)
+    x = make_x(1024, 1, seed=3)
+    x[0, 3] = 1.0
+    h = hip.ffn_gate_up_host(wg, wu, x, O.ACT_SILU, hip.FWD_ZERO_NONFINITE)
+    assert hip.ffn_last_fused()
+    assert wg.nonfinite_count() == 1 and wu.nonfinite_count() == 0
+    assert h[0, 7] == 0.0 and np.all(np.isfinite(h))     # silu(0) * u = 0, as the reference's guard + swiglu give
+    y = hip.ffn_forward_host(wg, wu, wd, x, O.ACT_SILU, hip.FWD_ZERO_NONFINITE)
+    assert np.all(np.isfinite(y)) and wd.nonfinite_count() == 0
+
+
+def test_ffn_device_io_and_strides(hip):
+    gate, up, down, x, act, h_ref, y_ref = load_ffn_golden("ffn_silu_base_coo_t5")
+    wg, wu, wd = hip.SeedDeltaWeight(gate), hip.SeedDeltaWeight(up), hip.SeedDeltaWeight(down)
+    T, n_embd = x.shape
+    ldx, ldy = n_embd + 8, n_embd + 4
+    xd = torch.zeros((T, ldx), dtype=torch.float32, device="cuda")
+    xd[:, :n_embd] = torch.from_numpy(x).cuda()
+    yd = torch.full((T, ldy), 7.0, dtype=torch.float32, device="cuda")
+    hip.ffn_forward_device(wg, wu, wd, act, xd.data_ptr(), ldx, T, yd.data_ptr(), ldy, 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    y = yd.cpu().numpy()
+    assert np.all(y[:, n_embd:] == 7.0)
+    y_host = hip.ffn_forward_host(wg, wu, wd, x, act)
+    assert np.array_equal(bits(y[:, :n_embd]), bits(y_host))
+
+
+def test_glu_kernel_vs_oracle(hip):
+    rng = np.random.default_rng(8)
+    n = 100003
+    g = (6.0 * rng.standard_normal(n)).astype(np.float32)
+    u = rng.standard_normal(n).astype(np.float32)
+    g[:6] = [10.0, -10.0, 0.0, -0.0, np.inf, -np.inf]
+    gd, ud = torch.from_numpy(g).cuda(), torch.from_numpy(u).cuda()
+    yd = torch.empty_like(gd)
+    for act in (O.ACT_GELU, O.ACT_SILU):
+        hip.glu_device(act, gd.data_ptr(), ud.data_ptr(), yd.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        y, ref = yd.cpu().numpy(), O.glu(act, g, u)
+        if act == O.ACT_GELU:
+            assert np.array_equal(bits(y), bits(ref))
+        else:
+            fin = np.isfinite(ref)
+            assert np.array_equal(np.isfinite(y), fin)
+            assert np.all(np.abs(y[fin] - ref[fin]) <= 1e-6 * np.abs(ref[fin]) + 1e-37)
+
+
+def test_ffn_full_size_mistral_layer(hip):
+    """Mistral-7B layer shape, T = 1: gate|up launch + down against the oracle."""
+    kw = dict(scheme="coo", K=128, base=True)
+    gate, up = make_payload(4096, 14336, seed=31, **kw), make_payload(4096, 14336, seed=32, **kw)
+    down = make_payload(14336, 4096, seed=33, **kw)
+    wg, wu, wd = hip.SeedDeltaWeight(gate), hip.SeedDeltaWeight(up), hip.SeedDeltaWeight(down)
+    x = make_x(4096, 1, seed=4)
+    smooth, full, h_ref = h_bounds(gate, up, x, O.ACT_SILU)
+    h = hip.ffn_gate_up_host(wg, wu, x, O.ACT_SILU)
+    assert hip.ffn_last_fused()
+    check_h(h, smooth, full, h_ref)
+    y = hip.ffn_forward_host(wg, wu, wd, x, O.ACT_SILU)
+    y2 = hip.ffn_forward_host(wg, wu, wd, x, O.ACT_SILU, hip.FWD_NO_FUSE)
+    y_or = O.forward(down, h_ref.astype(np.float32))
+    # |W_down| . |dh| without materialising W_down: bound dh by its norm and the row norms of the two parts
+    scale = np.abs(y_or).max()
+    assert np.max(np.abs(y - y_or)) <= 2e-4 * scale and np.max(np.abs(y2 - y_or)) <= 2e-4 * scale

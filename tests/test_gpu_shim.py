@@ -89,3 +89,18 @@ def test_shim_random_payloads(shim, scheme, base, dims, T):
     p = make_payload(n_in, n_out, scheme=scheme, K=64, block=32, base=base, d13_random=base, seed=T + n_in)
     x = make_x(n_in, T, seed=5)
     check_fast(p, x, O.forward_shim(p, x, nth=2), O.forward(p, x, nth=4))
+
+
+@pytest.mark.parametrize("name", ["ffn_silu_base_coo_t5", "ffn_gelu_base_block_t1", "ffn_gelu_block_nobase_t3"])
+def test_shim_nodes_inside_the_reference_ffn_graph(shim, name):
+    """The whole gated FFN as ONE ggml graph computed by the reference's CPU backend
+    (ggml_graph_compute, 2 threads), its three SeedDelta nodes served by the drop-in TU and its own
+    swiglu / geglu between them (src/llama-graph.cpp:811-953) — against the same graph with the
+    reference's op TU (the fixture)."""
+    from conftest import load_ffn_golden
+    from test_gpu_ffn import check_h, check_y, h_bounds
+    gate, up, down, x, act, h_ref, y_ref = load_ffn_golden(name)
+    h, y = O.ffn_forward_graph(gate, up, down, x, act, nth=2, shim=True)
+    smooth, full, _ = h_bounds(gate, up, x, act)
+    check_h(h, smooth, full, h_ref.astype(np.float64))
+    check_y(y, y_ref.astype(np.float64), down, h_ref, full)
