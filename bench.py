@@ -53,6 +53,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-scan", action="store_true", help="skip the scan (candidates/s) leg")
+    ap.add_argument("--no-ffn", action="store_true", help="skip the gated-FFN-block leg")
+    ap.add_argument("--ffn-layers", type=int, default=16, help="distinct synthetic Mistral-7B layers rotated in the FFN-block leg")
     ap.add_argument("--scan-layers", type=int, default=8, help="synthetic Mistral-7B layers in the scan job")
     ap.add_argument("--scan-threads", type=int, default=16, help="host threads preparing candidates per rank")
     ap.add_argument("--host-io", action="store_true",
@@ -186,6 +188,71 @@ def run_scan(args, rank, world, dev):
                       "host_threads_per_rank": args.scan_threads, "dense_bytes_resident_per_rank": dense_bytes,
                       "collective": "one all_gather of %d-double records" % SC.RECORD_LEN}}
     return out
+
+
+def run_ffn(args, dev):
+    """Gated FFN block at T=1: one Mistral-7B layer = gate, up (4096->14336) and down
+    (14336->4096), COO K=128 with base, SiLU. Compares sdh_ffn_forward (gate|up in one launch, h kept on
+    the device, then down) with the same three nodes + activation issued one by one. Layers rotate so
+    that the payloads (17 MB per layer) do not stay in the 256 MB Infinity Cache."""
+    import torch
+    from llama_cpp_amd import seeddelta
+    from llama_cpp_amd.payload import make_payload
+    NL = max(1, args.ffn_layers)
+    n_embd, n_ff, K = 4096, 14336, 128
+    layers, alg = [], 0
+    for i in range(NL):
+        ps = [make_payload(n_embd, n_ff, scheme="coo", K=K, base=True, seed=7000 + 3 * i),
+              make_payload(n_embd, n_ff, scheme="coo", K=K, base=True, seed=7001 + 3 * i),
+              make_payload(n_ff, n_embd, scheme="coo", K=K, base=True, seed=7002 + 3 * i)]
+        alg = sum(p.algorithmic_bytes(1) for p in ps)
+        layers.append([seeddelta.SeedDeltaWeight(p) for p in ps])
+        del ps
+    x = torch.randn((1, n_embd), dtype=torch.float32, device=dev)
+    y = torch.empty((1, n_embd), dtype=torch.float32, device=dev)
+    g = torch.empty((1, n_ff), dtype=torch.float32, device=dev)
+    u = torch.empty((1, n_ff), dtype=torch.float32, device=dev)
+    h = torch.empty((1, n_ff), dtype=torch.float32, device=dev)
+    sp = torch.cuda.current_stream().cuda_stream
+
+    def block():
+        for wg, wu, wd in layers:
+            seeddelta.ffn_forward_device(wg, wu, wd, seeddelta.ACT_SILU, x.data_ptr(), n_embd, 1, y.data_ptr(), n_embd, 0, sp)
+
+    def nodes():
+        for wg, wu, wd in layers:
+            wg.forward_device(x.data_ptr(), n_embd, 1, g.data_ptr(), n_ff, 0, sp)
+            wu.forward_device(x.data_ptr(), n_embd, 1, u.data_ptr(), n_ff, 0, sp)
+            seeddelta.glu_device(seeddelta.ACT_SILU, g.data_ptr(), u.data_ptr(), h.data_ptr(), n_ff, sp)
+            wd.forward_device(h.data_ptr(), n_ff, 1, y.data_ptr(), n_embd, 0, sp)
+
+    def timed(fn, reps):
+        for _ in range(max(2, reps // 8)):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / (reps * NL)        # us per layer
+
+    reps = max(8, 2048 // NL)
+    us_block = timed(block, reps)
+    fused = seeddelta.ffn_last_fused()
+    us_nodes = timed(nodes, reps)
+    for ws in layers:
+        for w in ws:
+            w.close()
+    return {"metric": "gated FFN block decode, layers/s (Mistral-7B layer, COO K=128 + base, SiLU, T=1)",
+            "value": 1e6 / us_block, "unit": "layers/s", "us_per_layer": us_block,
+            "us_per_layer_node_by_node": us_nodes, "speedup_vs_node_by_node": us_nodes / us_block,
+            "gate_up_single_launch": bool(fused), "distinct_layers": NL,
+            "algorithmic_bytes_per_layer": alg,
+            "roofline": {"bound": "hbm", "achieved": alg / us_block / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / us_block / 1e3 / HBM_PEAK_GBS, "traffic": None,
+                         "note": "two launches per layer (gate|up, down): launch-latency bound like the single-tensor decode"}}
 
 
 def scan_cpu_baseline(budget_s):
@@ -354,12 +421,18 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.workload, T, args.cpu_seconds)
 
+    for w in weights:
+        w.close()
+    weights.clear()
+    torch.cuda.empty_cache()
+
+    ffn = None
+    if not args.no_ffn and rank == 0 and world == 1:
+        ffn = run_ffn(args, dev)
+        torch.cuda.empty_cache()
+
     scan = None
     if not args.no_scan:
-        for w in weights:
-            w.close()
-        weights.clear()
-        torch.cuda.empty_cache()
         scan = run_scan(args, rank, world, dev)
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             scan["cpu_baseline"] = scan_cpu_baseline(args.cpu_seconds)
@@ -378,6 +451,8 @@ def main():
         }
         if host_io is not None:
             line["pcie_inclusive"] = host_io
+        if ffn is not None:
+            line["ffn_block"] = ffn
         if scan is not None:
             line["scan"] = scan
         print(json.dumps(line), flush=True)

@@ -1,7 +1,7 @@
 #!/bin/bash
 set -o pipefail
 mkdir -p gpurun_out
-B="python -u bench.py --tokens 512 --payloads 4 --steps 32 --warmup 8 --no-cpu-baseline --no-scan"
+B="python -u bench.py --tokens 512 --payloads 4 --steps 32 --warmup 8 --no-cpu-baseline --no-scan --no-ffn"
 for wl in cfg4_mistral_gate_coo_k128 cfg4_mistral_gate_block16_k128 cfg2_gemma4b_gate_coo_k128 cfg4_mistral_down_coo_k128; do
   for v in four one; do
     if [ $v = one ]; then export SDH_SPMM_ONE_TOKEN=1; else unset SDH_SPMM_ONE_TOKEN; fi
