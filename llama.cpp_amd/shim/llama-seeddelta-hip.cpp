@@ -19,6 +19,7 @@
 // The reference's LLAMA_SEEDDELTA_DEBUG_* comparison paths (src/llama-seeddelta.cpp:81-203,
 // :394-458) are diagnostics of the CPU op and are not reproduced.
 #include "llama-seeddelta.h"
+#include "llama-seeddelta-hip-ffn.h"
 
 #include "ggml.h"
 #include "ggml-backend.h"
@@ -274,7 +275,91 @@ ggml_tensor * make_node(ggml_context * ctx, ggml_tensor * x, ggml_tensor * w_ref
                           seeddelta_hip_op<BASE, BLOCK>, 1, w_ref);
 }
 
+// ---- the optional whole-FFN node (llama-seeddelta-hip-ffn.h) -----------------------------------------
+struct ffn_node {
+    llama_seeddelta_weight gate, up, down;
+    bool gelu = false;
+};
+std::vector<ffn_node *> g_ffn_nodes;     // owned here, freed by llama_seeddelta_hip_release_all
+
+node_payload payload_of(const llama_seeddelta_weight & w, const ggml_tensor * x) {
+    node_payload n;
+    n.x = x;
+    n.d_idx = w.b_idx ? nullptr : w.d_idx;   // dispatch of src/llama-graph.cpp:681-703: block wins over COO
+    n.d_val = w.b_idx ? nullptr : w.d_val;
+    n.b_idx = w.b_idx; n.b_val = w.b_val;
+    n.row_scale = w.row_scale;
+    n.d1 = w.base_d1;
+    if (w.base_d1) { n.d2 = w.base_d2; n.d3 = w.base_d3; n.p1 = w.base_perm1; n.p2 = w.base_perm2; }
+    return n;
+}
+
+void seeddelta_hip_ffn_op(ggml_tensor * dst, int ith, int /*nth*/, void * userdata) {
+    if (ith != 0) {
+        return;
+    }
+    const ffn_node * f = (const ffn_node *) userdata;
+    const ggml_tensor * x = dst->src[0];
+    const int64_t n_embd = x->ne[0], n_tok = x->ne[1];
+    if (n_tok <= 0) {
+        return;
+    }
+    GGML_ASSERT(dst->type == GGML_TYPE_F32 && dst->nb[0] == sizeof(float) && dst->nb[1] % sizeof(float) == 0);
+    sdh_weight * wg = resident_payload(payload_of(f->gate, x));
+    sdh_weight * wu = resident_payload(payload_of(f->up, x));
+    // ffn_down reads the [n_ff, n_tokens] activation: only its row count enters the payload key
+    ggml_tensor hshape = *x;
+    hshape.ne[0] = (f->gate.b_idx ? f->gate.b_idx : f->gate.d_idx)->ne[1];
+    sdh_weight * wd = resident_payload(payload_of(f->down, &hshape));
+    int64_t ldx = n_embd;
+    const float * xs = packed_x(x, n_embd, n_tok, &ldx);
+    const int64_t n_out = dst->ne[0];
+    const int64_t ldy = n_tok > 1 ? (int64_t) (dst->nb[1] / sizeof(float)) : n_out;
+    const int flags = SDH_FWD_HOST_IO | SDH_FWD_ZERO_NONFINITE;
+    if (sdh_ffn_forward(wg, wu, wd, f->gelu ? SDH_ACT_GELU : SDH_ACT_SILU, xs, ldx, n_tok, (float *) dst->data, ldy, flags, nullptr) != SDH_OK) {
+        die("sdh_ffn_forward");
+    }
+    const int64_t bad = sdh_nonfinite_count(wg) + sdh_nonfinite_count(wu) + sdh_nonfinite_count(wd);
+    if (bad > 0) {
+        g_nonfinite_total.fetch_add(bad, std::memory_order_relaxed);
+        if (!g_nonfinite_warned.test_and_set(std::memory_order_relaxed)) {
+            std::fprintf(stderr, "llama-seeddelta-hip: non-finite output inside an FFN block; writing 0.0 (dense weight unavailable)\n");
+        }
+    }
+}
+
+bool dense_present(const ggml_tensor * w) {
+    return w && w->data && ggml_nbytes(w) > 0 && ggml_n_dims(w) == 2;
+}
+
 } // namespace
+
+ggml_tensor * llama_seeddelta_hip_ffn(
+        ggml_context * ctx, ggml_tensor * x,
+        const llama_seeddelta_weight * gate, const llama_seeddelta_weight * up, const llama_seeddelta_weight * down,
+        const ggml_tensor * w_gate, const ggml_tensor * w_up, const ggml_tensor * w_down,
+        bool gelu) {
+    if (!gate || !up || !down) {
+        return nullptr;
+    }
+    if (x->ne[1] > 1 && (dense_present(w_gate) || dense_present(w_up) || dense_present(w_down))) {
+        return nullptr;   // the reference would repair from the dense rows: keep three nodes
+    }
+    const ggml_tensor * didx = down->b_idx ? down->b_idx : down->d_idx;
+    const ggml_tensor * gidx = gate->b_idx ? gate->b_idx : gate->d_idx;
+    const ggml_tensor * uidx = up->b_idx ? up->b_idx : up->d_idx;
+    if (!didx || !gidx || !uidx || gidx->ne[1] != uidx->ne[1]) {
+        return nullptr;
+    }
+    ffn_node * f = new ffn_node;
+    f->gate = *gate; f->up = *up; f->down = *down; f->gelu = gelu;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        g_ffn_nodes.push_back(f);
+    }
+    ggml_tensor * args[1] = { x };
+    return ggml_custom_4d(ctx, GGML_TYPE_F32, didx->ne[1], x->ne[1], 1, 1, args, 1, seeddelta_hip_ffn_op, 1, f);
+}
 
 // Exported for teardown paths and tests: frees every device-resident payload.
 extern "C" void llama_seeddelta_hip_release_all(void) {
@@ -283,6 +368,10 @@ extern "C" void llama_seeddelta_hip_release_all(void) {
         sdh_weight_destroy(kv.second);
     }
     g_payloads.clear();
+    for (ffn_node * f : g_ffn_nodes) {
+        delete f;
+    }
+    g_ffn_nodes.clear();
 }
 
 extern "C" int64_t llama_seeddelta_hip_nonfinite_total(void) {

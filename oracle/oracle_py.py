@@ -147,6 +147,9 @@ def shim_lib():
         _shim.llama_seeddelta_hip_release_all.restype = None
         _shim.llama_seeddelta_hip_nonfinite_total.restype = C.c_int64
         _bind_ffn(_shim)
+        _shim.sdshim_ffn_node.argtypes = [C.POINTER(C.c_int), C.POINTER(SdoOpArgs), C.POINTER(SdoOpArgs), C.POINTER(SdoOpArgs),
+                                          C.c_int, C.c_int, C.c_int, C.c_void_p]
+        _shim.sdshim_ffn_node.restype = C.c_int
     return _shim
 
 
@@ -290,3 +293,34 @@ def ffn_forward_graph(gate, up, down, x: np.ndarray, act: int, nth: int = 1, shi
     if rc != 0:
         raise RuntimeError(f"sdref_ffn failed: {rc}")
     return h, y
+
+
+def ffn_node_shim(gate, up, down, x: np.ndarray, act: int, nth: int = 1, dense_ref=None):
+    """The drop-in's optional whole-FFN node (llama_seeddelta_hip_ffn) inside a ggml graph computed by
+    the reference's CPU backend -> y, or None when the constructor declines (keeps three nodes).
+    dense_ref: a dense gate weight to present as still loaded."""
+    T = x.shape[0]
+    y = np.empty((T, down.n_out), dtype=np.float32)
+    dummy = np.empty((T, gate.n_out), dtype=np.float32)
+    if dense_ref is not None:
+        gate = _copy_with_w_ref(gate, dense_ref)
+    ga, ua, da = _args(gate, x, dummy), _args(up, x, dummy), _args(down, dummy, y)
+    kinds = (C.c_int * 3)(gate.kind, up.kind, down.kind)
+    lib = shim_lib()
+    try:
+        rc = lib.sdshim_ffn_node(kinds, C.byref(ga), C.byref(ua), C.byref(da), act, nth, 1 if dense_ref is not None else 0,
+                                 y.ctypes.data)
+    finally:
+        lib.llama_seeddelta_hip_release_all()
+    if rc == 1:
+        return None
+    if rc != 0:
+        raise RuntimeError(f"sdshim_ffn_node failed: {rc}")
+    return y
+
+
+def _copy_with_w_ref(p, w_ref):
+    import copy
+    q = copy.copy(p)
+    q.w_ref = w_ref
+    return q

@@ -104,3 +104,27 @@ def test_shim_nodes_inside_the_reference_ffn_graph(shim, name):
     smooth, full, _ = h_bounds(gate, up, x, act)
     check_h(h, smooth, full, h_ref.astype(np.float64))
     check_y(y, y_ref.astype(np.float64), down, h_ref, full)
+
+
+@pytest.mark.parametrize("name", ["ffn_silu_base_coo_t1", "ffn_gelu_base_block_t1", "ffn_silu_base_coo_t5", "ffn_gelu_block_nobase_t3"])
+def test_shim_whole_ffn_node(shim, name):
+    """The optional fifth constructor (one ggml node for the whole gated FFN) inside a
+    graph computed by the reference's CPU backend, against the reference's three-node graph."""
+    from conftest import load_ffn_golden
+    from test_gpu_ffn import check_y, h_bounds
+    gate, up, down, x, act, h_ref, y_ref = load_ffn_golden(name)
+    y = O.ffn_node_shim(gate, up, down, x, act, nth=2)
+    assert y is not None
+    _, full, _ = h_bounds(gate, up, x, act)
+    check_y(y, y_ref.astype(np.float64), down, h_ref, full)
+
+
+def test_shim_whole_ffn_node_declines_when_dense_repair_is_possible(shim):
+    """more than one token and a dense weight still loaded: the reference would repair from the dense
+    row, so the constructor keeps the three-node form; with one token it does not (the reference's
+    guard declines 1-D activations, src/llama-seeddelta.cpp:323)."""
+    from conftest import load_ffn_golden
+    gate, up, down, x, act, h_ref, y_ref = load_ffn_golden("ffn_silu_base_coo_t5")
+    dense = np.zeros((gate.n_out, gate.n_in), dtype=np.float32)
+    assert O.ffn_node_shim(gate, up, down, x, act, dense_ref=dense) is None
+    assert O.ffn_node_shim(gate, up, down, x[:1], act, dense_ref=dense) is not None
