@@ -49,14 +49,29 @@ struct DeviceDense {
     int64_t stored_bytes = 0;
 };
 
+// The stored type is a template parameter of every kernel that reads the weight: with a run-time
+// branch on W.type inside the accessor each load sits in a basic block of its own and hipcc waits for
+// it before issuing the next (one memory round trip per element instead of one per batch).
+template <int DT>
 __device__ __forceinline__ float dense_at(const DenseView & W, int64_t row, int64_t i) {
-    if (W.type == SDH_TYPE_Q8_0) {
+    if constexpr (DT == SDH_TYPE_Q8_0) {
         const float d = __half2float(W.d[row * (W.n_in >> 5) + (i >> 5)]);
         return (float) W.q[row * W.n_in + i] * d;
+    } else if constexpr (DT == SDH_TYPE_F16) {
+        return __half2float(((const __half *) W.data)[row * W.n_in + i]);
+    } else {
+        return ((const float *) W.data)[row * W.n_in + i];
     }
-    if (W.type == SDH_TYPE_F16) return __half2float(((const __half *) W.data)[row * W.n_in + i]);
-    return ((const float *) W.data)[row * W.n_in + i];
 }
+
+#define SDH_LAUNCH_DT(VIEW, KERNEL, GRID, BLOCK, LDS, STREAM, ...)                                              \
+    do {                                                                                                        \
+        switch ((VIEW).type) {                                                                                  \
+            case SDH_TYPE_Q8_0: hipLaunchKernelGGL((KERNEL<SDH_TYPE_Q8_0>), GRID, BLOCK, LDS, STREAM, __VA_ARGS__); break; \
+            case SDH_TYPE_F16:  hipLaunchKernelGGL((KERNEL<SDH_TYPE_F16>),  GRID, BLOCK, LDS, STREAM, __VA_ARGS__); break; \
+            default:            hipLaunchKernelGGL((KERNEL<SDH_TYPE_F32>),  GRID, BLOCK, LDS, STREAM, __VA_ARGS__); break; \
+        }                                                                                                       \
+    } while (0)
 
 struct BaseView {            // fitted base on device, [B][L]
     const float * h2;
@@ -107,6 +122,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int * scratch /* >= 5 ints
 // order, the one element of that row that falls into XOR bin u: j = u ^ p, src = in0 + perm[j].
 struct FitJob { int b; int rows_off; int n_rows; int perm_off; };
 
+template <int DT>
 __global__ __launch_bounds__(256)
 void scan_fit_kernel(DenseView W, int L, int tall, const FitJob * __restrict__ jobs, const int * __restrict__ rows,
                      const int * __restrict__ perms, const float * __restrict__ ws, double * __restrict__ out /* [n_jobs][3][L] */) {
@@ -129,7 +145,7 @@ void scan_fit_kernel(DenseView W, int L, int tall, const FitJob * __restrict__ j
         const int64_t src = in0 + perm_s[j];
         const bool ok = src >= in0 && src < in1;
         const int64_t srcc = ok ? src : in0;
-        const double v = ok ? (double) dense_at(W, row, srcc) : 0.0;
+        const double v = ok ? (double) dense_at<DT>(W, row, srcc) : 0.0;
         if (ws) {
             const double w1 = ok ? (double) ws[srcc] : 0.0;
             const double ww = w1 * w1;
@@ -150,6 +166,20 @@ void scan_fit_kernel(DenseView W, int L, int tall, const FitJob * __restrict__ j
 // One workgroup per output row. LDS: r[n_in] f32 | sort[Kpad] u64 | hist[256] | misc.
 __device__ __forceinline__ uint32_t score_key(float r) { return __float_as_uint(fabsf(r)); }
 
+// hist[bin] += 1 for every active lane, one LDS atomic per distinct bin of the wave. The top byte of an
+// fp32 score (sign + 7 exponent bits) takes a handful of values over a weight row: plain per-lane
+// atomics would put all 64 lanes of a wave on one or two LDS words, which the LDS serialises.
+__device__ __forceinline__ void hist_add_aggregated(uint32_t * hist, uint32_t bin, bool active) {
+    unsigned long long todo = __ballot(active);
+    while (todo) {
+        const int leader = __ffsll((long long) todo) - 1;
+        const uint32_t b = (uint32_t) __shfl((int) bin, leader, 64);
+        const unsigned long long same = __ballot(active && bin == b);
+        if ((int) (threadIdx.x & 63) == leader) atomicAdd(&hist[b], (uint32_t) __popcll(same));
+        todo &= ~same;
+    }
+}
+
 template <typename CMP>
 __device__ __forceinline__ void bitonic_desc(int n, CMP swap_if_needed) {
     for (int k = 2; k <= n; k <<= 1) {
@@ -163,6 +193,7 @@ __device__ __forceinline__ void bitonic_desc(int n, CMP swap_if_needed) {
     }
 }
 
+template <int DT>
 __global__ __launch_bounds__(256)
 void scan_select_coo_kernel(DenseView W, BaseView base, int has_base, int K, int Kpad, int want_rs,
                             const float * __restrict__ ws,
@@ -179,7 +210,7 @@ void scan_select_coo_kernel(DenseView W, BaseView base, int has_base, int K, int
 
     double dot = 0.0, nn = 0.0;
     for (int i = tid; i < n_in; i += 256) {
-        const float w = dense_at(W, row, i);
+        const float w = dense_at<DT>(W, row, i);
         if (has_base) {
             const float bw = base_weight(base, row, i);
             r[i] = w - bw;
@@ -204,9 +235,17 @@ void scan_select_coo_kernel(DenseView W, BaseView base, int has_base, int K, int
         const int shift = 24 - 8 * pass;
         hist[tid] = 0;
         __syncthreads();
-        for (int i = tid; i < n_in; i += 256) {
-            const uint32_t key = key_of(i);
-            if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        if (pass == 0) {
+            for (int i0 = 0; i0 < n_in; i0 += 256) {      // whole waves stay in the loop: the ballots need them
+                const int i = i0 + tid;
+                const bool act = i < n_in;
+                hist_add_aggregated(hist, act ? (key_of(i) >> 24) : 0u, act);
+            }
+        } else {
+            for (int i = tid; i < n_in; i += 256) {
+                const uint32_t key = key_of(i);
+                if ((key >> (shift + 8)) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+            }
         }
         __syncthreads();
         {   // digit = the largest d with (count of keys in bins > d) < need <= (count in bins >= d):
@@ -265,7 +304,7 @@ void scan_select_coo_kernel(DenseView W, BaseView base, int has_base, int K, int
         idx_out[row * K + rr] = i;
         val_out[row * K + rr] = r[i];
         if (want_rs) {
-            const double wi = (double) dense_at(W, row, i), di = (double) r[i];
+            const double wi = (double) dense_at<DT>(W, row, i), di = (double) r[i];
             const double s1 = ws ? (double) ws[i] : 1.0;
             if (has_base) { dot2 += wi * di * s1 * s1; nn2 += (2.0 * wi * di - di * di) * s1 * s1; }
             else          { dot2 += wi * wi * s1 * s1; nn2 += wi * wi * s1 * s1; }
@@ -280,6 +319,7 @@ void scan_select_coo_kernel(DenseView W, BaseView base, int has_base, int K, int
 
 // ---- kernel: block selection -------------------------------------------------------------------------
 // LDS: r[n_in] f32 | energy[NBpad] f64 | bid[NBpad] i32 | misc
+template <int DT>
 __global__ __launch_bounds__(256)
 void scan_select_block_kernel(DenseView W, BaseView base, int has_base, int block, int keep, int n_blocks, int NBpad,
                               int want_rs, const float * __restrict__ ws,
@@ -295,7 +335,7 @@ void scan_select_block_kernel(DenseView W, BaseView base, int has_base, int bloc
 
     double dot = 0.0, nn = 0.0;
     for (int i = tid; i < n_in; i += 256) {
-        const float w = dense_at(W, row, i);
+        const float w = dense_at<DT>(W, row, i);
         if (has_base) {
             const float bw = base_weight(base, row, i);
             r[i] = w - bw;
@@ -338,7 +378,7 @@ void scan_select_block_kernel(DenseView W, BaseView base, int has_base, int bloc
         if (i < n_in) {
             v = r[i];
             if (want_rs) {
-                const double wi = (double) dense_at(W, row, i), di = (double) v;
+                const double wi = (double) dense_at<DT>(W, row, i), di = (double) v;
                 const double s1 = ws ? (double) ws[i] : 1.0;
                 if (has_base) { dot2 += wi * di * s1 * s1; nn2 += (2.0 * wi * di - di * di) * s1 * s1; }
                 else          { dot2 += wi * wi * s1 * s1; nn2 += wi * wi * s1 * s1; }
@@ -354,6 +394,7 @@ void scan_select_block_kernel(DenseView W, BaseView base, int has_base, int bloc
 }
 
 // ---- kernel: weight-space metric triples (w_norm2, hat_norm2, dot) per sampled row -------------------
+template <int DT>
 __global__ __launch_bounds__(256)
 void scan_evalw_kernel(DenseView W, BaseView base, int has_base, int scheme, int K, int block,
                        const int * __restrict__ idx, const float * __restrict__ val, const float * __restrict__ rs,
@@ -365,7 +406,7 @@ void scan_evalw_kernel(DenseView W, BaseView base, int has_base, int scheme, int
     double wn = 0.0, hn = 0.0, dt = 0.0;
     for (int i = threadIdx.x; i < n_in; i += 256) {
         const double s1 = ws ? (double) ws[i] : 1.0;
-        const double wi = (double) dense_at(W, row, i) * s1;
+        const double wi = (double) dense_at<DT>(W, row, i) * s1;
         wn += wi * wi;
         if (has_base) {
             const double bs = (double) base_weight(base, row, i) * s1;
@@ -392,7 +433,7 @@ void scan_evalw_kernel(DenseView W, BaseView base, int has_base, int scheme, int
         }
         const double s1 = ws ? (double) ws[i] : 1.0;
         if (has_base) {
-            const double wi = (double) dense_at(W, row, i) * s1;
+            const double wi = (double) dense_at<DT>(W, row, i) * s1;
             const double ds = (double) dv * s1, bs = (double) base_weight(base, row, i) * s1;
             dt += wi * ds;
             hn += 2.0 * bs * ds + ds * ds;
@@ -400,7 +441,7 @@ void scan_evalw_kernel(DenseView W, BaseView base, int has_base, int scheme, int
             const double wh = scale * (double) dv;
             const double whs = wh * s1;
             hn += whs * whs;
-            dt += (double) dense_at(W, row, i) * s1 * whs;
+            dt += (double) dense_at<DT>(W, row, i) * s1 * whs;
         }
     }
     wn = block_sum(wn, dsc); hn = block_sum(hn, dsc); dt = block_sum(dt, dsc);
@@ -409,6 +450,7 @@ void scan_evalw_kernel(DenseView W, BaseView base, int has_base, int scheme, int
 }
 
 // ---- kernel: y_true[xi][ci] = sum_i W[row_ci][i] * x[xi][i] in double -----------------------------------
+template <int DT>
 __global__ __launch_bounds__(256)
 void scan_dense_dot_kernel(DenseView W, const int * __restrict__ rows, int n_rows, const float * __restrict__ xs,
                            double * __restrict__ out /* [n_x][n_rows] */) {
@@ -417,7 +459,7 @@ void scan_dense_dot_kernel(DenseView W, const int * __restrict__ rows, int n_row
     const int64_t row = rows[ci];
     const float * x = xs + (size_t) xi * W.n_in;
     double acc = 0.0;
-    for (int i = threadIdx.x; i < (int) W.n_in; i += 256) acc += (double) dense_at(W, row, i) * (double) x[i];
+    for (int i = threadIdx.x; i < (int) W.n_in; i += 256) acc += (double) dense_at<DT>(W, row, i) * (double) x[i];
     acc = block_sum(acc, dsc);
     if (threadIdx.x == 0) out[(size_t) xi * n_rows + ci] = acc;
 }
@@ -469,12 +511,13 @@ void scan_delta_dot_kernel(int n_in, int scheme, int K, int block, const int * _
     }
 }
 
+template <int DT>
 __global__ void scan_gather_kernel(DenseView W, const int * __restrict__ rows, int n_rows, const int * __restrict__ cols,
                                    int n_cols, float * __restrict__ out) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_rows * n_cols) return;
     const int c = cols[e % n_cols];
-    out[e] = c < W.n_in ? dense_at(W, rows[e / n_cols], c) : 0.0f;
+    out[e] = c < W.n_in ? dense_at<DT>(W, rows[e / n_cols], c) : 0.0f;
 }
 
 // ---- host: scan state --------------------------------------------------------------------------------
@@ -798,7 +841,7 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
         if ((rc = s.dbl.ensure((size_t) n_jobs * 3 * L))) return rc;
         const int threads = 256;
         if (L < threads) { set_error("scan: base block length %lld < 256 not supported on the GPU path", (long long) L); return SDH_ERR_UNSUPPORTED; }
-        hipLaunchKernelGGL(scan_fit_kernel, dim3((unsigned) (L / threads), (unsigned) n_jobs), dim3(threads),
+        SDH_LAUNCH_DT(W, scan_fit_kernel, dim3((unsigned) (L / threads), (unsigned) n_jobs), dim3(threads),
                            (size_t) L * sizeof(int), st, W, (int) L, tall ? 1 : 0, s.jobs.p, s.rows.p, s.perms.p, ws_dev, s.dbl.p);
         SDH_HIP_CHECK(hipGetLastError());
         std::vector<double> sums((size_t) n_jobs * 3 * L);
@@ -861,8 +904,10 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
             set_error("scan: n_in=%lld with K=%lld needs %zu B of LDS (max 163840)", (long long) n_in, (long long) K_eff, lds);
             return SDH_ERR_UNSUPPORTED;
         }
-        SDH_HIP_CHECK(hipFuncSetAttribute((const void *) scan_select_coo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipLaunchKernelGGL(scan_select_coo_kernel, dim3((unsigned) n_out), dim3(256), lds, st, W, bv, p.write_base ? 1 : 0,
+        SDH_HIP_CHECK(hipFuncSetAttribute((const void *) scan_select_coo_kernel<SDH_TYPE_Q8_0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SDH_HIP_CHECK(hipFuncSetAttribute((const void *) scan_select_coo_kernel<SDH_TYPE_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SDH_HIP_CHECK(hipFuncSetAttribute((const void *) scan_select_coo_kernel<SDH_TYPE_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SDH_LAUNCH_DT(W, scan_select_coo_kernel, dim3((unsigned) n_out), dim3(256), lds, st, W, bv, p.write_base ? 1 : 0,
                            (int) K_eff, Kpad, p.write_row_scale ? 1 : 0, ws_dev, s.idx.p, s.val.p, s.rs.p);
     } else {
         const int64_t n_blocks = (n_in + p.block - 1) / p.block;
@@ -873,8 +918,10 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
             set_error("scan: n_in=%lld block=%lld needs %zu B of LDS (max 163840)", (long long) n_in, (long long) p.block, lds);
             return SDH_ERR_UNSUPPORTED;
         }
-        SDH_HIP_CHECK(hipFuncSetAttribute((const void *) scan_select_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipLaunchKernelGGL(scan_select_block_kernel, dim3((unsigned) n_out), dim3(256), lds, st, W, bv, p.write_base ? 1 : 0,
+        SDH_HIP_CHECK(hipFuncSetAttribute((const void *) scan_select_block_kernel<SDH_TYPE_Q8_0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SDH_HIP_CHECK(hipFuncSetAttribute((const void *) scan_select_block_kernel<SDH_TYPE_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SDH_HIP_CHECK(hipFuncSetAttribute((const void *) scan_select_block_kernel<SDH_TYPE_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SDH_LAUNCH_DT(W, scan_select_block_kernel, dim3((unsigned) n_out), dim3(256), lds, st, W, bv, p.write_base ? 1 : 0,
                            (int) p.block, (int) keep, (int) n_blocks, NBpad, p.write_row_scale ? 1 : 0, ws_dev, s.idx.p, s.val.p, s.rs.p);
     }
     SDH_HIP_CHECK(hipGetLastError());
@@ -901,7 +948,7 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
         const int nr = (int) rows.size();
         int rc2;
         if ((rc2 = s.rows.put(rows, st)) || (rc2 = s.dbl.ensure((size_t) nr * 3))) return rc2;
-        hipLaunchKernelGGL(scan_evalw_kernel, dim3((unsigned) nr), dim3(256), 0, st, W, bv, p.write_base ? 1 : 0, p.scheme,
+        SDH_LAUNCH_DT(W, scan_evalw_kernel, dim3((unsigned) nr), dim3(256), 0, st, W, bv, p.write_base ? 1 : 0, p.scheme,
                            (int) Ksel, (int) s.block, s.idx.p, s.val.p, rs_dev, ws, s.rows.p, s.dbl.p);
         SDH_HIP_CHECK(hipGetLastError());
         std::vector<double> tr((size_t) nr * 3);
@@ -933,7 +980,7 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
                                                  s.perm1.p, nullptr, nx, s.v.p, st))) return rc2;
             vdev = s.v.p;
         }
-        hipLaunchKernelGGL(scan_dense_dot_kernel, dim3((unsigned) nr, (unsigned) nx), dim3(256), 0, st, W, s.rows.p, nr, s.xs.p, s.dbl.p);
+        SDH_LAUNCH_DT(W, scan_dense_dot_kernel, dim3((unsigned) nr, (unsigned) nx), dim3(256), 0, st, W, s.rows.p, nr, s.xs.p, s.dbl.p);
         hipLaunchKernelGGL(scan_delta_dot_kernel, dim3((unsigned) nr, (unsigned) nx), dim3(256), 0, st, (int) n_in, p.scheme,
                            (int) Ksel, (int) s.block, s.idx.p, s.val.p, rs_dev, vdev, (int) L, (int) B, tall ? 1 : 0,
                            s.rows.p, nr, s.xs.p, s.dbl2.p);
@@ -981,13 +1028,13 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
         if ((rc = s.rows.put(hid, st)) || (rc = s.cols.put(outs, st)) || (rc = s.xs.put(xs, st)) ||
             (rc = s.dbl.ensure((size_t) nh * nx * 2)) || (rc = s.dbl2.ensure((size_t) nh * nx)) ||
             (rc = s.gat.ensure((size_t) no * nh))) return rc;
-        hipLaunchKernelGGL(scan_dense_dot_kernel, dim3((unsigned) nh, (unsigned) nx), dim3(256), 0, st, G, s.rows.p, nh, s.xs.p, s.dbl.p);
-        hipLaunchKernelGGL(scan_dense_dot_kernel, dim3((unsigned) nh, (unsigned) nx), dim3(256), 0, st, U, s.rows.p, nh, s.xs.p,
+        SDH_LAUNCH_DT(G, scan_dense_dot_kernel, dim3((unsigned) nh, (unsigned) nx), dim3(256), 0, st, G, s.rows.p, nh, s.xs.p, s.dbl.p);
+        SDH_LAUNCH_DT(U, scan_dense_dot_kernel, dim3((unsigned) nh, (unsigned) nx), dim3(256), 0, st, U, s.rows.p, nh, s.xs.p,
                            s.dbl.p + (size_t) nh * nx);
         hipLaunchKernelGGL(scan_delta_dot_kernel, dim3((unsigned) nh, (unsigned) nx), dim3(256), 0, st, (int) n_in, 0, (int) Ksel, 1,
                            s.idx.p, s.val.p, (const float *) nullptr, (const float *) nullptr, 0, 0, 1, s.rows.p, nh, s.xs.p, s.dbl2.p);
         // W_down[out rows][hidden cols]
-        hipLaunchKernelGGL(scan_gather_kernel, dim3((unsigned) ((no * nh + 255) / 256)), dim3(256), 0, st, D, s.cols.p, no, s.rows.p, nh, s.gat.p);
+        SDH_LAUNCH_DT(D, scan_gather_kernel, dim3((unsigned) ((no * nh + 255) / 256)), dim3(256), 0, st, D, s.cols.p, no, s.rows.p, nh, s.gat.p);
         SDH_HIP_CHECK(hipGetLastError());
         std::vector<double> gu((size_t) nh * nx * 2), hat((size_t) nh * nx);
         std::vector<float> wd((size_t) no * nh);
