@@ -73,20 +73,25 @@ __device__ __forceinline__ float dense_at(const DenseView & W, int64_t row, int6
         }                                                                                                       \
     } while (0)
 
-struct BaseView {            // fitted base on device, [B][L]
+struct BaseView {            // fitted base on device, [B][L]; L is a power of two (fit_dims)
     const float * h2;
     const int *   inv;
-    int L, B, tall;
+    int L, B, tall, log2L;
 };
 
-__device__ __forceinline__ float base_weight(const BaseView & a, int64_t row, int64_t i) {
-    const int64_t L = a.L;
-    const int64_t b = a.tall ? row / L : i / L;
-    const int64_t p = a.tall ? row - b * L : row;
-    const int64_t q = a.tall ? i : i - b * L;
-    const int64_t j = a.inv[b * L + q];
-    return a.h2[b * L + ((p ^ j) & (L - 1))];
+// W0[row, i] of the fitted base: h2_b[(p ^ inv_b[q]) & (L-1)]  (sd_eval.cpp:506,528,714-716)
+__device__ __forceinline__ int base_inv_index(const BaseView & a, int row, int i) {
+    return a.tall ? ((row >> a.log2L) << a.log2L) + i : i;      // b*L + q
 }
+__device__ __forceinline__ int base_h2_index(const BaseView & a, int row, int i, int j) {
+    const int b = a.tall ? row >> a.log2L : i >> a.log2L;
+    return (b << a.log2L) + ((row ^ j) & (a.L - 1));             // (p ^ j) & (L-1): the bits of b drop out of p
+}
+__device__ __forceinline__ float base_weight(const BaseView & a, int64_t row, int64_t i) {
+    const int j = a.inv[base_inv_index(a, (int) row, (int) i)];
+    return a.h2[base_h2_index(a, (int) row, (int) i, j)];
+}
+
 
 // ---- block-wide helpers (256 threads = 4 waves) -----------------------------------------------------
 __device__ __forceinline__ double block_sum(double v, double * scratch /* >= 4 doubles */) {
@@ -115,6 +120,55 @@ __device__ __forceinline__ int block_excl_scan(int v, int * scratch /* >= 5 ints
     for (int w = 0; w < wave; ++w) base += scratch[w];
     *total = scratch[0] + scratch[1] + scratch[2] + scratch[3];
     return base + inc - v;
+}
+
+// ---- residual row into LDS (both selection kernels) -------------------------------------------------
+// r[i] = W[row,i] - W0[row,i] (or W[row,i]); dot / nn: this thread's partial sums of w*bw*s^2 and bw^2*s^2
+// over its elements i = tid, tid+256, ... in ascending order. Eight elements per thread per round, every
+// load of a round issued before the first use and no branch around a load (clamped addresses): three
+// memory round trips per round (weights + inv, then the h2 gather) instead of three per element.
+template <int DT>
+__device__ __forceinline__ void load_residual_row(const DenseView & W, const BaseView & base, bool has_base,
+                                                  const float * __restrict__ ws, int64_t row, float * r,
+                                                  double & dot, double & nn) {
+    constexpr int U = 8;
+    const int n_in = (int) W.n_in, tid = threadIdx.x;
+    for (int i0 = 0; i0 < n_in; i0 += 256 * U) {
+        int ic[U];
+        float w[U], bw[U], s1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * 256 + tid;
+            ic[u] = i < n_in ? i : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) w[u] = dense_at<DT>(W, row, ic[u]);
+        if (has_base) {
+            int j[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) j[u] = base.inv[base_inv_index(base, (int) row, ic[u])];
+#pragma unroll
+            for (int u = 0; u < U; ++u) bw[u] = base.h2[base_h2_index(base, (int) row, ic[u], j[u])];
+        }
+        if (ws) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) s1[u] = ws[ic[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * 256 + tid;
+            if (i < n_in) {
+                if (has_base) {
+                    r[i] = w[u] - bw[u];
+                    const double sd = ws ? (double) s1[u] : 1.0;
+                    dot += (double) w[u] * (double) bw[u] * sd * sd;
+                    nn  += (double) bw[u] * (double) bw[u] * sd * sd;
+                } else {
+                    r[i] = w[u];
+                }
+            }
+        }
+    }
 }
 
 // ---- kernel: base fit accumulation ---------------------------------------------------------------------
@@ -209,18 +263,7 @@ void scan_select_coo_kernel(DenseView W, BaseView base, int has_base, int K, int
     const int tid = threadIdx.x;
 
     double dot = 0.0, nn = 0.0;
-    for (int i = tid; i < n_in; i += 256) {
-        const float w = dense_at<DT>(W, row, i);
-        if (has_base) {
-            const float bw = base_weight(base, row, i);
-            r[i] = w - bw;
-            const double s1 = ws ? (double) ws[i] : 1.0;
-            dot += (double) w * (double) bw * s1 * s1;
-            nn  += (double) bw * (double) bw * s1 * s1;
-        } else {
-            r[i] = w;
-        }
-    }
+    load_residual_row<DT>(W, base, has_base != 0, ws, row, r, dot, nn);
     __syncthreads();
     // the score is |r| (times the imatrix scale, one fp32 product, sd_eval.cpp:53-56); keys are its bits
     auto key_of = [&](int i) -> uint32_t {
@@ -293,10 +336,31 @@ void scan_select_coo_kernel(DenseView W, BaseView base, int has_base, int K, int
     for (int i = K + tid; i < Kpad; i += 256) sbuf[i] = 0;
     __syncthreads();
 
-    bitonic_desc(Kpad, [&](int a, int b, bool desc) {
-        const uint64_t x = sbuf[a], y = sbuf[b];
-        if (desc ? (x < y) : (x > y)) { sbuf[a] = y; sbuf[b] = x; }
-    });
+    // bitonic sort, descending; a thread's pairs of one stage are disjoint, so their loads are issued
+    // together (four LDS round trips per stage become one)
+    for (int k = 2; k <= Kpad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t0 = 0; t0 < (Kpad >> 1); t0 += 256 * 4) {
+                uint64_t x[4], y[4];
+                int ia[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = t0 + u * 256 + tid;
+                    const int tc = t < (Kpad >> 1) ? t : 0;
+                    ia[u] = ((tc & ~(j - 1)) << 1) | (tc & (j - 1));
+                    x[u] = sbuf[ia[u]];
+                    y[u] = sbuf[ia[u] | j];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = t0 + u * 256 + tid;
+                    const bool desc = (ia[u] & k) == 0;
+                    if (t < (Kpad >> 1) && (desc ? (x[u] < y[u]) : (x[u] > y[u]))) { sbuf[ia[u]] = y[u]; sbuf[ia[u] | j] = x[u]; }
+                }
+            }
+            __syncthreads();
+        }
+    }
 
     double dot2 = 0.0, nn2 = 0.0;
     for (int rr = tid; rr < K; rr += 256) {
@@ -334,18 +398,7 @@ void scan_select_block_kernel(DenseView W, BaseView base, int has_base, int bloc
     const int tid = threadIdx.x;
 
     double dot = 0.0, nn = 0.0;
-    for (int i = tid; i < n_in; i += 256) {
-        const float w = dense_at<DT>(W, row, i);
-        if (has_base) {
-            const float bw = base_weight(base, row, i);
-            r[i] = w - bw;
-            const double s1 = ws ? (double) ws[i] : 1.0;
-            dot += (double) w * (double) bw * s1 * s1;
-            nn  += (double) bw * (double) bw * s1 * s1;
-        } else {
-            r[i] = w;
-        }
-    }
+    load_residual_row<DT>(W, base, has_base != 0, ws, row, r, dot, nn);
     __syncthreads();
     for (int b = tid; b < NBpad; b += 256) {
         double e = -1.0;                                   // padding sorts last
@@ -831,7 +884,7 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
             return SDH_ERR_INVALID;
         }
         if (p.base_mode == 2) (void) plan_fit(s.rng, n_in, n_out, L, B, p.base_max_samples, p.base_perm_trials);
-        bv.h2 = s.h2.p; bv.inv = s.inv.p; bv.L = (int) L; bv.B = (int) B; bv.tall = tall ? 1 : 0;
+        bv.h2 = s.h2.p; bv.inv = s.inv.p; bv.L = (int) L; bv.B = (int) B; bv.tall = tall ? 1 : 0; bv.log2L = 0; while ((1 << bv.log2L) < bv.L) ++bv.log2L;
     } else if (p.write_base) {
         fit_dims(n_in, n_out, &L, &B);
         if (L > 16384) { set_error("scan: base block length %lld too large", (long long) L); return SDH_ERR_UNSUPPORTED; }
@@ -884,7 +937,7 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
             (rc = s.perm1.put(s.h_perm1, st))) return rc;
         s.h_ones.assign((size_t) (L * B), 1.0f);               // D1 = I in the fit (sd_eval.cpp:450)
         if ((rc = s.d1.put(s.h_ones, st))) return rc;
-        bv.h2 = s.h2.p; bv.inv = s.inv.p; bv.L = (int) L; bv.B = (int) B; bv.tall = tall ? 1 : 0;
+        bv.h2 = s.h2.p; bv.inv = s.inv.p; bv.L = (int) L; bv.B = (int) B; bv.tall = tall ? 1 : 0; bv.log2L = 0; while ((1 << bv.log2L) < bv.L) ++bv.log2L;
         s.fit_of = (const void *) Wh;
     }
     out->L = L; out->B = B;
