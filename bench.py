@@ -55,7 +55,9 @@ def parse_args():
     ap.add_argument("--no-scan", action="store_true", help="skip the scan (candidates/s) leg")
     ap.add_argument("--no-ffn", action="store_true", help="skip the gated-FFN-block leg")
     ap.add_argument("--ffn-layers", type=int, default=16, help="distinct synthetic Mistral-7B layers rotated in the FFN-block leg")
-    ap.add_argument("--scan-layers", type=int, default=8, help="synthetic Mistral-7B layers in the scan job")
+    ap.add_argument("--scan-layers", type=int, default=32, help="synthetic Mistral-7B layers in the scan job")
+    ap.add_argument("--scan-payload-sample", type=int, default=48,
+                    help="candidates re-run with every output row selected (payload emission), reported beside the scan rate")
     ap.add_argument("--scan-threads", type=int, default=16, help="host threads preparing candidates per rank")
     ap.add_argument("--host-io", action="store_true",
                     help="also time the PCIe-inclusive boundary (host x in, host y out, one sync per call: what "
@@ -94,7 +96,9 @@ def cpu_baseline(workload: str, tokens: int, budget_s: float):
 
 
 # K schedules of policies/policy.mistral7b.base.json (gate/up 128..768, down 256..1536): two points each
-SCAN_K = {"ffn_gate": (128, 768), "ffn_up": (128, 768), "ffn_down": (256, 1536)}
+# K schedules of the reference's Mistral policy (tools/seeddelta-build/policies/policy.mistral7b.base.json:15-16,31-32,46-47)
+SCAN_K = {"ffn_gate": (128, 256, 384, 512, 640, 768), "ffn_up": (128, 256, 384, 512, 640, 768),
+          "ffn_down": (256, 512, 768, 1024, 1280, 1536)}
 MISTRAL = {"n_embd": 4096, "n_ff": 14336}
 
 
@@ -117,10 +121,14 @@ def scan_model(layer, kind):
     return np.roll(_SCAN_BASE[kind], 97 * layer, axis=0)
 
 
-def scan_variants():
+def scan_variants(metrics_only=True):
+    """metrics_only: the layer-scan / autogate use — a report entry per candidate, the builder's output
+    GGUF discarded (scripts/seeddelta-layer-scan.py), so only the rows the metric passes sample are
+    selected; the entry is bit-identical to the full selection (tests/test_gpu_scan.py)."""
     from llama_cpp_amd.scan import ScanParams
-    return {0: ScanParams(scheme="coo", base=False, row_scale=False, eval_cols=64, eval_x=32),          # proxy on
-            1: ScanParams(scheme="coo", base=True, row_scale=True, eval_cols=64, eval_x=32, base_perm_trials=4)}
+    return {0: ScanParams(scheme="coo", base=False, row_scale=False, eval_cols=64, eval_x=32, metrics_only=metrics_only),   # proxy on
+            1: ScanParams(scheme="coo", base=True, row_scale=True, eval_cols=64, eval_x=32, base_perm_trials=4,
+                          metrics_only=metrics_only)}
 
 
 def run_scan(args, rank, world, dev):
@@ -172,6 +180,16 @@ def run_scan(args, rank, world, dev):
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if os.environ.get("SDH_BENCH_ONE_DEVICE") == "1" else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    # the same pipeline with every output row selected (what build_run needs to write a GGUF), on a sample
+    payload = None
+    if rank == 0 and args.scan_payload_sample > 0 and mine:
+        full = scan_variants(metrics_only=False)
+        sample = mine[:: max(1, len(mine) // args.scan_payload_sample)][: args.scan_payload_sample]
+        ev.run_many(sample[:2], threads=2, params_of=lambda c: full[c.variant])
+        t1 = time.perf_counter()
+        ev.run_many(sample, threads=args.scan_threads, params_of=lambda c: full[c.variant])
+        payload = {"value": len(sample) / (time.perf_counter() - t1), "unit": "candidates/s", "candidates": len(sample),
+                   "note": "every output row selected and kept on the device (payload emission), rank 0 only"}
     ev.close()
     assert len(allr) == len(cands)
     # algorithmic bytes per candidate: the quantised tensor read once + idx/val/row_scale emitted
@@ -181,10 +199,14 @@ def run_scan(args, rank, world, dev):
            "scaling": "strong", "candidates": len(cands), "seconds": elapsed,
            "roofline": {"bound": "hbm", "achieved": alg / elapsed / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                         "frac": alg / elapsed / 1e9 / (HBM_PEAK_GBS * world), "traffic": None,
-                        "note": "whole-pipeline rate (host sample drawing included), not one kernel: the scan is "
-                                "bound by per-row selection and host RNG, not by the weight stream"},
-           "config": {"workload": f"cfg5 subset: {args.scan_layers} synthetic Mistral-7B layers x gate/up/down x "
-                                  f"K {SCAN_K} x {{coo no-base + proxy, coo base + row_scale}}, eval_cols=64 eval_x=32, Q8_0",
+                        "note": "whole-pipeline, work-equivalent rate: bytes are those of the reference algorithm per candidate "
+                                "(SURVEY 8d: the quantised tensor read once + emitted payload); the metrics-only path reads only "
+                                "the sampled rows and the fit samples, and the pipeline is bound by host sample drawing "
+                                "(libstdc++ mt19937 / normal_distribution, bit-identical streams), not by the weight stream"},
+           "with_payload_emission": payload,
+           "config": {"workload": f"cfg5: {args.scan_layers} synthetic Mistral-7B layers x gate/up/down x "
+                                  f"K {SCAN_K} x {{coo no-base + proxy, coo base + row_scale}}, eval_cols=64 eval_x=32, Q8_0; "
+                                  "report entries only (metrics_only: rows the metric passes sample)",
                       "host_threads_per_rank": args.scan_threads, "dense_bytes_resident_per_rank": dense_bytes,
                       "collective": "one all_gather of %d-double records" % SC.RECORD_LEN}}
     return out

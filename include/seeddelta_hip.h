@@ -234,6 +234,12 @@ typedef struct sdh_scan_params {
     const float * w_scale;      /* host, n_in floats or NULL: the imatrix scale of sdh_imatrix_scale(); when
                                    set the fit, the selection scores and the row scale are weighted and the
                                    _w / _x_w metric passes run as well (sd_build.cpp:421-422, :753-794)      */
+    int32_t metrics_only;       /* 0 = select every output row (the payload the builder writes; sdh_scan_fetch
+                                       returns it); 1 = select only the rows the metric passes sample: the report
+                                       entry is identical (eval_* and the proxy read nothing else, sd_eval.cpp:138,
+                                       :1052, sd_ffn_proxy.cpp:60-75) and no payload is kept. This is the layer-scan /
+                                       autogate use, where the builder's output GGUF is discarded.              */
+    int32_t reserved0;
 } sdh_scan_params;
 
 /* What one report.json entry is computed from (tools/seeddelta-build/sd_report.cpp:112-288). Metric

@@ -24,6 +24,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
 #include <numeric>
 #include <random>
 #include <vector>
@@ -250,6 +253,7 @@ __device__ __forceinline__ void bitonic_desc(int n, CMP swap_if_needed) {
 template <int DT>
 __global__ __launch_bounds__(256)
 void scan_select_coo_kernel(DenseView W, BaseView base, int has_base, int K, int Kpad, int want_rs,
+                            const int * __restrict__ rows_sel /* null: every row; else outputs are compact */,
                             const float * __restrict__ ws,
                             int * __restrict__ idx_out, float * __restrict__ val_out, float * __restrict__ rs_out) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -259,7 +263,8 @@ void scan_select_coo_kernel(DenseView W, BaseView base, int has_base, int K, int
     uint32_t * hist = (uint32_t *) (sbuf + Kpad);
     double *   dsc  = (double *) (hist + 256);       // 4 doubles
     int *      isc  = (int *) (dsc + 4);             // 8 ints
-    const int64_t row = blockIdx.x;
+    const int64_t row = rows_sel ? rows_sel[blockIdx.x] : blockIdx.x;      // weight row
+    const int64_t orow = blockIdx.x;                                       // output slot
     const int tid = threadIdx.x;
 
     double dot = 0.0, nn = 0.0;
@@ -365,8 +370,8 @@ void scan_select_coo_kernel(DenseView W, BaseView base, int has_base, int K, int
     double dot2 = 0.0, nn2 = 0.0;
     for (int rr = tid; rr < K; rr += 256) {
         const int i = (int) (0xffffffffu - (uint32_t) sbuf[rr]);
-        idx_out[row * K + rr] = i;
-        val_out[row * K + rr] = r[i];
+        idx_out[orow * K + rr] = i;
+        val_out[orow * K + rr] = r[i];
         if (want_rs) {
             const double wi = (double) dense_at<DT>(W, row, i), di = (double) r[i];
             const double s1 = ws ? (double) ws[i] : 1.0;
@@ -377,7 +382,7 @@ void scan_select_coo_kernel(DenseView W, BaseView base, int has_base, int K, int
     if (want_rs) {
         const double d_all = block_sum(dot, dsc) + block_sum(dot2, dsc);
         const double n_all = block_sum(nn, dsc) + block_sum(nn2, dsc);
-        if (tid == 0) rs_out[row] = n_all > 1e-30 ? (float) (d_all / n_all) : 1.0f;
+        if (tid == 0) rs_out[orow] = n_all > 1e-30 ? (float) (d_all / n_all) : 1.0f;
     }
 }
 
@@ -386,7 +391,7 @@ void scan_select_coo_kernel(DenseView W, BaseView base, int has_base, int K, int
 template <int DT>
 __global__ __launch_bounds__(256)
 void scan_select_block_kernel(DenseView W, BaseView base, int has_base, int block, int keep, int n_blocks, int NBpad,
-                              int want_rs, const float * __restrict__ ws,
+                              int want_rs, const int * __restrict__ rows_sel, const float * __restrict__ ws,
                               int * __restrict__ idx_out, float * __restrict__ val_out, float * __restrict__ rs_out) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int n_in = (int) W.n_in;
@@ -394,7 +399,8 @@ void scan_select_block_kernel(DenseView W, BaseView base, int has_base, int bloc
     double * en  = (double *) (smem + (((size_t) n_in * 4 + 15) & ~(size_t) 15));
     int *    bid = (int *) (en + NBpad);
     double * dsc = (double *) (bid + NBpad + (NBpad & 1));
-    const int64_t row = blockIdx.x;
+    const int64_t row = rows_sel ? rows_sel[blockIdx.x] : blockIdx.x;
+    const int64_t orow = blockIdx.x;
     const int tid = threadIdx.x;
 
     double dot = 0.0, nn = 0.0;
@@ -426,7 +432,7 @@ void scan_select_block_kernel(DenseView W, BaseView base, int has_base, int bloc
         const int bi = e / block, t = e - bi * block;
         const int blk = bid[bi];
         const int i = blk * block + t;
-        if (t == 0) idx_out[row * keep + bi] = blk;
+        if (t == 0) idx_out[orow * keep + bi] = blk;
         float v = 0.0f;
         if (i < n_in) {
             v = r[i];
@@ -437,12 +443,12 @@ void scan_select_block_kernel(DenseView W, BaseView base, int has_base, int bloc
                 else          { dot2 += wi * wi * s1 * s1; nn2 += wi * wi * s1 * s1; }
             }
         }
-        val_out[((size_t) row * keep + bi) * block + t] = v;
+        val_out[((size_t) orow * keep + bi) * block + t] = v;
     }
     if (want_rs) {
         const double d_all = block_sum(dot, dsc) + block_sum(dot2, dsc);
         const double n_all = block_sum(nn, dsc) + block_sum(nn2, dsc);
-        if (tid == 0) rs_out[row] = n_all > 1e-30 ? (float) (d_all / n_all) : 1.0f;
+        if (tid == 0) rs_out[orow] = n_all > 1e-30 ? (float) (d_all / n_all) : 1.0f;
     }
 }
 
@@ -451,11 +457,13 @@ template <int DT>
 __global__ __launch_bounds__(256)
 void scan_evalw_kernel(DenseView W, BaseView base, int has_base, int scheme, int K, int block,
                        const int * __restrict__ idx, const float * __restrict__ val, const float * __restrict__ rs,
-                       const float * __restrict__ ws, const int * __restrict__ rows, double * __restrict__ out /* [n_rows][3] */) {
+                       const float * __restrict__ ws, const int * __restrict__ rows, int compact /* payload indexed by sample, not by row */,
+                       double * __restrict__ out /* [n_rows][3] */) {
     __shared__ double dsc[4];
     const int64_t row = rows[blockIdx.x];
+    const int64_t pr = compact ? (int64_t) blockIdx.x : row;       // payload slot of this row
     const int n_in = (int) W.n_in;
-    const double scale = rs ? (double) rs[row] : 1.0;
+    const double scale = rs ? (double) rs[pr] : 1.0;
     double wn = 0.0, hn = 0.0, dt = 0.0;
     for (int i = threadIdx.x; i < n_in; i += 256) {
         const double s1 = ws ? (double) ws[i] : 1.0;
@@ -473,16 +481,16 @@ void scan_evalw_kernel(DenseView W, BaseView base, int has_base, int scheme, int
         float dv;
         if (scheme == 1) {
             const int bi = e / block, t = e - bi * block;
-            const int blk = idx[row * K + bi];
+            const int blk = idx[pr * K + bi];
             if (blk < 0) continue;
             i = (int64_t) blk * block + t;
             if (i >= n_in) continue;
-            dv = val[((size_t) row * K + bi) * block + t];
+            dv = val[((size_t) pr * K + bi) * block + t];
         } else {
-            const int ii = idx[row * K + e];
+            const int ii = idx[pr * K + e];
             if (ii < 0 || ii >= n_in) continue;
             i = ii;
-            dv = val[row * K + e];
+            dv = val[pr * K + e];
         }
         const double s1 = ws ? (double) ws[i] : 1.0;
         if (has_base) {
@@ -524,26 +532,27 @@ __global__ __launch_bounds__(256)
 void scan_delta_dot_kernel(int n_in, int scheme, int K, int block, const int * __restrict__ idx,
                            const float * __restrict__ val, const float * __restrict__ rs,
                            const float * __restrict__ v, int L, int B, int tall,
-                           const int * __restrict__ rows, int n_rows, const float * __restrict__ xs,
+                           const int * __restrict__ rows, int n_rows, int compact, const float * __restrict__ xs,
                            double * __restrict__ out /* [n_x][n_rows] */) {
     __shared__ double dsc[4];
     const int ci = blockIdx.x, xi = blockIdx.y;
     const int64_t row = rows[ci];
+    const int64_t pr = compact ? (int64_t) ci : row;
     const float * x = xs + (size_t) xi * n_in;
     double acc = 0.0;
     const int n_ent = scheme == 1 ? K * block : K;
     for (int e = threadIdx.x; e < n_ent; e += 256) {
         if (scheme == 1) {
             const int bi = e / block, t = e - bi * block;
-            const int blk = idx[row * K + bi];
+            const int blk = idx[pr * K + bi];
             if (blk < 0) continue;
             const int64_t i = (int64_t) blk * block + t;
             if (i >= n_in) continue;
-            acc += (double) val[((size_t) row * K + bi) * block + t] * (double) x[i];
+            acc += (double) val[((size_t) pr * K + bi) * block + t] * (double) x[i];
         } else {
-            const int ii = idx[row * K + e];
+            const int ii = idx[pr * K + e];
             if (ii < 0 || ii >= n_in) continue;
-            acc += (double) val[row * K + e] * (double) x[ii];
+            acc += (double) val[pr * K + e] * (double) x[ii];
         }
     }
     acc = block_sum(acc, dsc);
@@ -560,7 +569,7 @@ void scan_delta_dot_kernel(int n_in, int scheme, int K, int block, const int * _
                 y0 = (double) s;
             }
         }
-        out[(size_t) xi * n_rows + ci] = (y0 + acc) * (rs ? (double) rs[row] : 1.0);
+        out[(size_t) xi * n_rows + ci] = (y0 + acc) * (rs ? (double) rs[pr] : 1.0);
     }
 }
 
@@ -599,6 +608,7 @@ struct Scan {
     // last candidate
     int64_t n_in = 0, n_out = 0, K = 0, block = 0, L = 0, B = 0;
     int scheme = 0; bool has_base = false, has_rs = false;
+    bool emitted = false;               // the last candidate selected every row (sdh_scan_fetch can return the payload)
     const void * fit_of = nullptr;      // the dense handle the current fit belongs to
     DevBuf<int> idx; DevBuf<float> val; DevBuf<float> rs;
     DevBuf<float> h2, d2, d1; DevBuf<int> inv, perm1;
@@ -661,6 +671,43 @@ static std::vector<int> draw_rows(std::mt19937 & rng, int64_t n_out, int64_t wan
     std::shuffle(all.begin(), all.end(), rng);
     all.resize((size_t) std::min(want, n_out));
     return std::vector<int>(all.begin(), all.end());
+}
+
+// n draws of std::normal_distribution<float>(0,1) from rng, memoised on the generator state. The
+// evaluators draw eval_x * n_in Gaussians per pass (sd_eval.cpp:1084-1087, sd_ffn_proxy.cpp:77-80) at
+// ~26 ns each, and the stream position they start from depends only on the seed and the tensor shapes:
+// not on the layer, not on K. Across a sweep the same (state, n) recurs for every layer and every K of
+// a tensor kind, so the draws — identical by construction — are made once and the generator is moved
+// to the state it would have reached. Lookups compare the full mt19937 state (operator==).
+struct NormalMemo {
+    std::mt19937 before, after;
+    int64_t n;
+    std::shared_ptr<const std::vector<float>> vals;
+};
+static std::mutex g_memo_mu;
+static std::deque<NormalMemo> g_memo;
+
+static std::shared_ptr<const std::vector<float>> draw_normals(std::mt19937 & rng, int64_t n) {
+    {
+        std::lock_guard<std::mutex> lock(g_memo_mu);
+        for (const NormalMemo & m : g_memo) {
+            if (m.n == n && m.before == rng) { rng = m.after; return m.vals; }
+        }
+    }
+    NormalMemo m;
+    m.before = rng;
+    m.n = n;
+    auto v = std::make_shared<std::vector<float>>((size_t) n);
+    std::normal_distribution<float> nd(0.0f, 1.0f);
+    for (int64_t i = 0; i < n; ++i) (*v)[(size_t) i] = nd(rng);
+    m.after = rng;
+    m.vals = v;
+    {
+        std::lock_guard<std::mutex> lock(g_memo_mu);
+        g_memo.push_back(m);
+        while (g_memo.size() > 96) g_memo.pop_front();
+    }
+    return v;
 }
 
 // RNG consumption of the base fit (sd_eval.cpp:557-651), with or without the work
@@ -842,8 +889,7 @@ int sdh_scan_skip(sdh_scan * h, int64_t n_in, int64_t n_out, const sdh_scan_para
     for (int k = 0; k < passes && p->eval_cols > 0; ++k) (void) draw_rows(s.rng, n_out, p->eval_cols);
     for (int k = 0; k < passes && p->eval_cols > 0 && p->eval_x > 0; ++k) {
         (void) draw_rows(s.rng, n_out, p->eval_cols);
-        std::normal_distribution<float> nd(0.0f, 1.0f);
-        for (int64_t j = 0; j < p->eval_x * n_in; ++j) (void) nd(s.rng);
+        (void) draw_normals(s.rng, p->eval_x * n_in);
     }
     return SDH_OK;
 }
@@ -946,39 +992,55 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
     if (!p.write_base) s.fit_of = nullptr;
 
     // ---- selection ------------------------------------------------------------------------------------
-    const size_t n_val = (size_t) n_out * (size_t) K_eff;
-    if ((rc = s.idx.ensure((size_t) n_out * (size_t) Ksel)) || (rc = s.val.ensure(n_val)) || (rc = s.rs.ensure((size_t) n_out))) return rc;
+    // select(rows_dev, n_sel): rows_dev == null selects every output row into [n_out] slots (the payload);
+    // otherwise only the listed rows, into compact slots [n_sel] in list order (metrics_only)
+    const bool metrics_only = p.metrics_only != 0;
+    const int compact = metrics_only ? 1 : 0;
     const size_t r_bytes = ((size_t) n_in * 4 + 15) & ~(size_t) 15;
-    if (p.scheme == 0) {
-        int Kpad = 2;
-        while (Kpad < K_eff) Kpad <<= 1;
-        const size_t lds = r_bytes + (size_t) Kpad * 8 + 256 * 4 + 4 * 8 + 8 * 4;
-        if (lds > 160 * 1024) {
-            set_error("scan: n_in=%lld with K=%lld needs %zu B of LDS (max 163840)", (long long) n_in, (long long) K_eff, lds);
-            return SDH_ERR_UNSUPPORTED;
+    static const bool lds_attr_set = [] {
+        bool ok = true;
+        ok &= hipFuncSetAttribute((const void *) scan_select_coo_kernel<SDH_TYPE_Q8_0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        ok &= hipFuncSetAttribute((const void *) scan_select_coo_kernel<SDH_TYPE_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        ok &= hipFuncSetAttribute((const void *) scan_select_coo_kernel<SDH_TYPE_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        ok &= hipFuncSetAttribute((const void *) scan_select_block_kernel<SDH_TYPE_Q8_0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        ok &= hipFuncSetAttribute((const void *) scan_select_block_kernel<SDH_TYPE_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        ok &= hipFuncSetAttribute((const void *) scan_select_block_kernel<SDH_TYPE_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        return ok;
+    }();
+    if (!lds_attr_set) { set_error("scan: raising the dynamic LDS limit failed"); return SDH_ERR_HIP; }
+    auto select = [&](const int * rows_dev, int64_t n_sel) -> int {
+        int rc2;
+        if ((rc2 = s.idx.ensure((size_t) n_sel * (size_t) Ksel)) || (rc2 = s.val.ensure((size_t) n_sel * (size_t) K_eff)) ||
+            (rc2 = s.rs.ensure((size_t) n_sel))) return rc2;
+        if (n_sel <= 0) return SDH_OK;
+        if (p.scheme == 0) {
+            int Kpad = 2;
+            while (Kpad < K_eff) Kpad <<= 1;
+            const size_t lds = r_bytes + (size_t) Kpad * 8 + 256 * 4 + 4 * 8 + 8 * 4;
+            if (lds > 160 * 1024) {
+                set_error("scan: n_in=%lld with K=%lld needs %zu B of LDS (max 163840)", (long long) n_in, (long long) K_eff, lds);
+                return SDH_ERR_UNSUPPORTED;
+            }
+            SDH_LAUNCH_DT(W, scan_select_coo_kernel, dim3((unsigned) n_sel), dim3(256), lds, st, W, bv, p.write_base ? 1 : 0,
+                          (int) K_eff, Kpad, p.write_row_scale ? 1 : 0, rows_dev, ws_dev, s.idx.p, s.val.p, s.rs.p);
+        } else {
+            const int64_t n_blocks = (n_in + p.block - 1) / p.block;
+            int NBpad = 2;
+            while (NBpad < n_blocks) NBpad <<= 1;
+            const size_t lds = r_bytes + (size_t) NBpad * 8 + (size_t) (NBpad + (NBpad & 1)) * 4 + 4 * 8;
+            if (lds > 160 * 1024) {
+                set_error("scan: n_in=%lld block=%lld needs %zu B of LDS (max 163840)", (long long) n_in, (long long) p.block, lds);
+                return SDH_ERR_UNSUPPORTED;
+            }
+            SDH_LAUNCH_DT(W, scan_select_block_kernel, dim3((unsigned) n_sel), dim3(256), lds, st, W, bv, p.write_base ? 1 : 0,
+                          (int) p.block, (int) keep, (int) n_blocks, NBpad, p.write_row_scale ? 1 : 0, rows_dev, ws_dev, s.idx.p, s.val.p, s.rs.p);
         }
-        SDH_HIP_CHECK(hipFuncSetAttribute((const void *) scan_select_coo_kernel<SDH_TYPE_Q8_0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SDH_HIP_CHECK(hipFuncSetAttribute((const void *) scan_select_coo_kernel<SDH_TYPE_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SDH_HIP_CHECK(hipFuncSetAttribute((const void *) scan_select_coo_kernel<SDH_TYPE_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SDH_LAUNCH_DT(W, scan_select_coo_kernel, dim3((unsigned) n_out), dim3(256), lds, st, W, bv, p.write_base ? 1 : 0,
-                           (int) K_eff, Kpad, p.write_row_scale ? 1 : 0, ws_dev, s.idx.p, s.val.p, s.rs.p);
-    } else {
-        const int64_t n_blocks = (n_in + p.block - 1) / p.block;
-        int NBpad = 2;
-        while (NBpad < n_blocks) NBpad <<= 1;
-        const size_t lds = r_bytes + (size_t) NBpad * 8 + (size_t) (NBpad + (NBpad & 1)) * 4 + 4 * 8;
-        if (lds > 160 * 1024) {
-            set_error("scan: n_in=%lld block=%lld needs %zu B of LDS (max 163840)", (long long) n_in, (long long) p.block, lds);
-            return SDH_ERR_UNSUPPORTED;
-        }
-        SDH_HIP_CHECK(hipFuncSetAttribute((const void *) scan_select_block_kernel<SDH_TYPE_Q8_0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SDH_HIP_CHECK(hipFuncSetAttribute((const void *) scan_select_block_kernel<SDH_TYPE_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SDH_HIP_CHECK(hipFuncSetAttribute((const void *) scan_select_block_kernel<SDH_TYPE_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SDH_LAUNCH_DT(W, scan_select_block_kernel, dim3((unsigned) n_out), dim3(256), lds, st, W, bv, p.write_base ? 1 : 0,
-                           (int) p.block, (int) keep, (int) n_blocks, NBpad, p.write_row_scale ? 1 : 0, ws_dev, s.idx.p, s.val.p, s.rs.p);
-    }
-    SDH_HIP_CHECK(hipGetLastError());
-    const float * rs_dev = p.write_row_scale ? s.rs.p : nullptr;
+        SDH_HIP_CHECK(hipGetLastError());
+        return SDH_OK;
+    };
+    s.emitted = !metrics_only;
+    if (!metrics_only && (rc = select(nullptr, n_out))) return rc;
+    const float * rs_dev = nullptr;      // set once s.rs is allocated (select() may move it)
 
     // ---- cost model (sd_cost.cpp:7-40) --------------------------------------------------------------
     {
@@ -1001,8 +1063,10 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
         const int nr = (int) rows.size();
         int rc2;
         if ((rc2 = s.rows.put(rows, st)) || (rc2 = s.dbl.ensure((size_t) nr * 3))) return rc2;
+        if (metrics_only && (rc2 = select(s.rows.p, nr))) return rc2;
+        rs_dev = p.write_row_scale ? s.rs.p : nullptr;
         SDH_LAUNCH_DT(W, scan_evalw_kernel, dim3((unsigned) nr), dim3(256), 0, st, W, bv, p.write_base ? 1 : 0, p.scheme,
-                           (int) Ksel, (int) s.block, s.idx.p, s.val.p, rs_dev, ws, s.rows.p, s.dbl.p);
+                           (int) Ksel, (int) s.block, s.idx.p, s.val.p, rs_dev, ws, s.rows.p, compact, s.dbl.p);
         SDH_HIP_CHECK(hipGetLastError());
         std::vector<double> tr((size_t) nr * 3);
         SDH_HIP_CHECK(hipMemcpyAsync(tr.data(), s.dbl.p, tr.size() * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1016,13 +1080,15 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
         std::vector<int> rows = draw_rows(s.rng, n_out, p.eval_cols);
         const int nr = (int) rows.size();
         const int nx = (int) p.eval_x;
-        std::vector<float> xs((size_t) nx * (size_t) n_in);
-        std::normal_distribution<float> nd(0.0f, 1.0f);
-        for (int xi = 0; xi < nx; ++xi)
-            for (int64_t i = 0; i < n_in; ++i) {
-                const float sc = x_scale_host ? x_scale_host[i] : 1.0f;
-                xs[(size_t) xi * (size_t) n_in + (size_t) i] = nd(s.rng) * sc;           // sd_eval.cpp:1084-1087
-            }
+        const std::shared_ptr<const std::vector<float>> gauss = draw_normals(s.rng, (int64_t) nx * n_in);
+        std::vector<float> scaled;
+        if (x_scale_host) {
+            scaled.resize(gauss->size());
+            for (int xi = 0; xi < nx; ++xi)
+                for (int64_t i = 0; i < n_in; ++i)
+                    scaled[(size_t) xi * (size_t) n_in + (size_t) i] = (*gauss)[(size_t) xi * (size_t) n_in + (size_t) i] * x_scale_host[i];   // sd_eval.cpp:1084-1087
+        }
+        const std::vector<float> & xs = x_scale_host ? scaled : *gauss;
         int rc2;
         if ((rc2 = s.rows.put(rows, st)) || (rc2 = s.xs.put(xs, st)) || (rc2 = s.dbl.ensure((size_t) nr * nx)) ||
             (rc2 = s.dbl2.ensure((size_t) nr * nx))) return rc2;
@@ -1033,10 +1099,12 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
                                                  s.perm1.p, nullptr, nx, s.v.p, st))) return rc2;
             vdev = s.v.p;
         }
+        if (metrics_only && (rc2 = select(s.rows.p, nr))) return rc2;
+        rs_dev = p.write_row_scale ? s.rs.p : nullptr;
         SDH_LAUNCH_DT(W, scan_dense_dot_kernel, dim3((unsigned) nr, (unsigned) nx), dim3(256), 0, st, W, s.rows.p, nr, s.xs.p, s.dbl.p);
         hipLaunchKernelGGL(scan_delta_dot_kernel, dim3((unsigned) nr, (unsigned) nx), dim3(256), 0, st, (int) n_in, p.scheme,
                            (int) Ksel, (int) s.block, s.idx.p, s.val.p, rs_dev, vdev, (int) L, (int) B, tall ? 1 : 0,
-                           s.rows.p, nr, s.xs.p, s.dbl2.p);
+                           s.rows.p, nr, compact, s.xs.p, s.dbl2.p);
         SDH_HIP_CHECK(hipGetLastError());
         std::vector<double> yt((size_t) nr * nx), yh((size_t) nr * nx);
         SDH_HIP_CHECK(hipMemcpyAsync(yt.data(), s.dbl.p, yt.size() * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1075,17 +1143,17 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
         std::vector<int> hid = draw_rows(prng, n_hidden, std::min(n_hidden, cap));
         std::vector<int> outs = draw_rows(prng, n_o, std::min(n_o, cap));
         const int nh = (int) hid.size(), no = (int) outs.size();
-        std::vector<float> xs((size_t) nx * (size_t) G.n_in);
-        std::normal_distribution<float> nd(0.0f, 1.0f);
-        for (float & x : xs) x = nd(prng);
+        const std::shared_ptr<const std::vector<float>> pxs = draw_normals(prng, (int64_t) nx * G.n_in);
+        const std::vector<float> & xs = *pxs;
         if ((rc = s.rows.put(hid, st)) || (rc = s.cols.put(outs, st)) || (rc = s.xs.put(xs, st)) ||
             (rc = s.dbl.ensure((size_t) nh * nx * 2)) || (rc = s.dbl2.ensure((size_t) nh * nx)) ||
             (rc = s.gat.ensure((size_t) no * nh))) return rc;
+        if (metrics_only && (rc = select(s.rows.p, nh))) return rc;     // the replaced tensor's sampled hidden rows
         SDH_LAUNCH_DT(G, scan_dense_dot_kernel, dim3((unsigned) nh, (unsigned) nx), dim3(256), 0, st, G, s.rows.p, nh, s.xs.p, s.dbl.p);
         SDH_LAUNCH_DT(U, scan_dense_dot_kernel, dim3((unsigned) nh, (unsigned) nx), dim3(256), 0, st, U, s.rows.p, nh, s.xs.p,
                            s.dbl.p + (size_t) nh * nx);
         hipLaunchKernelGGL(scan_delta_dot_kernel, dim3((unsigned) nh, (unsigned) nx), dim3(256), 0, st, (int) n_in, 0, (int) Ksel, 1,
-                           s.idx.p, s.val.p, (const float *) nullptr, (const float *) nullptr, 0, 0, 1, s.rows.p, nh, s.xs.p, s.dbl2.p);
+                           s.idx.p, s.val.p, (const float *) nullptr, (const float *) nullptr, 0, 0, 1, s.rows.p, nh, compact, s.xs.p, s.dbl2.p);
         // W_down[out rows][hidden cols]
         SDH_LAUNCH_DT(D, scan_gather_kernel, dim3((unsigned) ((no * nh + 255) / 256)), dim3(256), 0, st, D, s.cols.p, no, s.rows.p, nh, s.gat.p);
         SDH_HIP_CHECK(hipGetLastError());
@@ -1142,6 +1210,10 @@ int sdh_scan_fetch(sdh_scan * h, int32_t * idx, float * val, float * row_scale,
     if (s.n_out <= 0) { set_error("sdh_scan_fetch: no candidate evaluated yet"); return SDH_ERR_INVALID; }
     hipStream_t st = s.stream;
     const size_t n_idx = (size_t) s.n_out * (size_t) s.K;
+    if ((idx || val || row_scale) && !s.emitted) {
+        set_error("sdh_scan_fetch: the candidate was evaluated with metrics_only, no payload was kept");
+        return SDH_ERR_INVALID;
+    }
     if (idx) SDH_HIP_CHECK(hipMemcpyAsync(idx, s.idx.p, n_idx * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     if (val) SDH_HIP_CHECK(hipMemcpyAsync(val, s.val.p, n_idx * (size_t) s.block * sizeof(float), hipMemcpyDeviceToHost, st));
     if (row_scale) {

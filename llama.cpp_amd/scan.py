@@ -85,6 +85,8 @@ class ScanParams:
     metric: str = "cos"            # policy gating metric
     w_scale: Optional[np.ndarray] = None   # imatrix scale for this tensor (imatrix_scale()); None = no imatrix
     base_mode: int = 0             # 0 fit; 1 reuse the previous fit, no draws; 2 reuse it, replay its draws
+    metrics_only: bool = False     # select only the rows the metric passes sample: same report entry, no payload
+                                   # to fetch (what layer-scan / autogate need; build_run keeps the full selection)
 
     def c_struct(self, kind: str, layer: int) -> sd.SdhScanParams:
         p = sd.SdhScanParams()
@@ -97,6 +99,7 @@ class ScanParams:
         p.eval_cols, p.eval_x = self.eval_cols, self.eval_x
         p.proxy_seed = self.seed + layer * 101 + KIND_ID[kind] + 1        # sd_build.cpp:1032
         p.base_mode = self.base_mode if self.base else 0
+        p.metrics_only = int(self.metrics_only)
         if self.w_scale is not None:
             self._ws = np.ascontiguousarray(self.w_scale, dtype=np.float32)   # kept alive for the call
             p.w_scale = self._ws.ctypes.data

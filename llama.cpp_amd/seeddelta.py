@@ -54,7 +54,8 @@ class SdhScanParams(C.Structure):
     _fields_ = [("scheme", C.c_int32), ("kind", C.c_int32), ("K", C.c_int64), ("block", C.c_int64),
                 ("write_base", C.c_int32), ("write_row_scale", C.c_int32), ("base_max_samples", C.c_int64),
                 ("base_perm_trials", C.c_int32), ("want_proxy", C.c_int32), ("eval_cols", C.c_int64),
-                ("eval_x", C.c_int64), ("proxy_seed", C.c_int32), ("base_mode", C.c_int32), ("w_scale", C.c_void_p)]
+                ("eval_x", C.c_int64), ("proxy_seed", C.c_int32), ("base_mode", C.c_int32), ("w_scale", C.c_void_p),
+                ("metrics_only", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class SdhScanResult(C.Structure):

@@ -358,3 +358,41 @@ def test_build_run_follows_the_builder_control_flow(hip):
         em_x = o.eval_x(Wnp, fit, 0, idx, val, e["K"], 32, rs, 16, 4)
         assert e["cos_mean"] == pytest.approx(em[2], rel=2e-6) and e["rel_l2_p95"] == pytest.approx(em[1], rel=2e-6)
         assert e["cos_p05_x"] == pytest.approx(em_x[3], rel=2e-6)
+
+
+@pytest.mark.parametrize("name", scan_golden_names())
+def test_metrics_only_gives_the_same_report_entry(hip, name):
+    """metrics_only selects just the rows the metric passes sample: every number of the report entry is
+    bit-identical to the full selection (same rows, same kernels, same order), the RNG stream ends in
+    the same place, and no payload is kept."""
+    from llama_cpp_amd.seeddelta import SeedDeltaError
+    g = load_scan_golden(name)
+    s_full, p, res_full, W = run_gpu(g)
+    ws = {k: SC.DenseWeight(g[k]) for k in ("Wg", "Wu", "Wd") if k in g}
+    Wm = ws[("Wg", "Wu", "Wd")[g["kind"]]]
+    pm = SC.ScanParams(**{**p.__dict__, "metrics_only": True})
+    s = SC.ScanSession(g["seed"])
+    res = s.tensor(Wm, pm, KIND[g["kind"]], g["layer"], (ws["Wg"], ws["Wu"], ws["Wd"]) if len(ws) == 3 else None)
+    for k in ("em", "em_x", "cost", "proxy"):
+        assert np.array_equal(np.asarray(res[k]).view(np.uint64), np.asarray(res_full[k]).view(np.uint64)), k
+    assert res["proxy_available"] == res_full["proxy_available"] and res["K_eff"] == res_full["K_eff"]
+    # both sessions drew the same samples: a follow-up candidate agrees bit for bit as well
+    nxt = SC.ScanParams(scheme="coo", K=8, eval_cols=8, eval_x=2, seed=g["seed"], metrics_only=True)
+    a = s.tensor(Wm, nxt, KIND[g["kind"]], g["layer"], None)
+    b = s_full.tensor(W, nxt, KIND[g["kind"]], g["layer"], None)
+    assert np.array_equal(np.asarray(a["em_x"]).view(np.uint64), np.asarray(b["em_x"]).view(np.uint64))
+    with pytest.raises(SeedDeltaError):
+        s.fetch()
+
+
+def test_metrics_only_with_imatrix_and_block_scheme(hip):
+    rng = np.random.default_rng(5)
+    W = make_dense(1024, 1536, "q8_0", seed=9, structure=0.3)
+    im = (rng.random(1024) * 3 + 0.01).astype(np.float32)
+    dw = SC.DenseWeight(W)
+    for scheme, K, block in (("coo", 48, 16), ("block", 64, 16)):
+        kw = dict(scheme=scheme, K=K, block=block, base=True, row_scale=True, eval_cols=32, eval_x=8, w_scale=SC.imatrix_scale(im, 1024))
+        r1 = SC.ScanSession(7).tensor(dw, SC.ScanParams(**kw), "ffn_up", 3, None)
+        r2 = SC.ScanSession(7).tensor(dw, SC.ScanParams(metrics_only=True, **kw), "ffn_up", 3, None)
+        for k in ("em", "em_w", "em_x", "em_x_w"):
+            assert np.array_equal(np.asarray(r1[k]).view(np.uint64), np.asarray(r2[k]).view(np.uint64)), (scheme, k)
