@@ -98,7 +98,7 @@ void base_apply_kernel(const float * __restrict__ x, int64_t ldx, int n_in, int 
     SDH_STAMP(0);
     float * out = v + ((size_t) t * B + b) * (size_t) L;
     float y[1 << LOG_E];
-    base_transform<LOG_E, P32, false>(x + t * ldx, n_in, tall ? 0 : b * L, x_vec_ok != 0, pd, b, lds, threadIdx.x, y);
+    base_transform<BaseLay<LOG_E>, P32, false>(x + t * ldx, n_in, tall ? 0 : b * L, x_vec_ok != 0, pd, b, lds, threadIdx.x, y);
 #pragma unroll
     for (int r = 0; r < (1 << LOG_E); ++r) out[BaseLay<LOG_E>::idx(BaseLay<LOG_E>::J - 1, threadIdx.x, r)] = y[r];
     SDH_STAMP(9);

@@ -3,15 +3,15 @@
 //
 //   v_b = D3 * H * [D2 * [P2] * H] * P1 * D1 * x_b      (reference: src/llama-seeddelta.cpp:497-574)
 //
-// One workgroup of 256 threads transforms one block of L = 256 * E elements (E = 2^LOG_E per
-// thread). The FWHT runs entirely in registers: the index bits are processed LOG_E at a time, and
+// One workgroup of 2^TB threads (256 by default) transforms one block of L = 2^TB * E elements
+// (E = 2^LOG_E per thread). The FWHT runs entirely in registers: the index bits are processed LOG_E at a time, and
 // between groups the block is transposed through LDS into the layout that makes the next LOG_E
 // bits register-resident. The STAGE ORDER is the reference's (bit 0 first), every butterfly is
 // (u+v, u-v) with u the element whose bit is clear, and multiplies / adds are never contracted,
 // so the result is bit-identical to the CPU op.
 //
 // Layout j: the register index r supplies index bits [s_j, s_j + LOG_E), s_j = min(j*LOG_E, N-LOG_E);
-// the thread id supplies the other N - LOG_E = 8 bits (low part below s_j, high part above).
+// the thread id supplies the other N - LOG_E = TB bits (low part below s_j, high part above).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -40,14 +40,15 @@ __device__ unsigned long long * sdh_diag_buf;
 
 namespace sdh {
 
-template <int LOG_E>
+template <int LOG_E_, int TB_ = 8>
 struct BaseLay {
+    static constexpr int LOG_E = LOG_E_;
     static constexpr int E  = 1 << LOG_E;
-    static constexpr int TB = 8;                     // thread-id bits (256 threads)
+    static constexpr int TB = TB_;                   // thread-id bits (256 threads by default)
     static constexpr int N  = LOG_E + TB;
     static constexpr int L  = 1 << N;
     static constexpr int J  = (N + LOG_E - 1) / LOG_E;
-    static constexpr int THREADS = 256;
+    static constexpr int THREADS = 1 << TB;
     static __host__ __device__ constexpr int shift(int j) { return (j * LOG_E <= N - LOG_E) ? j * LOG_E : N - LOG_E; }
     static __device__ __forceinline__ int idx(int j, int tid, int r) {
         const int s = shift(j);
@@ -63,9 +64,9 @@ struct BaseLay {
     // gathers pay three more VALU ops per element), so the plain layout stays the default.
 #ifdef SDH_BASE_SWIZZLE
     static __device__ __forceinline__ int phys(int i) {
-        if constexpr (LOG_E == 4) return i ^ (((i >> 8) & 3) << 4);
-        else if constexpr (LOG_E == 3) return i ^ (((i >> 6) & 3) << 3);
-        else if constexpr (LOG_E == 2) return i ^ (((i >> 5) & 3) << 2) ^ (((i >> 6) & 1) << 4);
+        if constexpr (TB == 8 && LOG_E == 4) return i ^ (((i >> 8) & 3) << 4);
+        else if constexpr (TB == 8 && LOG_E == 3) return i ^ (((i >> 6) & 3) << 3);
+        else if constexpr (TB == 8 && LOG_E == 2) return i ^ (((i >> 5) & 3) << 2) ^ (((i >> 6) & 1) << 4);
         else return i;
     }
 #else
@@ -73,11 +74,10 @@ struct BaseLay {
 #endif
 };
 
-template <int LOG_E, int JJ>
-__device__ __forceinline__ void base_stages(float (&y)[1 << LOG_E]) {
+template <class Ly, int JJ>
+__device__ __forceinline__ void base_stages(float (&y)[Ly::E]) {
 #pragma clang fp contract(off)
-    using Ly = BaseLay<LOG_E>;
-    constexpr int E = Ly::E;
+    constexpr int E = Ly::E, LOG_E = Ly::LOG_E;
     constexpr int b0 = JJ * LOG_E;
     constexpr int b1 = (b0 + LOG_E < Ly::N) ? b0 + LOG_E : Ly::N;
 #pragma unroll
@@ -94,9 +94,8 @@ __device__ __forceinline__ void base_stages(float (&y)[1 << LOG_E]) {
     }
 }
 
-template <int LOG_E, int JJ>
-__device__ __forceinline__ void base_lds_write(float * lds, const float (&y)[1 << LOG_E], int tid) {
-    using Ly = BaseLay<LOG_E>;
+template <class Ly, int JJ>
+__device__ __forceinline__ void base_lds_write(float * lds, const float (&y)[Ly::E], int tid) {
     constexpr int E = Ly::E;
     if constexpr (Ly::shift(JJ) == 0 && E >= 4) {
 #pragma unroll
@@ -108,9 +107,8 @@ __device__ __forceinline__ void base_lds_write(float * lds, const float (&y)[1 <
     }
 }
 
-template <int LOG_E, int JJ>
-__device__ __forceinline__ void base_lds_read(float (&y)[1 << LOG_E], const float * lds, int tid) {
-    using Ly = BaseLay<LOG_E>;
+template <class Ly, int JJ>
+__device__ __forceinline__ void base_lds_read(float (&y)[Ly::E], const float * lds, int tid) {
     constexpr int E = Ly::E;
     if constexpr (Ly::shift(JJ) == 0 && E >= 4) {
 #pragma unroll
@@ -129,17 +127,16 @@ __device__ __forceinline__ void base_lds_read(float (&y)[1 << LOG_E], const floa
 // is never rewritten before a barrier has separated it from its last readers.
 // With ONE_BUF (lds0 == lds1, half the LDS: the fused decode kernel needs the occupancy) every
 // rewrite is preceded by a barrier of its own instead.
-template <int LOG_E, int PAR, bool ONE_BUF, int JJ = 0>
-__device__ __forceinline__ void base_fwht(float (&y)[1 << LOG_E], float * lds0, float * lds1, int tid) {
-    using Ly = BaseLay<LOG_E>;
-    base_stages<LOG_E, JJ>(y);
+template <class Ly, int PAR, bool ONE_BUF, int JJ = 0>
+__device__ __forceinline__ void base_fwht(float (&y)[Ly::E], float * lds0, float * lds1, int tid) {
+    base_stages<Ly, JJ>(y);
     if constexpr (JJ + 1 < Ly::J) {
         float * buf = ((JJ + PAR) & 1) ? lds0 : lds1;
         if constexpr (ONE_BUF) __syncthreads();
-        base_lds_write<LOG_E, JJ>(buf, y, tid);
+        base_lds_write<Ly, JJ>(buf, y, tid);
         __syncthreads();
-        base_lds_read<LOG_E, JJ + 1>(y, buf, tid);
-        base_fwht<LOG_E, PAR, ONE_BUF, JJ + 1>(y, lds0, lds1, tid);
+        base_lds_read<Ly, JJ + 1>(y, buf, tid);
+        base_fwht<Ly, PAR, ONE_BUF, JJ + 1>(y, lds0, lds1, tid);
     }
 }
 
@@ -159,12 +156,11 @@ __device__ __forceinline__ int base_param_i(const uint8_t * p, int i) {
 // (ONE_BUF: L floats, at the price of one more barrier per transpose).
 // On return y[r] holds output element BaseLay::idx(J-1, tid, r) (the last layout: consecutive
 // threads hold consecutive elements, so a plain store per register is coalesced).
-template <int LOG_E, bool P32, bool ONE_BUF>
+template <class Ly, bool P32, bool ONE_BUF>
 __device__ __forceinline__ void base_transform(const float * __restrict__ xt, int n_in, int in0, bool x_vec_ok,
                                                const BasePackDesc & pd, int b, float * lds, int tid,
-                                               float (&y)[1 << LOG_E]) {
+                                               float (&y)[Ly::E]) {
 #pragma clang fp contract(off)
-    using Ly = BaseLay<LOG_E>;
     constexpr int E = Ly::E, L = Ly::L, JL = Ly::J - 1;
     float * lds0 = lds;
     float * lds1 = ONE_BUF ? lds : lds + L;
@@ -205,14 +201,14 @@ __device__ __forceinline__ void base_transform(const float * __restrict__ xt, in
     SDH_STAMP(1);
     // ---- P1 (gather) ----------------------------------------------------------------------------
     if (has_p1) {
-        base_lds_write<LOG_E, 0>(lds0, y, tid);
+        base_lds_write<Ly, 0>(lds0, y, tid);
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < E; ++r) y[r] = lds0[Ly::phys(g1[r])];
     }
     SDH_STAMP(2);
     // ---- H ----------------------------------------------------------------------------------------
-    base_fwht<LOG_E, 0, ONE_BUF>(y, lds0, lds1, tid);        // y now in layout JL
+    base_fwht<Ly, 0, ONE_BUF>(y, lds0, lds1, tid);        // y now in layout JL
     SDH_STAMP(3);
     if (!has_d2 && !has_p2) {                                // depth 1 (:537-544)
         if (has_d3) {
@@ -231,16 +227,16 @@ __device__ __forceinline__ void base_transform(const float * __restrict__ xt, in
     // then starts on the buffer that is not being read here (PAR = J & 1).
     float * back = (Ly::J & 1) ? lds1 : lds0;
     if constexpr (ONE_BUF) __syncthreads();
-    base_lds_write<LOG_E, JL>(back, y, tid);
+    base_lds_write<Ly, JL>(back, y, tid);
     __syncthreads();
     if (has_p2) {
 #pragma unroll
         for (int r = 0; r < E; ++r) y[r] = back[Ly::phys(base_param_i<P32>(pk + pd.off_p2, E * tid + r))];
     } else {
-        base_lds_read<LOG_E, 0>(y, back, tid);
+        base_lds_read<Ly, 0>(y, back, tid);
     }
     SDH_STAMP(4);
-    base_fwht<LOG_E, (Ly::J & 1), ONE_BUF>(y, lds0, lds1, tid);
+    base_fwht<Ly, (Ly::J & 1), ONE_BUF>(y, lds0, lds1, tid);
     SDH_STAMP(5);
     if (has_d3) {
 #pragma unroll
@@ -251,13 +247,12 @@ __device__ __forceinline__ void base_transform(const float * __restrict__ xt, in
 // Re-order a finished block from the last layout to layout 0 (E consecutive elements per thread,
 // thread t holding [E*t, E*t+E)) through a single LDS buffer that may still be in use: a barrier
 // first, then write, barrier, read.
-template <int LOG_E>
-__device__ __forceinline__ void base_to_layout0(float (&y)[1 << LOG_E], float * lds, int tid) {
-    using Ly = BaseLay<LOG_E>;
+template <class Ly>
+__device__ __forceinline__ void base_to_layout0(float (&y)[Ly::E], float * lds, int tid) {
     __syncthreads();
-    base_lds_write<LOG_E, Ly::J - 1>(lds, y, tid);
+    base_lds_write<Ly, Ly::J - 1>(lds, y, tid);
     __syncthreads();
-    base_lds_read<LOG_E, 0>(y, lds, tid);
+    base_lds_read<Ly, 0>(y, lds, tid);
 }
 
 } // namespace sdh

@@ -42,6 +42,7 @@ constexpr unsigned long long SPIN_TICKS = 50000;      // 100 MHz ticks = 500 us
 struct FusedArgs {
     unsigned long long * vg;      // [B][L] granules {value, epoch}
     unsigned   epoch;
+    int        resid_delay;       // residual workgroups start after this many s_sleep(8) (512 clocks each)
     int        census;            // 1: census launch (no computation)
     unsigned * census_ctr;        // [0] arrivals, [1] failures
 };
@@ -83,11 +84,17 @@ __device__ __forceinline__ bool poll_granules(const FusedArgs & fa, int o, int L
     return ok;
 }
 
-template <bool BLOCK, int STEPS, int LOG_E>
-__global__ __launch_bounds__(256)
+// LOG_T: log2 of the workgroup size. The base role's chain (2 FWHTs + gathers) is the critical path of
+// the launch and its time falls with the number of threads sharing a block (fewer elements and LDS
+// accesses per thread), so L = 4096 runs 512-thread workgroups (E = 8); the residual role simply has
+// 8 waves per workgroup instead of 4.
+template <bool BLOCK, int STEPS, int LOG_E, int LOG_T>
+__global__ __launch_bounds__(1 << LOG_T)
 void decode_fused_kernel(const DeltaParams p, const BasePackDesc pd, const FusedArgs fa) {
-    constexpr int L = BaseLay<LOG_E>::L;
-    constexpr int E = BaseLay<LOG_E>::E;
+    using Ly = BaseLay<LOG_E, LOG_T>;
+    constexpr int L = Ly::L;
+    constexpr int E = Ly::E;
+    constexpr int WAVES = (1 << LOG_T) / 64;
     __shared__ __align__(16) float lds[L];             // one transpose buffer: occupancy over barriers
 
     if (fa.census) {                                   // residency self-test, see header comment
@@ -110,7 +117,7 @@ void decode_fused_kernel(const DeltaParams p, const BasePackDesc pd, const Fused
         const int tid = threadIdx.x;
         __builtin_amdgcn_s_setprio(SDH_BASE_PRIO);     // the base blocks are the critical path of the launch
         float y[E];
-        base_transform<LOG_E, false, true>(p.x, p.n_in, p.tall ? 0 : b * L, p.x_vec_ok != 0, pd, b, lds, tid, y);
+        base_transform<Ly, false, true>(p.x, p.n_in, p.tall ? 0 : b * L, p.x_vec_ok != 0, pd, b, lds, tid, y);
         // Publish as {value, epoch} granules, one agent-scope (sc1, write-through) 8-byte store each,
         // straight from the last layout (consecutive lanes write consecutive granules). Measured
         // alternatives, all slower end to end on the cfg3 shape: two granules per 16-byte sc1 store
@@ -120,21 +127,23 @@ void decode_fused_kernel(const DeltaParams p, const BasePackDesc pd, const Fused
         const unsigned long long tag = (unsigned long long) fa.epoch << 32;
 #pragma unroll
         for (int r = 0; r < E; ++r)
-            __hip_atomic_store(out + BaseLay<LOG_E>::idx(BaseLay<LOG_E>::J - 1, tid, r),
+            __hip_atomic_store(out + Ly::idx(Ly::J - 1, tid, r),
                                tag | (unsigned long long) __float_as_uint(y[r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         SDH_STAMP(6);
         return;
     }
 
     // ---- residual role ------------------------------------------------------------------------
-#ifdef SDH_RESID_DELAY
-    __builtin_amdgcn_s_sleep(SDH_RESID_DELAY);         // build variant (A/B): within 2 % for any value tried
-#endif
+    // A short head start for the base workgroups: their parameter and activation loads head the
+    // critical path of the launch, and issued together with the payload flood of ~1000 residual
+    // workgroups they queue behind it. ~1.2 us of delay costs the residual role nothing (it is done
+    // long before the base) and takes cfg3 from 9.9 to 8.9 us.
+    for (int i = 0; i < fa.resid_delay; ++i) __builtin_amdgcn_s_sleep(8);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int G = p.G;
     const int l = lane & (G - 1);
-    const int o = (((int) blockIdx.x - p.B) * 4 + wave) * (64 / G) + (lane / G);
+    const int o = (((int) blockIdx.x - p.B) * WAVES + wave) * (64 / G) + (lane / G);
     const bool row_ok = o < p.n_out;
     const int orow = row_ok ? o : 0;
     const bool leader = row_ok && l == 0;
@@ -182,15 +191,18 @@ struct PairArgs {
     int          act;
     const uint16_t * gelu_tab;
     float *      h;
+    int          resid_delay;
     int          census;
     unsigned *   census_ctr;
 };
 
-template <bool BLOCK, int STEPS, int LOG_E>
-__global__ __launch_bounds__(256)
+template <bool BLOCK, int STEPS, int LOG_E, int LOG_T>
+__global__ __launch_bounds__(1 << LOG_T)
 void decode_pair_kernel(const PairArgs a) {
-    constexpr int L = BaseLay<LOG_E>::L;
-    constexpr int E = BaseLay<LOG_E>::E;
+    using Ly = BaseLay<LOG_E, LOG_T>;
+    constexpr int L = Ly::L;
+    constexpr int E = Ly::E;
+    constexpr int WAVES = (1 << LOG_T) / 64;
     __shared__ __align__(16) float lds[L];
 
     if (a.census) {
@@ -215,21 +227,22 @@ void decode_pair_kernel(const PairArgs a) {
         __builtin_amdgcn_s_setprio(SDH_BASE_PRIO);
         float y[E];
         const BasePackDesc & pd = second ? a.pd[1] : a.pd[0];
-        base_transform<LOG_E, false, true>(a.p[0].x, a.p[0].n_in, 0, a.p[0].x_vec_ok != 0, pd, b, lds, tid, y);
+        base_transform<Ly, false, true>(a.p[0].x, a.p[0].n_in, 0, a.p[0].x_vec_ok != 0, pd, b, lds, tid, y);
         unsigned long long * out = (second ? a.vg[1] : a.vg[0]) + (size_t) b * L;
         const unsigned long long tag = (unsigned long long) (second ? a.epoch[1] : a.epoch[0]) << 32;
 #pragma unroll
         for (int r = 0; r < E; ++r)
-            __hip_atomic_store(out + BaseLay<LOG_E>::idx(BaseLay<LOG_E>::J - 1, tid, r),
+            __hip_atomic_store(out + Ly::idx(Ly::J - 1, tid, r),
                                tag | (unsigned long long) __float_as_uint(y[r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
 
+    for (int i = 0; i < a.resid_delay; ++i) __builtin_amdgcn_s_sleep(8);     // head start for the base role (see decode_fused_kernel)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int G = a.p[0].G;
     const int l = lane & (G - 1);
-    const int o = (((int) blockIdx.x - 2 * B) * 4 + wave) * (64 / G) + (lane / G);
+    const int o = (((int) blockIdx.x - 2 * B) * WAVES + wave) * (64 / G) + (lane / G);
     const bool row_ok = o < a.p[0].n_out;
     const int orow = row_ok ? o : 0;
     const bool leader = row_ok && l == 0;
@@ -265,25 +278,50 @@ void decode_pair_kernel(const PairArgs a) {
 }
 
 // ---- host side ----------------------------------------------------------------------------------
+// workgroup shape per base block length: L = 2^(LOG_E + LOG_T)
+#if defined(SDH_DECODE_L4096_T256)    // build variants (A/B): 256 threads x 16 elements was the first version
+#define SDH_L4096_LOG_E 4
+#define SDH_L4096_LOG_T 8
+#elif defined(SDH_DECODE_L4096_T1024)
+#define SDH_L4096_LOG_E 2
+#define SDH_L4096_LOG_T 10
+#else
+#define SDH_L4096_LOG_E 3
+#define SDH_L4096_LOG_T 9
+#endif
+#if defined(SDH_DECODE_L2048_T512)
+#define SDH_L2048_LOG_E 2
+#define SDH_L2048_LOG_T 9
+#else
+#define SDH_L2048_LOG_E 3
+#define SDH_L2048_LOG_T 8
+#endif
+static int decode_log_t(int L) { return L == 4096 ? SDH_L4096_LOG_T : L == 2048 ? SDH_L2048_LOG_T : 8; }
+// head start of the base role, in s_sleep(8) units of 512 clocks; SDH_DECODE_DELAY overrides (A/B runs)
+static int resid_delay_units() {
+    static const int v = [] { const char * e = getenv("SDH_DECODE_DELAY"); return e ? atoi(e) : 5; }();
+    return v < 0 ? 0 : (v > 64 ? 64 : v);
+}
+
 struct FusedKernelInfo {
     int occ = -1;                 // resident workgroups per CU (occupancy API)
     unsigned census_ok_grid = 0;  // largest grid the census has confirmed
     bool census_failed = false;
 };
 
-template <bool BLOCK, int STEPS, int LOG_E>
+template <bool BLOCK, int STEPS, int LOG_E, int LOG_T>
 static FusedKernelInfo & kernel_info() {
     static FusedKernelInfo info;
     return info;
 }
 
-template <bool BLOCK, int STEPS, int LOG_E>
+template <bool BLOCK, int STEPS, int LOG_E, int LOG_T>
 static int launch_inst(const DeltaParams & p, const BasePackDesc & pd, FusedArgs fa, unsigned grid, hipStream_t s) {
-    FusedKernelInfo & ki = kernel_info<BLOCK, STEPS, LOG_E>();
+    FusedKernelInfo & ki = kernel_info<BLOCK, STEPS, LOG_E, LOG_T>();
     LibState & ls = lib();
     if (ki.occ < 0) {
         int occ = 0;
-        SDH_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, decode_fused_kernel<BLOCK, STEPS, LOG_E>, 256, 0));
+        SDH_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, decode_fused_kernel<BLOCK, STEPS, LOG_E, LOG_T>, 1 << LOG_T, 0));
         ki.occ = occ;
     }
     static const bool dbg = getenv("SDH_DEBUG") != nullptr;
@@ -300,7 +338,7 @@ static int launch_inst(const DeltaParams & p, const BasePackDesc & pd, FusedArgs
         FusedArgs ca = fa;
         ca.census = 1;
         ca.census_ctr = ls.census_ctr;
-        hipLaunchKernelGGL((decode_fused_kernel<BLOCK, STEPS, LOG_E>), dim3(grid), dim3(256), 0, s, p, pd, ca);
+        hipLaunchKernelGGL((decode_fused_kernel<BLOCK, STEPS, LOG_E, LOG_T>), dim3(grid), dim3(1 << LOG_T), 0, s, p, pd, ca);
         SDH_HIP_CHECK(hipGetLastError());
         unsigned h[2] = {0, 0};
         SDH_HIP_CHECK(hipMemcpyAsync(h, ls.census_ctr, sizeof(h), hipMemcpyDeviceToHost, s));
@@ -311,18 +349,18 @@ static int launch_inst(const DeltaParams & p, const BasePackDesc & pd, FusedArgs
     }
     fa.census = 0;
     fa.census_ctr = nullptr;
-    hipLaunchKernelGGL((decode_fused_kernel<BLOCK, STEPS, LOG_E>), dim3(grid), dim3(256), 0, s, p, pd, fa);
+    hipLaunchKernelGGL((decode_fused_kernel<BLOCK, STEPS, LOG_E, LOG_T>), dim3(grid), dim3(1 << LOG_T), 0, s, p, pd, fa);
     SDH_HIP_CHECK(hipGetLastError());
     return SDH_OK;
 }
 
-template <bool BLOCK, int LOG_E>
+template <bool BLOCK, int LOG_E, int LOG_T>
 static int launch_steps(int steps, const DeltaParams & p, const BasePackDesc & pd, const FusedArgs & fa, unsigned grid, hipStream_t s) {
     switch (steps) {
-        case 1: return launch_inst<BLOCK, 1, LOG_E>(p, pd, fa, grid, s);
-        case 2: return launch_inst<BLOCK, 2, LOG_E>(p, pd, fa, grid, s);
-        case 3: return launch_inst<BLOCK, 3, LOG_E>(p, pd, fa, grid, s);
-        case 4: return launch_inst<BLOCK, 4, LOG_E>(p, pd, fa, grid, s);
+        case 1: return launch_inst<BLOCK, 1, LOG_E, LOG_T>(p, pd, fa, grid, s);
+        case 2: return launch_inst<BLOCK, 2, LOG_E, LOG_T>(p, pd, fa, grid, s);
+        case 3: return launch_inst<BLOCK, 3, LOG_E, LOG_T>(p, pd, fa, grid, s);
+        case 4: return launch_inst<BLOCK, 4, LOG_E, LOG_T>(p, pd, fa, grid, s);
         default: return 1;
     }
 }
@@ -347,29 +385,33 @@ int launch_decode_fused(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s) 
     if (!delta_vector_shape(p, is_block, &G, &steps) || steps < 1 || steps > 4) SDH_DECLINE("row shape needs the scalar or looped kernel");
 #undef SDH_DECLINE
     p.G = G;
-    const int rows_per_block = 4 * (64 / G);
+    const int log_t = decode_log_t((int) w.L);
+    const int rows_per_block = ((1 << log_t) / 64) * (64 / G);
     const unsigned grid = (unsigned) w.B + (unsigned) ((p.n_out + rows_per_block - 1) / rows_per_block);
 
     if (++w.epoch == 0) w.epoch = 1;
     FusedArgs fa{};
     fa.vg = reinterpret_cast<unsigned long long *>(w.handoff);
     fa.epoch = w.epoch;
+    fa.resid_delay = resid_delay_units();
     switch (w.L) {
-        case 1024: return is_block ? launch_steps<true, 2>(steps, p, w.pack, fa, grid, s) : launch_steps<false, 2>(steps, p, w.pack, fa, grid, s);
-        case 2048: return is_block ? launch_steps<true, 3>(steps, p, w.pack, fa, grid, s) : launch_steps<false, 3>(steps, p, w.pack, fa, grid, s);
-        default:   return is_block ? launch_steps<true, 4>(steps, p, w.pack, fa, grid, s) : launch_steps<false, 4>(steps, p, w.pack, fa, grid, s);
+        case 1024: return is_block ? launch_steps<true, 2, 8>(steps, p, w.pack, fa, grid, s) : launch_steps<false, 2, 8>(steps, p, w.pack, fa, grid, s);
+        case 2048: return is_block ? launch_steps<true, SDH_L2048_LOG_E, SDH_L2048_LOG_T>(steps, p, w.pack, fa, grid, s)
+                                   : launch_steps<false, SDH_L2048_LOG_E, SDH_L2048_LOG_T>(steps, p, w.pack, fa, grid, s);
+        default:   return is_block ? launch_steps<true, SDH_L4096_LOG_E, SDH_L4096_LOG_T>(steps, p, w.pack, fa, grid, s)
+                                   : launch_steps<false, SDH_L4096_LOG_E, SDH_L4096_LOG_T>(steps, p, w.pack, fa, grid, s);
     }
 }
 
 
 // ---- gate | up pair ---------------------------------------------------------------------------------
-template <bool BLOCK, int STEPS, int LOG_E>
+template <bool BLOCK, int STEPS, int LOG_E, int LOG_T>
 static int launch_pair_inst(PairArgs & a, unsigned grid, hipStream_t s) {
     static FusedKernelInfo ki;
     LibState & ls = lib();
     if (ki.occ < 0) {
         int occ = 0;
-        SDH_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, decode_pair_kernel<BLOCK, STEPS, LOG_E>, 256, 0));
+        SDH_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, decode_pair_kernel<BLOCK, STEPS, LOG_E, LOG_T>, 1 << LOG_T, 0));
         ki.occ = occ;
     }
     static const bool dbg = getenv("SDH_DEBUG") != nullptr;
@@ -383,7 +425,7 @@ static int launch_pair_inst(PairArgs & a, unsigned grid, hipStream_t s) {
         PairArgs ca = a;
         ca.census = 1;
         ca.census_ctr = ls.census_ctr;
-        hipLaunchKernelGGL((decode_pair_kernel<BLOCK, STEPS, LOG_E>), dim3(grid), dim3(256), 0, s, ca);
+        hipLaunchKernelGGL((decode_pair_kernel<BLOCK, STEPS, LOG_E, LOG_T>), dim3(grid), dim3(1 << LOG_T), 0, s, ca);
         SDH_HIP_CHECK(hipGetLastError());
         unsigned h[2] = {0, 0};
         SDH_HIP_CHECK(hipMemcpyAsync(h, ls.census_ctr, sizeof(h), hipMemcpyDeviceToHost, s));
@@ -394,16 +436,16 @@ static int launch_pair_inst(PairArgs & a, unsigned grid, hipStream_t s) {
     }
     a.census = 0;
     a.census_ctr = nullptr;
-    hipLaunchKernelGGL((decode_pair_kernel<BLOCK, STEPS, LOG_E>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((decode_pair_kernel<BLOCK, STEPS, LOG_E, LOG_T>), dim3(grid), dim3(1 << LOG_T), 0, s, a);
     SDH_HIP_CHECK(hipGetLastError());
     return SDH_OK;
 }
 
-template <bool BLOCK, int LOG_E>
+template <bool BLOCK, int LOG_E, int LOG_T>
 static int launch_pair_steps(int steps, PairArgs & a, unsigned grid, hipStream_t s) {
     switch (steps) {                                   // two rows per wave: rows of up to 2 steps per lane
-        case 1: return launch_pair_inst<BLOCK, 1, LOG_E>(a, grid, s);
-        case 2: return launch_pair_inst<BLOCK, 2, LOG_E>(a, grid, s);
+        case 1: return launch_pair_inst<BLOCK, 1, LOG_E, LOG_T>(a, grid, s);
+        case 2: return launch_pair_inst<BLOCK, 2, LOG_E, LOG_T>(a, grid, s);
         default: return 1;
     }
 }
@@ -434,7 +476,7 @@ int launch_decode_pair(DeviceWeight & g, DeviceWeight & u, int act, const uint16
 #undef SDH_DECLINE
     a.p[0].G = a.p[1].G = G0;
     a.pd[0] = g.pack; a.pd[1] = u.pack;
-    const int rows_per_block = 4 * (64 / G0);
+    const int rows_per_block = ((1 << decode_log_t((int) g.L)) / 64) * (64 / G0);
     const unsigned grid = 2u * (unsigned) g.B + (unsigned) ((a.p[0].n_out + rows_per_block - 1) / rows_per_block);
     if (++g.epoch == 0) g.epoch = 1;
     if (++u.epoch == 0) u.epoch = 1;
@@ -442,10 +484,13 @@ int launch_decode_pair(DeviceWeight & g, DeviceWeight & u, int act, const uint16
     a.vg[1] = reinterpret_cast<unsigned long long *>(u.handoff);
     a.epoch[0] = g.epoch; a.epoch[1] = u.epoch;
     a.act = act; a.gelu_tab = gelu_tab; a.h = h;
+    a.resid_delay = resid_delay_units();
     switch (g.L) {
-        case 1024: return is_block ? launch_pair_steps<true, 2>(st0, a, grid, s) : launch_pair_steps<false, 2>(st0, a, grid, s);
-        case 2048: return is_block ? launch_pair_steps<true, 3>(st0, a, grid, s) : launch_pair_steps<false, 3>(st0, a, grid, s);
-        default:   return is_block ? launch_pair_steps<true, 4>(st0, a, grid, s) : launch_pair_steps<false, 4>(st0, a, grid, s);
+        case 1024: return is_block ? launch_pair_steps<true, 2, 8>(st0, a, grid, s) : launch_pair_steps<false, 2, 8>(st0, a, grid, s);
+        case 2048: return is_block ? launch_pair_steps<true, SDH_L2048_LOG_E, SDH_L2048_LOG_T>(st0, a, grid, s)
+                                   : launch_pair_steps<false, SDH_L2048_LOG_E, SDH_L2048_LOG_T>(st0, a, grid, s);
+        default:   return is_block ? launch_pair_steps<true, SDH_L4096_LOG_E, SDH_L4096_LOG_T>(st0, a, grid, s)
+                                   : launch_pair_steps<false, SDH_L4096_LOG_E, SDH_L4096_LOG_T>(st0, a, grid, s);
     }
 }
 

@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/../llama.cpp_amd/csrc"
 make -j8 >/dev/null
-for v in "poll1:-DSDH_POLL_SLEEP=1" "poll16:-DSDH_POLL_SLEEP=16" "delay2:-DSDH_RESID_DELAY=2" "delay8:-DSDH_RESID_DELAY=8" "delay24:-DSDH_RESID_DELAY=24" "prio0:-DSDH_BASE_PRIO=0"; do
+for v in ${VARIANTS:-"t256:-DSDH_DECODE_L4096_T256" "delay24:-DSDH_RESID_DELAY=24"}; do
   name=${v%%:*}; flag=${v#*:}
   out=../../tools/bin/variants/$name; mkdir -p $out
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $flag -c sdh_decode.hip -o $out/sdh_decode.o

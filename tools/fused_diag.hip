@@ -27,7 +27,7 @@ static sdh_tensor mk(const void * d, int type, int nd, int64_t n0, int64_t n1, i
 
 int main() {
     const int L = 4096, B = 4, NIN = 14336, NOUT = 4096, NB = 48, BLOCK = 32, NPAY = 32, ITERS = 160;
-    const int GRID = B + NOUT / 4;
+    const int GRID = B + NOUT / 8;      // 512-thread workgroups: 8 rows each
     CK(hipSetDevice(0));
     if (sdh_init(0) != 0) { fprintf(stderr, "init: %s\n", sdh_last_error()); return 1; }
     hipStream_t s;
