@@ -1311,17 +1311,24 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
         SDH_HIP_CHECK(hipStreamSynchronize(st));
         std::vector<double> cs_all, l2_all, lnr_all;
         auto silu = [](double v) { return v / (1.0 + std::exp(-v)); };
+        std::vector<double> at((size_t) nh), ah((size_t) nh);
         for (int xi = 0; xi < nx; ++xi) {
             const double * gt = gu.data() + (size_t) xi * nh, * ut = gu.data() + (size_t) nh * nx + (size_t) xi * nh;
             const double * ht = hat.data() + (size_t) xi * nh;
+            // silu(g)*u per hidden sample, once per x (the reference evaluates it inside the output loop;
+            // (silu(g)*u)*w associates the same way, so the sums are bit-identical)
+            for (int hi = 0; hi < nh; ++hi) {
+                const double g_hat = p.kind == 0 ? ht[hi] : gt[hi], u_hat = p.kind == 1 ? ht[hi] : ut[hi];
+                at[(size_t) hi] = silu(gt[hi]) * ut[hi];
+                ah[(size_t) hi] = silu(g_hat) * u_hat;
+            }
             double dot = 0.0, n1 = 0.0, n2 = 0.0, l2 = 0.0;
             for (int oi = 0; oi < no; ++oi) {
                 double yt = 0.0, yh = 0.0;
                 for (int hi = 0; hi < nh; ++hi) {
-                    const double g_hat = p.kind == 0 ? ht[hi] : gt[hi], u_hat = p.kind == 1 ? ht[hi] : ut[hi];
                     const double w = (double) wd[(size_t) oi * nh + hi];
-                    yt += silu(gt[hi]) * ut[hi] * w;
-                    yh += silu(g_hat) * u_hat * w;
+                    yt += at[(size_t) hi] * w;
+                    yh += ah[(size_t) hi] * w;
                 }
                 dot += yt * yh; n1 += yt * yt; n2 += yh * yh;
                 const double d = yt - yh;

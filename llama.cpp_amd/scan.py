@@ -431,6 +431,23 @@ class Evaluator:
         self._cache: Dict[Tuple[int, str], DenseWeight] = {}
         self._order: List[Tuple[int, str]] = []
         self.max_resident = max(3, max_resident)
+        # one scan handle (stream, events, device buffers) per worker thread, reused across groups:
+        # creating and freeing them per group costs a dozen hipMalloc / hipFree each, and hipFree waits
+        # for the whole device
+        import threading
+        self._tls = threading.local()
+        self._sessions: List[ScanSession] = []
+        self._sessions_lock = threading.Lock()
+
+    def _session(self, seed: int) -> ScanSession:
+        s = getattr(self._tls, "session", None)
+        if s is None:
+            s = ScanSession(seed)
+            self._tls.session = s
+            with self._sessions_lock:
+                self._sessions.append(s)
+        s.reseed(seed)
+        return s
 
     def run_many(self, cands: Sequence[Candidate], threads: int = 8, params_of: Optional[Callable] = None) -> List[dict]:
         """Evaluate candidates layer by layer with a pool of host threads. Every candidate owns its RNG
@@ -513,27 +530,29 @@ class Evaluator:
         the same seed the base fit of the tensor comes out the same each time, so it is computed for the
         first K and reused (its draws replayed) for the others."""
         out = []
-        s = ScanSession((params or self.params).seed)
-        try:
-            for n, c in enumerate(group):
-                assert (c.layer, c.kind) == (group[0].layer, group[0].kind)
-                p = ScanParams(**{**(params or self.params).__dict__, "K": c.K})
-                p.base_mode = 2 if (n > 0 and p.base) else 0
-                s.reseed(p.seed)
-                for t in self.tensors:
-                    if t == c.kind:
-                        break
-                    n_in, n_out = self.dims_of(c.layer, t) if self.dims_of is not None else \
-                        (self.dense(c.layer, t).n_in, self.dense(c.layer, t).n_out)
-                    s.skip(n_in, n_out, p, t, c.layer)
-                need_proxy = p.scheme == "coo" and not p.base and p.eval_x > 0 and c.kind != "ffn_down"
-                ffn = tuple(self.dense(c.layer, k) for k in KINDS) if need_proxy else None
-                out.append(s.tensor(self.dense(c.layer, c.kind), p, c.kind, c.layer, ffn))
-        finally:
-            s.close()
+        s = self._session((params or self.params).seed)
+        for n, c in enumerate(group):
+            assert (c.layer, c.kind) == (group[0].layer, group[0].kind)
+            p = ScanParams(**{**(params or self.params).__dict__, "K": c.K})
+            p.base_mode = 2 if (n > 0 and p.base) else 0            # never across groups: the handle is reused
+            s.reseed(p.seed)
+            for t in self.tensors:
+                if t == c.kind:
+                    break
+                n_in, n_out = self.dims_of(c.layer, t) if self.dims_of is not None else \
+                    (self.dense(c.layer, t).n_in, self.dense(c.layer, t).n_out)
+                s.skip(n_in, n_out, p, t, c.layer)
+            need_proxy = p.scheme == "coo" and not p.base and p.eval_x > 0 and c.kind != "ffn_down"
+            ffn = tuple(self.dense(c.layer, k) for k in KINDS) if need_proxy else None
+            out.append(s.tensor(self.dense(c.layer, c.kind), p, c.kind, c.layer, ffn))
         return out
 
     def close(self):
+        with self._sessions_lock:
+            for s in self._sessions:
+                s.close()
+            self._sessions.clear()
+        self._tls = __import__("threading").local()
         for w in self._cache.values():
             w.close()
         self._cache.clear()
