@@ -43,6 +43,8 @@ struct FusedArgs {
     unsigned long long * vg;      // [B][L] granules {value, epoch}
     unsigned   epoch;
     int        resid_delay;       // residual workgroups start after this many s_sleep(8) (512 clocks each)
+    int        ncu;               // CUs of the device (round-robin period of the dispatcher); 0: no shadow workgroups
+    int        linger;            // how long a shadow workgroup stays, in 100 MHz ticks
     int        census;            // 1: census launch (no computation)
     unsigned * census_ctr;        // [0] arrivals, [1] failures
 };
@@ -88,6 +90,25 @@ __device__ __forceinline__ bool poll_granules(const FusedArgs & fa, int o, int L
 // the launch and its time falls with the number of threads sharing a block (fewer elements and LDS
 // accesses per thread), so L = 4096 runs 512-thread workgroups (E = 8); the residual role simply has
 // 8 waves per workgroup instead of 4.
+// Workgroup placement. The dispatcher deals the workgroups of a launch to the CUs round-robin in
+// blockIdx order (measured, tools/placement.hip: grid 256k+4 puts the 4 extra workgroups on the CUs of
+// workgroups 0-3). The base workgroups are blockIdx 0..nb-1, so blockIdx = w*ncu + i, i < nb, w >= 1 are
+// the residual workgroups that would share a CU with a base workgroup and slow its chain down (FWHT 1
+// measured 2.4 us with two residual workgroups on the CU, 1.4 us alone). Those ids are "shadows": they
+// do no work (they linger ~2 us so that the dispatcher does not refill their slot, then leave) and the
+// residual rows are dealt to the other ids. A performance assumption only: any placement is correct.
+//   returns -1 for a shadow, else the residual index of this workgroup
+__device__ __forceinline__ int residual_index(int bid, int nb, int ncu) {
+    if (ncu <= 0 || bid < ncu) return bid - nb;
+    const int wrap = bid / ncu;
+    if (bid - wrap * ncu < nb) return -1;
+    return bid - nb - nb * wrap;
+}
+__device__ __forceinline__ void shadow_linger(int ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long) ticks) __builtin_amdgcn_s_sleep(16);      // 100 MHz ticks
+}
+
 template <bool BLOCK, int STEPS, int LOG_E, int LOG_T>
 __global__ __launch_bounds__(1 << LOG_T)
 void decode_fused_kernel(const DeltaParams p, const BasePackDesc pd, const FusedArgs fa) {
@@ -138,12 +159,14 @@ void decode_fused_kernel(const DeltaParams p, const BasePackDesc pd, const Fused
     // critical path of the launch, and issued together with the payload flood of ~1000 residual
     // workgroups they queue behind it. ~1.2 us of delay costs the residual role nothing (it is done
     // long before the base) and takes cfg3 from 9.9 to 8.9 us.
+    const int ridx = residual_index((int) blockIdx.x, p.B, fa.ncu);
+    if (ridx < 0) { shadow_linger(fa.linger); return; }
     for (int i = 0; i < fa.resid_delay; ++i) __builtin_amdgcn_s_sleep(8);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int G = p.G;
     const int l = lane & (G - 1);
-    const int o = (((int) blockIdx.x - p.B) * WAVES + wave) * (64 / G) + (lane / G);
+    const int o = (ridx * WAVES + wave) * (64 / G) + (lane / G);
     const bool row_ok = o < p.n_out;
     const int orow = row_ok ? o : 0;
     const bool leader = row_ok && l == 0;
@@ -192,6 +215,8 @@ struct PairArgs {
     const uint16_t * gelu_tab;
     float *      h;
     int          resid_delay;
+    int          ncu;
+    int          linger;
     int          census;
     unsigned *   census_ctr;
 };
@@ -237,12 +262,14 @@ void decode_pair_kernel(const PairArgs a) {
         return;
     }
 
+    const int ridx = residual_index((int) blockIdx.x, 2 * B, a.ncu);
+    if (ridx < 0) { shadow_linger(a.linger); return; }
     for (int i = 0; i < a.resid_delay; ++i) __builtin_amdgcn_s_sleep(8);     // head start for the base role (see decode_fused_kernel)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int G = a.p[0].G;
     const int l = lane & (G - 1);
-    const int o = (((int) blockIdx.x - 2 * B) * WAVES + wave) * (64 / G) + (lane / G);
+    const int o = (ridx * WAVES + wave) * (64 / G) + (lane / G);
     const bool row_ok = o < a.p[0].n_out;
     const int orow = row_ok ? o : 0;
     const bool leader = row_ok && l == 0;
@@ -298,6 +325,26 @@ void decode_pair_kernel(const PairArgs a) {
 #endif
 static int decode_log_t(int L) { return L == 4096 ? SDH_L4096_LOG_T : L == 2048 ? SDH_L2048_LOG_T : 8; }
 // head start of the base role, in s_sleep(8) units of 512 clocks; SDH_DECODE_DELAY overrides (A/B runs)
+// grid size that holds nb base workgroups and n_res working residual workgroups when the ids that
+// would land on a base workgroup's CU are left empty (see residual_index)
+// Shadow ids are OFF by default: measured on the product build, back to back, they cost 0.5 us on cfg3
+// (9.29 vs 8.77 us) although a base workgroup alone on its CU runs its chain faster; the in-kernel stamps
+// that suggested a 2 us gain distort the comparison (the stamp stores sit on the base chain).
+// SDH_DECODE_SHADOW=<linger ticks> turns them on for experiments.
+static int shadow_linger_ticks() {
+    static const int v = [] { const char * e = getenv("SDH_DECODE_SHADOW"); return e ? atoi(e) : -1; }();
+    return v;
+}
+static int shadow_ncu() { return shadow_linger_ticks() >= 0 ? lib().num_cu : 0; }
+static unsigned shadow_grid(int nb, int n_res, int ncu) {
+    if (ncu <= 0 || nb >= ncu) return (unsigned) (nb + n_res);
+    int first = ncu - nb;                          // residual ids in the first wrap
+    if (n_res <= first) return (unsigned) (nb + n_res);
+    const int per = ncu - nb;                      // working ids per later wrap (nb shadows each)
+    const int rest = n_res - first;
+    const int full = rest / per, tail = rest % per;
+    return (unsigned) (ncu * (1 + full) + (tail ? nb + tail : 0));
+}
 static int resid_delay_units() {
     static const int v = [] { const char * e = getenv("SDH_DECODE_DELAY"); return e ? atoi(e) : 5; }();
     return v < 0 ? 0 : (v > 64 ? 64 : v);
@@ -387,13 +434,16 @@ int launch_decode_fused(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s) 
     p.G = G;
     const int log_t = decode_log_t((int) w.L);
     const int rows_per_block = ((1 << log_t) / 64) * (64 / G);
-    const unsigned grid = (unsigned) w.B + (unsigned) ((p.n_out + rows_per_block - 1) / rows_per_block);
+    const int ncu = shadow_ncu();
+    const unsigned grid = shadow_grid((int) w.B, (p.n_out + rows_per_block - 1) / rows_per_block, ncu);
 
     if (++w.epoch == 0) w.epoch = 1;
     FusedArgs fa{};
     fa.vg = reinterpret_cast<unsigned long long *>(w.handoff);
     fa.epoch = w.epoch;
     fa.resid_delay = resid_delay_units();
+    fa.ncu = ncu;
+    fa.linger = shadow_linger_ticks();
     switch (w.L) {
         case 1024: return is_block ? launch_steps<true, 2, 8>(steps, p, w.pack, fa, grid, s) : launch_steps<false, 2, 8>(steps, p, w.pack, fa, grid, s);
         case 2048: return is_block ? launch_steps<true, SDH_L2048_LOG_E, SDH_L2048_LOG_T>(steps, p, w.pack, fa, grid, s)
@@ -477,7 +527,8 @@ int launch_decode_pair(DeviceWeight & g, DeviceWeight & u, int act, const uint16
     a.p[0].G = a.p[1].G = G0;
     a.pd[0] = g.pack; a.pd[1] = u.pack;
     const int rows_per_block = ((1 << decode_log_t((int) g.L)) / 64) * (64 / G0);
-    const unsigned grid = 2u * (unsigned) g.B + (unsigned) ((a.p[0].n_out + rows_per_block - 1) / rows_per_block);
+    const int ncu = shadow_ncu();
+    const unsigned grid = shadow_grid(2 * (int) g.B, (a.p[0].n_out + rows_per_block - 1) / rows_per_block, ncu);
     if (++g.epoch == 0) g.epoch = 1;
     if (++u.epoch == 0) u.epoch = 1;
     a.vg[0] = reinterpret_cast<unsigned long long *>(g.handoff);
@@ -485,6 +536,8 @@ int launch_decode_pair(DeviceWeight & g, DeviceWeight & u, int act, const uint16
     a.epoch[0] = g.epoch; a.epoch[1] = u.epoch;
     a.act = act; a.gelu_tab = gelu_tab; a.h = h;
     a.resid_delay = resid_delay_units();
+    a.ncu = ncu;
+    a.linger = shadow_linger_ticks();
     switch (g.L) {
         case 1024: return is_block ? launch_pair_steps<true, 2, 8>(st0, a, grid, s) : launch_pair_steps<false, 2, 8>(st0, a, grid, s);
         case 2048: return is_block ? launch_pair_steps<true, SDH_L2048_LOG_E, SDH_L2048_LOG_T>(st0, a, grid, s)

@@ -2,7 +2,9 @@
 // (development tool): when do the base workgroups finish, when do the residual waves finish their
 // own work, and how long do they wait for the base term.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -o tools/bin/fused_diag tools/fused_diag.hip
+#ifndef SDH_DIAG_NO_STAMPS
 #define SDH_DIAG_STAMPS 1
+#endif
 #include "../llama.cpp_amd/csrc/sdh_api.hip"
 #include "../llama.cpp_amd/csrc/sdh_base.hip"
 #include "../llama.cpp_amd/csrc/sdh_delta.hip"
@@ -25,9 +27,10 @@ static sdh_tensor mk(const void * d, int type, int nd, int64_t n0, int64_t n1, i
     return t;
 }
 
-int main() {
+int main(int argc, char ** argv) {
+    const int BURST = argc > 1 ? atoi(argv[1]) : 1;
     const int L = 4096, B = 4, NIN = 14336, NOUT = 4096, NB = 48, BLOCK = 32, NPAY = 32, ITERS = 160;
-    const int GRID = B + NOUT / 8;      // 512-thread workgroups: 8 rows each
+    const int GRID = B + NOUT / 8 + 16;  // 512-thread workgroups, 8 rows each, plus shadow ids (sdh_decode.hip)
     CK(hipSetDevice(0));
     if (sdh_init(0) != 0) { fprintf(stderr, "init: %s\n", sdh_last_error()); return 1; }
     hipStream_t s;
@@ -62,35 +65,63 @@ int main() {
     unsigned long long * dbg;
     const size_t DB = (size_t) GRID * 32 * 8;
     CK(hipMalloc((void **) &dbg, DB));
+#ifdef SDH_DIAG_STAMPS
     CK(hipMemcpyToSymbol(HIP_SYMBOL(sdh_diag_buf), &dbg, sizeof(dbg)));
+#endif
     std::vector<unsigned long long> h((size_t) GRID * 32);
     double a_base_pub = 0, a_base_done = 0, a_base_x = 0, a_red_mean = 0, a_red_max = 0, a_wait_mean = 0, a_end_max = 0, a_start_max = 0;
     int n = 0;
+    hipEvent_t ev0, ev1;
+    CK(hipEventCreate(&ev0)); CK(hipEventCreate(&ev1));
+    if (argc > 2) {       // fused_diag <burst> <n>: back-to-back launch period from C++ (no stamps read), n launches
+        const int N = atoi(argv[2]);
+        for (int k = 0; k < 256; ++k) sdh_forward(ws[k % NPAY], xs[k % NPAY], NIN, 1, y, NOUT, 0, s);
+        CK(hipStreamSynchronize(s));
+        CK(hipEventRecord(ev0, s));
+        for (int k = 0; k < N; ++k) sdh_forward(ws[k % NPAY], xs[k % NPAY], NIN, 1, y, NOUT, 0, s);
+        CK(hipEventRecord(ev1, s));
+        CK(hipStreamSynchronize(s));
+        float ms = 0; CK(hipEventElapsedTime(&ms, ev0, ev1));
+        printf("back-to-back period over %d launches driven from C++: %.3f us\n", N, ms * 1e3 / N);
+        return 0;
+    }
+    double a_event_us = 0;
     for (int it = 0; it < ITERS; ++it) {
         const int p = it % NPAY;
         CK(hipMemsetAsync(dbg, 0, DB, s));
+        // BURST > 1: that many launches back to back on rotating payloads; the stamps read are the last one's
+        for (int k = 0; k + 1 < BURST; ++k)
+            if (sdh_forward(ws[(p + 1 + k) % NPAY], xs[(p + 1 + k) % NPAY], NIN, 1, y, NOUT, 0, s) != 0) { fprintf(stderr, "fwd: %s\n", sdh_last_error()); return 1; }
+        CK(hipEventRecord(ev0, s));
         if (sdh_forward(ws[p], xs[p], NIN, 1, y, NOUT, 0, s) != 0) { fprintf(stderr, "fwd: %s\n", sdh_last_error()); return 1; }
+        CK(hipEventRecord(ev1, s));
         CK(hipStreamSynchronize(s));
         if (it < 64) continue;       // census + warm-up
+        { float ms = 0; CK(hipEventElapsedTime(&ms, ev0, ev1)); a_event_us += ms * 1e3; }
         CK(hipMemcpy(h.data(), dbg, DB, hipMemcpyDeviceToHost));
         unsigned long long t0 = ~0ull;
-        for (int g = 0; g < GRID; ++g) { unsigned long long st = h[(size_t) g * 32 + (g < B ? 1 : 10)]; if (g >= B && st && st < t0) t0 = st; }
+        // time zero: the earliest stamp of the launch (a residual workgroup's start; the base role has no stamp before its loads land)
+        for (int g = B; g < GRID; ++g) { unsigned long long st = h[(size_t) g * 32 + 10]; if (st && st < t0) t0 = st; }
+        for (int b = 0; b < B; ++b) { unsigned long long st = h[(size_t) b * 32 + 1]; if (st && st < t0) t0 = st; }
         double base_pub = 0, base_done = 0, base_x = 0, red_mean = 0, red_max = 0, wait_mean = 0, end_max = 0, start_max = 0;
         for (int b = 0; b < B; ++b) {
             base_done = std::max(base_done, (double) (h[(size_t) b * 32 + 5] - t0) * 0.01);
             base_pub = std::max(base_pub, (double) (h[(size_t) b * 32 + 6] - t0) * 0.01);
             base_x = std::max(base_x, (double) (h[(size_t) b * 32 + 1] - t0) * 0.01);
         }
+        int nres = 0;
         for (int g = B; g < GRID; ++g) {
+            if (!h[(size_t) g * 32 + 10]) continue;          // shadow or unused id: no stamps
+            ++nres;
             const double st = (double) (h[(size_t) g * 32 + 10] - t0) * 0.01, r = (double) (h[(size_t) g * 32 + 11] - t0) * 0.01,
                          e = (double) (h[(size_t) g * 32 + 12] - t0) * 0.01;
             red_mean += r; red_max = std::max(red_max, r); wait_mean += e - r; end_max = std::max(end_max, e); start_max = std::max(start_max, st);
         }
-        red_mean /= (GRID - B); wait_mean /= (GRID - B);
+        red_mean /= std::max(nres, 1); wait_mean /= std::max(nres, 1);
         a_base_pub += base_pub; a_base_done += base_done; a_base_x += base_x; a_red_mean += red_mean; a_red_max += red_max; a_wait_mean += wait_mean; a_end_max += end_max; a_start_max += start_max;
         ++n;
     }
-    printf("fused decode kernel, cfg3 shape, us since the first residual workgroup started (mean over %d launches)\n", n);
+    printf("fused decode kernel, cfg3 shape, us since the earliest stamp of the launch (mean over %d launches)\n", n);
     printf("  last residual workgroup starts        %6.2f\n", a_start_max / n);
     printf("  base: x landed (slowest block)        %6.2f\n", a_base_x / n);
     printf("  base: second FWHT done (slowest)      %6.2f\n", a_base_done / n);
@@ -98,5 +129,15 @@ int main() {
     printf("  residual: own sum reduced, mean / max %6.2f / %6.2f\n", a_red_mean / n, a_red_max / n);
     printf("  residual: wait for the base, mean     %6.2f\n", a_wait_mean / n);
     printf("  last residual wave has its base term  %6.2f\n", a_end_max / n);
+    printf("  HIP events around the (isolated) launch  %6.2f\n", a_event_us / n);
+    {   // base block 0 of the last launch, phase by phase (stamps 1..6 of sdh_base_dev.h / sdh_decode.hip)
+        unsigned long long t0 = ~0ull;
+        for (int g = 0; g < GRID; ++g) for (int k : {1, 10}) { unsigned long long st = h[(size_t) g * 32 + k]; if (st && st < t0) t0 = st; }
+        for (int b = 0; b < B; ++b) {
+            printf("  base block %d (last launch): x,d1 landed %.2f | P1 gathered %.2f | FWHT1 %.2f | D2/back %.2f | FWHT2 %.2f | published %.2f\n", b,
+                   (double) (h[(size_t) b * 32 + 1] - t0) * 0.01, (double) (h[(size_t) b * 32 + 2] - t0) * 0.01, (double) (h[(size_t) b * 32 + 3] - t0) * 0.01,
+                   (double) (h[(size_t) b * 32 + 4] - t0) * 0.01, (double) (h[(size_t) b * 32 + 5] - t0) * 0.01, (double) (h[(size_t) b * 32 + 6] - t0) * 0.01);
+        }
+    }
     return 0;
 }
