@@ -161,7 +161,12 @@ def run_scan(args, rank, world, dev):
         for k in (SC.KINDS if c.kind != "ffn_down" else (c.kind,)):
             ev.dense(c.layer, k)
     dense_bytes = sum(w.stored_bytes for w in ev._cache.values())
-    ev.run_many(mine[:2], threads=2, params_of=lambda c: variants[c.variant])        # warm-up
+    # warm-up on the worker pool the timed run uses: every worker creates its scan handle (stream, events,
+    # device buffers) and the Gaussian-draw memo is filled, as in a sweep that has been running for a while
+    warm_n = min(len(mine), 8 * args.scan_threads)
+    ev.run_many(mine[:: max(1, len(mine) // max(1, warm_n))][:warm_n], threads=args.scan_threads, params_of=lambda c: variants[c.variant])
+    from llama_cpp_amd import seeddelta as _sd
+    _sd.load_library().sdh_scan_memo_clear()          # the timed sweep makes every distinct draw itself
     torch.cuda.synchronize()
     if world > 1:
         import torch.distributed as dist
@@ -185,7 +190,7 @@ def run_scan(args, rank, world, dev):
     if rank == 0 and args.scan_payload_sample > 0 and mine:
         full = scan_variants(metrics_only=False)
         sample = mine[:: max(1, len(mine) // args.scan_payload_sample)][: args.scan_payload_sample]
-        ev.run_many(sample[:2], threads=2, params_of=lambda c: full[c.variant])
+        ev.run_many(sample[:2], threads=args.scan_threads, params_of=lambda c: full[c.variant])
         t1 = time.perf_counter()
         ev.run_many(sample, threads=args.scan_threads, params_of=lambda c: full[c.variant])
         payload = {"value": len(sample) / (time.perf_counter() - t1), "unit": "candidates/s", "candidates": len(sample),

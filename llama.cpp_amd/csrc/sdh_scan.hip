@@ -995,6 +995,11 @@ int sdh_scan_create(uint32_t seed, sdh_scan ** out) {
     return SDH_OK;
 }
 
+void sdh_scan_memo_clear(void) {
+    std::lock_guard<std::mutex> lock(g_memo_mu);
+    g_memo.clear();
+}
+
 int sdh_scan_reseed(sdh_scan * h, uint32_t seed) {
     if (!h) { set_error("sdh_scan_reseed: null handle"); return SDH_ERR_INVALID; }
     ((Scan *) h)->rng.seed(seed);

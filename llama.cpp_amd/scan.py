@@ -438,6 +438,18 @@ class Evaluator:
         self._tls = threading.local()
         self._sessions: List[ScanSession] = []
         self._sessions_lock = threading.Lock()
+        self._pool = None               # worker threads live as long as the evaluator: their handles stay warm
+        self._pool_threads = 0
+
+    def _workers(self, threads: int):
+        from concurrent.futures import ThreadPoolExecutor
+        threads = max(1, threads)
+        if self._pool is None or self._pool_threads != threads:
+            if self._pool is not None:
+                self._pool.shutdown(wait=True)
+            self._pool = ThreadPoolExecutor(max_workers=threads)
+            self._pool_threads = threads
+        return self._pool
 
     def _session(self, seed: int) -> ScanSession:
         s = getattr(self._tls, "session", None)
@@ -454,7 +466,6 @@ class Evaluator:
         stream, and drawing its samples (std::shuffle, ~26 ns per Gaussian) is the host-side cost of a
         candidate, so several are prepared concurrently while the GPU works through their kernels in
         stream order. Dense tensors are uploaded by the calling thread before the pool touches them."""
-        from concurrent.futures import ThreadPoolExecutor
         out: Dict[int, dict] = {}
         layers: Dict[int, List[Candidate]] = {}
         for c in cands:
@@ -472,7 +483,8 @@ class Evaluator:
 
         fn = lambda g: self.run_group(g, params_of(g[0]) if params_of else None)      # noqa: E731
         want = [key for layer, group in layers.items() for key in needed(layer, group)]
-        with ThreadPoolExecutor(max_workers=max(1, threads)) as pool:
+        pool = self._workers(threads)
+        if True:
             if len(set(want)) <= self.max_resident:                   # everything fits: one wave of work
                 for key in want:
                     self.dense(*key)
@@ -548,6 +560,9 @@ class Evaluator:
         return out
 
     def close(self):
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
         with self._sessions_lock:
             for s in self._sessions:
                 s.close()
