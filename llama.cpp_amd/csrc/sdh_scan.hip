@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
 #include <deque>
 #include <memory>
@@ -814,32 +815,41 @@ static std::vector<int> draw_rows(std::mt19937 & rng, int64_t n_out, int64_t wan
 // to the state it would have reached. Lookups compare the full mt19937 state (operator==).
 struct NormalMemo {
     std::mt19937 before, after;
-    int64_t n;
+    int64_t n = 0;
+    bool ready = false;                 // false while the first caller is still drawing
     std::shared_ptr<const std::vector<float>> vals;
 };
 static std::mutex g_memo_mu;
-static std::deque<NormalMemo> g_memo;
+static std::condition_variable g_memo_cv;
+static std::deque<std::shared_ptr<NormalMemo>> g_memo;
 
 static std::shared_ptr<const std::vector<float>> draw_normals(std::mt19937 & rng, int64_t n) {
+    std::shared_ptr<NormalMemo> mine;
     {
-        std::lock_guard<std::mutex> lock(g_memo_mu);
-        for (const NormalMemo & m : g_memo) {
-            if (m.n == n && m.before == rng) { rng = m.after; return m.vals; }
+        std::unique_lock<std::mutex> lock(g_memo_mu);
+        for (const auto & m : g_memo) {
+            if (m->n == n && m->before == rng) {
+                g_memo_cv.wait(lock, [&] { return m->ready; });      // someone is drawing exactly this: wait for it
+                rng = m->after;
+                return m->vals;
+            }
         }
+        mine = std::make_shared<NormalMemo>();
+        mine->before = rng;
+        mine->n = n;
+        g_memo.push_back(mine);
+        while (g_memo.size() > 96) g_memo.pop_front();               // holders keep evicted entries alive
     }
-    NormalMemo m;
-    m.before = rng;
-    m.n = n;
     auto v = std::make_shared<std::vector<float>>((size_t) n);
     std::normal_distribution<float> nd(0.0f, 1.0f);
     for (int64_t i = 0; i < n; ++i) (*v)[(size_t) i] = nd(rng);
-    m.after = rng;
-    m.vals = v;
     {
         std::lock_guard<std::mutex> lock(g_memo_mu);
-        g_memo.push_back(m);
-        while (g_memo.size() > 96) g_memo.pop_front();
+        mine->after = rng;
+        mine->vals = v;
+        mine->ready = true;
     }
+    g_memo_cv.notify_all();
     return v;
 }
 
