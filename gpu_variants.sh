@@ -8,5 +8,5 @@ timeout -k 10 600 python -u -m pytest tests/test_gpu_forward.py tests/test_gpu_f
 rc=$?; tail -3 gpurun_out/pytest_dev.log; [ $rc -ne 0 ] && exit $rc
 fi
 run base ""
-for v in ${VARIANTS:-t256 delay24}; do run $v $GRAFT_REPO_ROOT/tools/bin/variants/$v/libseeddelta_hip.so; done
+for v in ${VARIANTS:-t256 t1024 swizzle}; do run $v $GRAFT_REPO_ROOT/tools/bin/variants/$v/libseeddelta_hip.so; done
 run base ""

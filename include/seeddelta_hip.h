@@ -163,7 +163,9 @@ int64_t sdh_nonfinite_count(sdh_weight * w);
  * SDH_FWD_ZERO_NONFINITE, zeroed before the activation, as the reference's guard does per node. A
  * caller that wants the dense repair (src/llama-seeddelta.cpp:294-361) re-runs the layer node by
  * node when a count is non-zero. Other flags as sdh_forward (SDH_FWD_NO_FUSE also disables the
- * gate|up launch). */
+ * gate|up launch). The intermediate activations live in one workspace per device: FFN calls on a
+ * device must not overlap (issue them on one stream, as a decode loop does); like sdh_forward, calls
+ * that overlap on one weight handle race on its hand-off buffer. */
 #define SDH_ACT_SILU 0
 #define SDH_ACT_GELU 1
 int sdh_ffn_forward(sdh_weight * gate, sdh_weight * up, sdh_weight * down, int act,

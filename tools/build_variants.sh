@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/../llama.cpp_amd/csrc"
 make -j8 >/dev/null
-for v in ${VARIANTS:-"t256:-DSDH_DECODE_L4096_T256" "delay24:-DSDH_RESID_DELAY=24"}; do
+for v in ${VARIANTS:-"t256:-DSDH_DECODE_L4096_T256" "t1024:-DSDH_DECODE_L4096_T1024" "swizzle:-DSDH_BASE_SWIZZLE"}; do
   name=${v%%:*}; flag=${v#*:}
   out=../../tools/bin/variants/$name; mkdir -p $out
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $flag -c sdh_decode.hip -o $out/sdh_decode.o
