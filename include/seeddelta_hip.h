@@ -242,6 +242,10 @@ typedef struct sdh_scan_params {
                                        :1052, sd_ffn_proxy.cpp:60-75) and no payload is kept. This is the layer-scan /
                                        autogate use, where the builder's output GGUF is discarded.              */
     int32_t reserved0;
+    double  delta_norm_clamp_down; /* (--delta-norm-clamp-down, default 0 = off) ffn_down, COO only: if the L2 norm
+                                       of all residual values exceeds clamp * ||W||_2 they are scaled down to it
+                                       before the metrics are taken (sd_build.cpp:29-46, :384-386, :705-720).
+                                       Needs every row, so it overrides metrics_only for that candidate.        */
 } sdh_scan_params;
 
 /* What one report.json entry is computed from (tools/seeddelta-build/sd_report.cpp:112-288). Metric
@@ -264,6 +268,7 @@ typedef struct sdh_scan_result {
     int32_t reserved;
     double  em_w[5];            /* weight-space metrics with the imatrix weighting                       */
     double  em_x_w[5];          /* activation-space metrics with x drawn as N(0,1) * w_scale             */
+    double  delta_clamp_scale;  /* factor applied by delta_norm_clamp_down, 1.0 when it did not act       */
 } sdh_scan_result;
 
 /* The builder's per-input weighting from an importance matrix row (sd_make_imatrix_sqrt_scale,

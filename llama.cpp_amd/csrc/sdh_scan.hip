@@ -586,6 +586,40 @@ void scan_select_block_kernel(DenseView W, BaseView base, int has_base, int bloc
     }
 }
 
+// ---- kernels: --delta-norm-clamp-down (sd_build.cpp:29-46, :705-720) --------------------------------------
+// per-row sums of squares in double (tree-reduced; the host adds the rows in order), and the rescale
+template <int DT>
+__global__ __launch_bounds__(256)
+void scan_row_sumsq_dense_kernel(DenseView W, double * __restrict__ out /* [n_out] */) {
+    __shared__ double dsc[4];
+    const int64_t row = blockIdx.x;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < (int) W.n_in; i += 256) {
+        const double v = (double) dense_at<DT>(W, row, i);
+        acc += v * v;
+    }
+    acc = block_sum(acc, dsc);
+    if (threadIdx.x == 0) out[row] = acc;
+}
+
+__global__ __launch_bounds__(256)
+void scan_row_sumsq_vals_kernel(const float * __restrict__ val, int K, double * __restrict__ out /* [n_out] */) {
+    __shared__ double dsc[4];
+    const int64_t row = blockIdx.x;
+    double acc = 0.0;
+    for (int e = threadIdx.x; e < K; e += 256) {
+        const double v = (double) val[row * K + e];
+        acc += v * v;
+    }
+    acc = block_sum(acc, dsc);
+    if (threadIdx.x == 0) out[row] = acc;
+}
+
+__global__ void scan_scale_vals_kernel(float * __restrict__ val, int64_t n, double scale) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) val[i] = (float) ((double) val[i] * scale);           // v = (float) (v * scale), :716
+}
+
 // ---- kernel: weight-space metric triples (w_norm2, hat_norm2, dot) per sampled row -------------------
 template <int DT>
 __global__ __launch_bounds__(256)
@@ -1155,7 +1189,8 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
     // ---- selection ------------------------------------------------------------------------------------
     // select(rows_dev, n_sel): rows_dev == null selects every output row into [n_out] slots (the payload);
     // otherwise only the listed rows, into compact slots [n_sel] in list order (metrics_only)
-    const bool metrics_only = p.metrics_only != 0;
+    const bool clamp_applies = p.delta_norm_clamp_down > 0.0 && p.kind == 2 && p.scheme == 0;   // ffn_down, d_val non-empty
+    const bool metrics_only = p.metrics_only != 0 && !clamp_applies;
     const int compact = metrics_only ? 1 : 0;
     const size_t r_bytes = ((size_t) n_in * 4 + 15) & ~(size_t) 15;
     static const bool lds_attr_set = [] {
@@ -1201,6 +1236,27 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
     };
     s.emitted = !metrics_only;
     if (!metrics_only && (rc = select(nullptr, n_out))) return rc;
+    out->delta_clamp_scale = 1.0;
+    if (clamp_applies && K_eff > 0) {
+        if ((rc = s.dbl.ensure((size_t) n_out * 2))) return rc;
+        SDH_LAUNCH_DT(W, scan_row_sumsq_dense_kernel, dim3((unsigned) n_out), dim3(256), 0, st, W, s.dbl.p);
+        hipLaunchKernelGGL(scan_row_sumsq_vals_kernel, dim3((unsigned) n_out), dim3(256), 0, st, s.val.p, (int) K_eff, s.dbl.p + n_out);
+        SDH_HIP_CHECK(hipGetLastError());
+        std::vector<double> sq((size_t) n_out * 2);
+        SDH_HIP_CHECK(hipMemcpyAsync(sq.data(), s.dbl.p, sq.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        SDH_HIP_CHECK(hipStreamSynchronize(st));
+        double w2 = 0.0, d2sum = 0.0;
+        for (int64_t o = 0; o < n_out; ++o) { w2 += sq[(size_t) o]; d2sum += sq[(size_t) (n_out + o)]; }
+        const double w_l2 = w2 > 0.0 ? std::sqrt(w2) : 0.0, delta_norm = d2sum > 0.0 ? std::sqrt(d2sum) : 0.0;
+        const double limit = p.delta_norm_clamp_down * w_l2;
+        if (w_l2 > 0.0 && limit > 0.0 && delta_norm > limit) {
+            const double scale = limit / delta_norm;
+            const int64_t nv = n_out * K_eff;
+            hipLaunchKernelGGL(scan_scale_vals_kernel, dim3((unsigned) ((nv + 255) / 256)), dim3(256), 0, st, s.val.p, nv, scale);
+            SDH_HIP_CHECK(hipGetLastError());
+            out->delta_clamp_scale = scale;
+        }
+    }
     const float * rs_dev = nullptr;      // set once s.rs is allocated (select() may move it)
 
     // ---- cost model (sd_cost.cpp:7-40) --------------------------------------------------------------

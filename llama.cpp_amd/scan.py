@@ -85,6 +85,7 @@ class ScanParams:
     metric: str = "cos"            # policy gating metric
     w_scale: Optional[np.ndarray] = None   # imatrix scale for this tensor (imatrix_scale()); None = no imatrix
     base_mode: int = 0             # 0 fit; 1 reuse the previous fit, no draws; 2 reuse it, replay its draws
+    delta_norm_clamp_down: float = 0.0   # --delta-norm-clamp-down (ffn_down, COO): cap ||delta||_2 at this multiple of ||W||_2
     metrics_only: bool = False     # select only the rows the metric passes sample: same report entry, no payload
                                    # to fetch (what layer-scan / autogate need; build_run keeps the full selection)
 
@@ -100,6 +101,7 @@ class ScanParams:
         p.proxy_seed = self.seed + layer * 101 + KIND_ID[kind] + 1        # sd_build.cpp:1032
         p.base_mode = self.base_mode if self.base else 0
         p.metrics_only = int(self.metrics_only)
+        p.delta_norm_clamp_down = float(self.delta_norm_clamp_down)
         if self.w_scale is not None:
             self._ws = np.ascontiguousarray(self.w_scale, dtype=np.float32)   # kept alive for the call
             p.w_scale = self._ws.ctypes.data
@@ -140,7 +142,8 @@ class ScanSession:
                 "has_x": bool(r.has_x), "has_w": bool(r.has_w), "proxy_available": bool(r.proxy_available),
                 "em": np.array(r.em[:]), "em_x": np.array(r.em_x[:]), "em_w": np.array(r.em_w[:]),
                 "em_x_w": np.array(r.em_x_w[:]), "cost": np.array(r.cost[:]),
-                "proxy": np.array(r.proxy[:]), "gpu_ms": float(r.gpu_ms)}
+                "proxy": np.array(r.proxy[:]), "gpu_ms": float(r.gpu_ms),
+                "delta_clamp_scale": float(r.delta_clamp_scale)}
 
     def reseed(self, seed: int):
         """A new builder run on this handle (fresh mt19937), keeping device buffers and the last fit."""

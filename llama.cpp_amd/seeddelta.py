@@ -55,7 +55,7 @@ class SdhScanParams(C.Structure):
                 ("write_base", C.c_int32), ("write_row_scale", C.c_int32), ("base_max_samples", C.c_int64),
                 ("base_perm_trials", C.c_int32), ("want_proxy", C.c_int32), ("eval_cols", C.c_int64),
                 ("eval_x", C.c_int64), ("proxy_seed", C.c_int32), ("base_mode", C.c_int32), ("w_scale", C.c_void_p),
-                ("metrics_only", C.c_int32), ("reserved0", C.c_int32)]
+                ("metrics_only", C.c_int32), ("reserved0", C.c_int32), ("delta_norm_clamp_down", C.c_double)]
 
 
 class SdhScanResult(C.Structure):
@@ -63,7 +63,7 @@ class SdhScanResult(C.Structure):
                 ("has_x", C.c_int32), ("proxy_available", C.c_int32), ("em", C.c_double * 5),
                 ("em_x", C.c_double * 5), ("cost", C.c_double * 8), ("proxy", C.c_double * 8),
                 ("gpu_ms", C.c_double), ("has_w", C.c_int32), ("reserved", C.c_int32),
-                ("em_w", C.c_double * 5), ("em_x_w", C.c_double * 5)]
+                ("em_w", C.c_double * 5), ("em_x_w", C.c_double * 5), ("delta_clamp_scale", C.c_double)]
 
 
 class SeedDeltaError(RuntimeError):

@@ -282,3 +282,14 @@ def percentile(v, p):
     lib.sdso_percentile.restype = C.c_double
     v = np.ascontiguousarray(v, dtype=np.float64)
     return float(lib.sdso_percentile(_p(v), C.c_int64(len(v)), C.c_double(p)))
+
+
+def delta_clamp(W, val: np.ndarray, clamp: float):
+    """--delta-norm-clamp-down on the residual values of one tensor (in place) -> scale applied."""
+    lib = oracle_lib()
+    lib.sdso_tensor_l2_norm.restype = C.c_double
+    lib.sdso_delta_clamp.restype = C.c_double
+    t = w_tensor(W)
+    w_l2 = lib.sdso_tensor_l2_norm(C.byref(t))
+    assert val.dtype == np.float32 and val.flags.c_contiguous
+    return float(lib.sdso_delta_clamp(_p(val), C.c_int64(val.size), C.c_double(w_l2), C.c_double(clamp)))

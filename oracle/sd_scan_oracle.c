@@ -743,3 +743,34 @@ void sdso_cost(int64_t L, int64_t B, int64_t n_in, int64_t n_out, int64_t K, int
     o[6] = o[3] + o[4] + o[5];
     o[7] = o[2] > 0.0 ? o[6] / o[2] : 0.0;
 }
+
+/* ---- --delta-norm-clamp-down (see sd_scan_oracle.h) --------------------------------------------- */
+double sdso_tensor_l2_norm(const sdo_tensor * W) {
+    const int64_t n_in = W->ne[0], n_out = W->ne[1];
+    if (n_in <= 0 || n_out <= 0) return 0.0;
+    float * col = (float *) malloc((size_t) n_in * sizeof(float));
+    double sum = 0.0;
+    for (int64_t j = 0; j < n_out; ++j) {
+        sdso_read_row(W, j, col);
+        for (int64_t i = 0; i < n_in; ++i) {
+            const double dv = (double) col[i];
+            sum += dv * dv;
+        }
+    }
+    free(col);
+    return sum > 0.0 ? sqrt(sum) : 0.0;
+}
+
+double sdso_delta_clamp(float * val, int64_t n, double w_l2_norm, double clamp) {
+    if (!(clamp > 0.0) || n <= 0 || !(w_l2_norm > 0.0)) return 1.0;
+    double delta_norm = 0.0;
+    for (int64_t i = 0; i < n; ++i) delta_norm += (double) val[i] * (double) val[i];
+    delta_norm = delta_norm > 0.0 ? sqrt(delta_norm) : 0.0;
+    const double limit = clamp * w_l2_norm;
+    if (limit > 0.0 && delta_norm > limit) {
+        const double scale = limit / delta_norm;
+        for (int64_t i = 0; i < n; ++i) val[i] = (float) (val[i] * scale);
+        return scale;
+    }
+    return 1.0;
+}

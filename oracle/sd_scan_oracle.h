@@ -69,6 +69,11 @@ int     sdso_ffn_proxy(int kind, const sdo_tensor * Wg, const sdo_tensor * Wu, c
                        int64_t eval_x, int64_t eval_cols, int seed, double * out8);
 void    sdso_cost(int64_t L, int64_t B, int64_t n_in, int64_t n_out, int64_t K, int row_scale, double * out8);
 double  sdso_percentile(const double * v, int64_t n, double p);
+/* --delta-norm-clamp-down: ||W||_2 as sd_tensor_l2_norm (sd_build.cpp:29-46: one running double sum over
+ * rows and elements), then the clamp of the residual values (:705-720). Returns the scale applied (1.0
+ * if none). PARITY UNPINNED against a compiled reference: sd_build.cpp does not build here. */
+double  sdso_tensor_l2_norm(const sdo_tensor * W);
+double  sdso_delta_clamp(float * val, int64_t n, double w_l2_norm, double clamp);
 
 #ifdef __cplusplus
 }
