@@ -453,6 +453,34 @@ int64_t sdh_weight_payload_bytes(const sdh_weight * h) {
     return reinterpret_cast<const DeviceWeight *>(h)->payload_bytes;
 }
 
+// host -> device of an [n_tokens][n] F32 activation with row stride ld (elements): through the pinned
+// bounce buffer when it fits, else a pageable 2-D copy
+static int host_to_device(LibState & L, float * dst, const float * src, int64_t ld, int64_t n, int64_t n_tokens, hipStream_t s) {
+    const size_t bytes = (size_t) n_tokens * (size_t) n * 4;
+    if (bytes <= LibState::PIN_BYTES) {
+        if (!L.pin_x) SDH_HIP_CHECK(hipHostMalloc((void **) &L.pin_x, LibState::PIN_BYTES, hipHostMallocDefault));
+        for (int64_t t = 0; t < n_tokens; ++t) memcpy(L.pin_x + t * n, src + t * ld, (size_t) n * 4);
+        SDH_HIP_CHECK(hipMemcpyAsync(dst, L.pin_x, bytes, hipMemcpyHostToDevice, s));
+        return SDH_OK;
+    }
+    SDH_HIP_CHECK(hipMemcpy2DAsync(dst, (size_t) n * 4, src, (size_t) ld * 4, (size_t) n * 4, (size_t) n_tokens, hipMemcpyHostToDevice, s));
+    return SDH_OK;
+}
+// device -> host, then wait for the stream
+static int device_to_host_sync(LibState & L, float * dst, int64_t ld, const float * src, int64_t n, int64_t n_tokens, hipStream_t s) {
+    const size_t bytes = (size_t) n_tokens * (size_t) n * 4;
+    if (bytes <= LibState::PIN_BYTES) {
+        if (!L.pin_y) SDH_HIP_CHECK(hipHostMalloc((void **) &L.pin_y, LibState::PIN_BYTES, hipHostMallocDefault));
+        SDH_HIP_CHECK(hipMemcpyAsync(L.pin_y, src, bytes, hipMemcpyDeviceToHost, s));
+        SDH_HIP_CHECK(hipStreamSynchronize(s));
+        for (int64_t t = 0; t < n_tokens; ++t) memcpy(dst + t * ld, L.pin_y + t * n, (size_t) n * 4);
+        return SDH_OK;
+    }
+    SDH_HIP_CHECK(hipMemcpy2DAsync(dst, (size_t) ld * 4, src, (size_t) n * 4, (size_t) n * 4, (size_t) n_tokens, hipMemcpyDeviceToHost, s));
+    SDH_HIP_CHECK(hipStreamSynchronize(s));
+    return SDH_OK;
+}
+
 // per-call non-finite counter: ring slot, the second half of the ring is re-zeroed while the
 // first half is in use (one small memset every NF_SLOTS/2 calls, none on the other calls)
 static int nf_slot(DeviceWeight * w, hipStream_t s, int * slot_out) {
@@ -496,8 +524,7 @@ int sdh_forward(sdh_weight * h, const float * x, int64_t ldx, int64_t n_tokens,
             L.hy = nullptr; L.hy_bytes = 0;
             SDH_HIP_CHECK(hipMalloc((void **) &L.hy, yb)); L.hy_bytes = yb;
         }
-        SDH_HIP_CHECK(hipMemcpy2DAsync(L.hx, (size_t) w->n_in * 4, x, (size_t) ldx * 4, (size_t) w->n_in * 4,
-                                       (size_t) n_tokens, hipMemcpyHostToDevice, s));
+        { int rc = host_to_device(L, L.hx, x, ldx, w->n_in, n_tokens, s); if (rc != SDH_OK) return rc; }
         dx = L.hx; dy = L.hy; dldx = w->n_in; dldy = w->n_out;
     }
 
@@ -580,9 +607,8 @@ int sdh_forward(sdh_weight * h, const float * x, int64_t ldx, int64_t n_tokens,
     ls.span_forwards++;
 
     if (host_io) {
-        SDH_HIP_CHECK(hipMemcpy2DAsync(y, (size_t) ldy * 4, dy, (size_t) w->n_out * 4, (size_t) w->n_out * 4,
-                                       (size_t) n_tokens, hipMemcpyDeviceToHost, s));
-        SDH_HIP_CHECK(hipStreamSynchronize(s));
+        int rc = device_to_host_sync(ls, y, ldy, dy, w->n_out, n_tokens, s);
+        if (rc != SDH_OK) return rc;
     }
     return SDH_OK;
 }
@@ -693,16 +719,15 @@ int sdh_ffn_gate_up(sdh_weight * hg, sdh_weight * hu, int act, const float * x, 
     if ((rc = ffn_workspace(ls, s, sec, 4, ws)) != SDH_OK) return rc;
     const float * dx = x; int64_t dldx = ldx;
     if (host_io) {
-        SDH_HIP_CHECK(hipMemcpy2DAsync(ws[0], (size_t) n_embd * 4, x, (size_t) ldx * 4, (size_t) n_embd * 4, T, hipMemcpyHostToDevice, s));
+        if ((rc = host_to_device(ls, ws[0], x, ldx, n_embd, n_tokens, s)) != SDH_OK) return rc;
         dx = ws[0]; dldx = n_embd;
     }
     float * hbuf = dense_h ? h : ws[1];
     if ((rc = ffn_gate_up(hg, hu, act, dx, dldx, n_tokens, hbuf, ws[2], ws[3], flags & ~SDH_FWD_HOST_IO, s)) != SDH_OK) return rc;
+    if (host_io) return device_to_host_sync(ls, h, ldh, hbuf, n_ff, n_tokens, s);
     if (!dense_h) {
-        SDH_HIP_CHECK(hipMemcpy2DAsync(h, (size_t) ldh * 4, hbuf, (size_t) n_ff * 4, (size_t) n_ff * 4, T,
-                                       host_io ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, s));
+        SDH_HIP_CHECK(hipMemcpy2DAsync(h, (size_t) ldh * 4, hbuf, (size_t) n_ff * 4, (size_t) n_ff * 4, T, hipMemcpyDeviceToDevice, s));
     }
-    if (host_io) SDH_HIP_CHECK(hipStreamSynchronize(s));
     return SDH_OK;
 }
 
@@ -732,16 +757,13 @@ int sdh_ffn_forward(sdh_weight * hg, sdh_weight * hu, sdh_weight * hd, int act,
     const float * dx = x; int64_t dldx = ldx;
     float * dy = y; int64_t dldy = ldy;
     if (host_io) {
-        SDH_HIP_CHECK(hipMemcpy2DAsync(ws[0], (size_t) n_embd * 4, x, (size_t) ldx * 4, (size_t) n_embd * 4, T, hipMemcpyHostToDevice, s));
+        if ((rc = host_to_device(ls, ws[0], x, ldx, n_embd, n_tokens, s)) != SDH_OK) return rc;
         dx = ws[0]; dldx = n_embd; dy = ws[1]; dldy = d->n_out;
     }
     const int sub = flags & ~SDH_FWD_HOST_IO;
     if ((rc = ffn_gate_up(hg, hu, act, dx, dldx, n_tokens, ws[2], ws[3], ws[4], sub, s)) != SDH_OK) return rc;
     if ((rc = sdh_forward(hd, ws[2], n_ff, n_tokens, dy, dldy, sub, s)) != SDH_OK) return rc;
-    if (host_io) {
-        SDH_HIP_CHECK(hipMemcpy2DAsync(y, (size_t) ldy * 4, dy, (size_t) d->n_out * 4, (size_t) d->n_out * 4, T, hipMemcpyDeviceToHost, s));
-        SDH_HIP_CHECK(hipStreamSynchronize(s));
-    }
+    if (host_io) return device_to_host_sync(ls, y, ldy, dy, d->n_out, n_tokens, s);
     return SDH_OK;
 }
 

@@ -86,6 +86,10 @@ struct LibState {
     // staging for host-IO forwards
     float * hx = nullptr; size_t hx_bytes = 0;
     float * hy = nullptr; size_t hy_bytes = 0;
+    // pinned bounce buffers for small host-IO transfers (a decode step): a pageable hipMemcpy stages and
+    // synchronises inside the driver, a pinned one is a plain DMA
+    static constexpr size_t PIN_BYTES = 512 * 1024;
+    float * pin_x = nullptr; float * pin_y = nullptr;
     unsigned * census_ctr = nullptr;    // residency census of the fused decode kernel (sdh_decode.hip)
     // gated FFN block (sdh_ffn.hip): f16 GELU table as ggml builds it, intermediate activations
     uint16_t * gelu_tab = nullptr;      // [65536] device
