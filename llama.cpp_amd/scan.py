@@ -593,7 +593,9 @@ def layer_scan(model: ModelFn, layers: Sequence[int], params: ScanParams, tensor
                  "strip_dense": False, "imatrix": ""},
         "layers": {}, "errors": [],
     }
-    ev = Evaluator(model, params, tensors)
+    # the scan reads report entries only (the reference discards the builder's output GGUF here), so every
+    # candidate selects just the rows its metric passes sample: identical entries, far less work
+    ev = Evaluator(model, ScanParams(**{**params.__dict__, "metrics_only": True}), tensors)
     try:
         for layer in layers:
             out = {}
