@@ -15,8 +15,17 @@
 // involved, nothing depends on workgroup placement or dispatch order, and the 4096 polling lanes
 // touch 4096 different addresses (a single shared flag word measured 3 us slower: every poll of the
 // launch lands on one line). The epoch is a host counter bumped per launch, so granules of earlier
-// launches are never accepted (which is also why this path is not used under stream capture: a
-// replayed launch would replay its epoch).
+// launches are never accepted.
+//
+// Stream capture: a launch recorded into a HIP graph would replay its epoch, so a captured launch
+// carries the reserved tag CAPTURE_TAG instead (never a host epoch) and sets `reset`: every residual
+// workgroup stores 0 over the granules its lanes have read, once they have all finished polling
+// (reset_granules). Each granule has exactly one reader, so when the kernel ends its granules are all
+// cleared and the next replay (or any other captured launch of the same
+// weight, which the stream or the graph's edges order after it) starts from tags that cannot match.
+// The residency census needs a host round trip, so it cannot run during capture: a kernel/grid that
+// has not been checked by an earlier eager launch declines, and the caller records the two-kernel
+// path (warm up once before capturing, as callers of graphs do anyway).
 //
 // Safety: the consumers spin, so every workgroup of the grid must be resident together. The host
 // only takes this path when grid <= occupancy x CUs, and verifies that once per kernel with a
@@ -42,6 +51,7 @@ constexpr unsigned long long SPIN_TICKS = 50000;      // 100 MHz ticks = 500 us
 struct FusedArgs {
     unsigned long long * vg;      // [B][L] granules {value, epoch}
     unsigned   epoch;
+    int        reset;             // 1: consumers clear the granules they read (captured launches, see header)
     int        resid_delay;       // residual workgroups start after this many s_sleep(8) (512 clocks each)
     int        ncu;               // CUs of the device (round-robin period of the dispatcher); 0: no shadow workgroups
     int        linger;            // how long a shadow workgroup stays, in 100 MHz ticks
@@ -63,6 +73,8 @@ __device__ __forceinline__ unsigned long long granule_load(const unsigned long l
 // Wait for the nbase <= N base granules of output o. One poll = all N loads issued back to back,
 // then the tags. The loads are branch-free (slots past nbase re-read block 0): with a branch around
 // each load hipcc waits for every load in turn, one memory-side round trip per base block.
+constexpr unsigned CAPTURE_TAG = 0xFFFFFFFFu;        // tag of launches recorded into a graph; never a host epoch
+
 template <int N>
 __device__ __forceinline__ bool poll_granules(const FusedArgs & fa, int o, int L, int nbase, float (&vals)[8]) {
     bool ok = false;
@@ -84,6 +96,27 @@ __device__ __forceinline__ bool poll_granules(const FusedArgs & fa, int o, int L
         __builtin_amdgcn_s_sleep(SDH_POLL_SLEEP);
     } while (__builtin_amdgcn_s_memrealtime() - t0 < SPIN_TICKS);
     return ok;
+}
+
+// Captured launches (reset): the granules a residual workgroup has read are cleared by the LAST of its
+// waves to finish polling, counted in LDS. Clearing from each lane right after its own poll measured
+// +3.3 us on cfg3: those stores land on lines that the neighbouring lanes are still polling (a
+// workgroup's rows are consecutive, so its granules of one base block are one contiguous run and, from
+// 16 rows per workgroup up, whole lines that only this workgroup reads).
+__device__ __forceinline__ void reset_begin(int * done) {
+    if (threadIdx.x == 0) *done = 0;
+    __syncthreads();
+}
+__device__ __forceinline__ bool reset_last_wave(int * done, int lane, int waves) {
+    int prev = 0;
+    if (lane == 0) prev = atomicAdd(done, 1);
+    return __builtin_amdgcn_readfirstlane(prev) == waves - 1;
+}
+__device__ __forceinline__ void reset_granules(unsigned long long * vg, int row0, int nrows, int nbase, int L, int lane) {
+    for (int i = lane; i < nrows * nbase; i += 64) {
+        const int b = i / nrows, r = i - b * nrows;
+        __hip_atomic_store(at32(vg, b * L + row0 + r), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // LOG_T: log2 of the workgroup size. The base role's chain (2 FWHTs + gathers) is the critical path of
@@ -161,6 +194,8 @@ void decode_fused_kernel(const DeltaParams p, const BasePackDesc pd, const Fused
     // long before the base) and takes cfg3 from 9.9 to 8.9 us.
     const int ridx = residual_index((int) blockIdx.x, p.B, fa.ncu);
     if (ridx < 0) { shadow_linger(fa.linger); return; }
+    int * const done = reinterpret_cast<int *>(lds);
+    if (fa.reset) reset_begin(done);
     for (int i = 0; i < fa.resid_delay; ++i) __builtin_amdgcn_s_sleep(8);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -199,6 +234,10 @@ void decode_fused_kernel(const DeltaParams p, const BasePackDesc pd, const Fused
         if (!ok) y = __uint_as_float(0x7FC00000u);       // base never arrived: surface it as a NaN
         store_output(p, o, 0, y, scale);
     }
+    if (fa.reset && reset_last_wave(done, lane, WAVES)) {
+        const int rows = WAVES * (64 / G), row0 = ridx * rows;
+        reset_granules(fa.vg, row0, min(rows, p.n_out - row0), p.tall ? 1 : p.B, L, lane);
+    }
 }
 
 // ---- gate | up in one launch (gated FFN block, T = 1) ----------------------------------------------
@@ -211,6 +250,7 @@ struct PairArgs {
     BasePackDesc pd[2];
     unsigned long long * vg[2];
     unsigned     epoch[2];
+    int          reset;
     int          act;
     const uint16_t * gelu_tab;
     float *      h;
@@ -264,6 +304,8 @@ void decode_pair_kernel(const PairArgs a) {
 
     const int ridx = residual_index((int) blockIdx.x, 2 * B, a.ncu);
     if (ridx < 0) { shadow_linger(a.linger); return; }
+    int * const done = reinterpret_cast<int *>(lds);
+    if (a.reset) reset_begin(done);
     for (int i = 0; i < a.resid_delay; ++i) __builtin_amdgcn_s_sleep(8);     // head start for the base role (see decode_fused_kernel)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -301,6 +343,11 @@ void decode_pair_kernel(const PairArgs a) {
         yg = finish_output(a.p[0], yg, sg);
         yu = finish_output(a.p[1], yu, su);
         a.h[o] = glu_value(a.act, yg, yu, a.gelu_tab);
+    }
+    if (a.reset && reset_last_wave(done, lane, WAVES)) {  // tall: the granules of rows row0.. are vg[t][row0..]
+        const int rows = WAVES * (64 / G), row0 = ridx * rows, n = min(rows, a.p[0].n_out - row0);
+        reset_granules(a.vg[0], row0, n, 1, L, lane);
+        reset_granules(a.vg[1], row0, n, 1, L, lane);
     }
 }
 
@@ -350,6 +397,13 @@ static int resid_delay_units() {
     return v < 0 ? 0 : (v > 64 ? 64 : v);
 }
 
+// host epochs run 1 .. 0xFFFFFFFE: 0 is "cleared", CAPTURE_TAG belongs to captured launches
+static unsigned next_epoch(unsigned & e) {
+    ++e;
+    if (e == 0 || e == CAPTURE_TAG) e = 1;
+    return e;
+}
+
 struct FusedKernelInfo {
     int occ = -1;                 // resident workgroups per CU (occupancy API)
     unsigned census_ok_grid = 0;  // largest grid the census has confirmed
@@ -374,6 +428,10 @@ static int launch_inst(const DeltaParams & p, const BasePackDesc & pd, FusedArgs
     static const bool dbg = getenv("SDH_DEBUG") != nullptr;
     if (ki.census_failed || (long long) grid > (long long) ki.occ * ls.num_cu) {   // not all resident: caller falls back
         if (dbg) fprintf(stderr, "[sdh] fused decode declined: grid=%u occ=%d cus=%d census_failed=%d\n", grid, ki.occ, ls.num_cu, (int) ki.census_failed);
+        return 1;
+    }
+    if (grid > ki.census_ok_grid && fa.epoch == CAPTURE_TAG) {   // capturing: the census cannot run now
+        if (dbg) fprintf(stderr, "[sdh] fused decode declined: capture before the first eager launch (grid=%u)\n", grid);
         return 1;
     }
     if (grid > ki.census_ok_grid) {
@@ -425,7 +483,8 @@ int launch_decode_fused(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s) 
     if (!(w.L == 1024 || w.L == 2048 || w.L == 4096)) SDH_DECLINE("L not in {1024,2048,4096}");
     if (!w.tall && w.B > 8) SDH_DECLINE("more than 8 base blocks per output");
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) SDH_DECLINE("stream is capturing");
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess) SDH_DECLINE("capture status unknown");
+    const bool capturing = (cs != hipStreamCaptureStatusNone);
 
     DeltaParams p = make_delta_params(w, a);
     int G = 1, steps = 0;
@@ -437,10 +496,11 @@ int launch_decode_fused(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s) 
     const int ncu = shadow_ncu();
     const unsigned grid = shadow_grid((int) w.B, (p.n_out + rows_per_block - 1) / rows_per_block, ncu);
 
-    if (++w.epoch == 0) w.epoch = 1;
     FusedArgs fa{};
     fa.vg = reinterpret_cast<unsigned long long *>(w.handoff);
-    fa.epoch = w.epoch;
+    fa.epoch = capturing ? CAPTURE_TAG : next_epoch(w.epoch);
+    static const bool force_reset = getenv("SDH_DECODE_FORCE_RESET") != nullptr;     // A/B: cost of the clearing stores
+    fa.reset = (capturing || force_reset) ? 1 : 0;
     fa.resid_delay = resid_delay_units();
     fa.ncu = ncu;
     fa.linger = shadow_linger_ticks();
@@ -467,6 +527,10 @@ static int launch_pair_inst(PairArgs & a, unsigned grid, hipStream_t s) {
     static const bool dbg = getenv("SDH_DEBUG") != nullptr;
     if (ki.census_failed || (long long) grid > (long long) ki.occ * ls.num_cu) {
         if (dbg) fprintf(stderr, "[sdh] gate|up launch declined: grid=%u occ=%d cus=%d census_failed=%d\n", grid, ki.occ, ls.num_cu, (int) ki.census_failed);
+        return 1;
+    }
+    if (grid > ki.census_ok_grid && a.epoch[0] == CAPTURE_TAG) {  // capturing: the census cannot run now
+        if (dbg) fprintf(stderr, "[sdh] gate|up launch declined: capture before the first eager launch (grid=%u)\n", grid);
         return 1;
     }
     if (grid > ki.census_ok_grid) {
@@ -505,13 +569,15 @@ int launch_decode_pair(DeviceWeight & g, DeviceWeight & u, int act, const uint16
     static const bool dbg = getenv("SDH_DEBUG") != nullptr;
 #define SDH_DECLINE(why) do { if (dbg) fprintf(stderr, "[sdh] gate|up launch declined: %s\n", why); return 1; } while (0)
     if (g.kind != u.kind || (g.kind != SDH_OP_BASE_BLOCK && g.kind != SDH_OP_BASE_COO)) SDH_DECLINE("not two base payloads of one kind");
+    if (&g == &u) SDH_DECLINE("gate and up are one handle (they would share hand-off granules)");
     if (!g.tall || !u.tall) SDH_DECLINE("not tall");
     if (g.n_in != u.n_in || g.n_out != u.n_out || g.L != u.L || g.B != u.B) SDH_DECLINE("shapes differ");
     if (g.idx_type != SDH_TYPE_I16 || g.val_type != SDH_TYPE_F16 || u.idx_type != SDH_TYPE_I16 || u.val_type != SDH_TYPE_F16) SDH_DECLINE("payload is not I16/F16");
     if (g.pack.wide32 || u.pack.wide32 || !g.handoff || !u.handoff) SDH_DECLINE("base parameters are 32-bit");
     if (!(g.L == 1024 || g.L == 2048 || g.L == 4096)) SDH_DECLINE("L not in {1024,2048,4096}");
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) SDH_DECLINE("stream is capturing");
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess) SDH_DECLINE("capture status unknown");
+    const bool capturing = (cs != hipStreamCaptureStatusNone);
 
     const bool is_block = (g.kind == SDH_OP_BASE_BLOCK);
     DeltaLaunch dl{};
@@ -529,11 +595,12 @@ int launch_decode_pair(DeviceWeight & g, DeviceWeight & u, int act, const uint16
     const int rows_per_block = ((1 << decode_log_t((int) g.L)) / 64) * (64 / G0);
     const int ncu = shadow_ncu();
     const unsigned grid = shadow_grid(2 * (int) g.B, (a.p[0].n_out + rows_per_block - 1) / rows_per_block, ncu);
-    if (++g.epoch == 0) g.epoch = 1;
-    if (++u.epoch == 0) u.epoch = 1;
     a.vg[0] = reinterpret_cast<unsigned long long *>(g.handoff);
     a.vg[1] = reinterpret_cast<unsigned long long *>(u.handoff);
-    a.epoch[0] = g.epoch; a.epoch[1] = u.epoch;
+    a.epoch[0] = capturing ? CAPTURE_TAG : next_epoch(g.epoch);
+    a.epoch[1] = capturing ? CAPTURE_TAG : next_epoch(u.epoch);
+    static const bool force_reset = getenv("SDH_DECODE_FORCE_RESET") != nullptr;
+    a.reset = (capturing || force_reset) ? 1 : 0;
     a.act = act; a.gelu_tab = gelu_tab; a.h = h;
     a.resid_delay = resid_delay_units();
     a.ncu = ncu;

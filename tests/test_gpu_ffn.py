@@ -164,6 +164,43 @@ def test_ffn_device_io_and_strides(hip):
     assert np.array_equal(bits(y[:, :n_embd]), bits(y_host))
 
 
+@pytest.mark.parametrize("act", [O.ACT_SILU, O.ACT_GELU])
+def test_ffn_block_under_graph_capture(hip, act):
+    """One decode FFN block (gate|up launch + fused down launch) recorded into a HIP graph and replayed
+    with changing inputs; eager blocks on the same handles run in between. Captured launches use the
+    reserved hand-off tag (sdh_decode.hip), so every replay must equal the eager block bit for bit."""
+    kw = dict(scheme="block", K=64, block=16, base=True, d13_random=True)
+    gate, up = make_payload(2048, 5632, seed=41, **kw), make_payload(2048, 5632, seed=42, **kw)
+    down = make_payload(5632, 2048, seed=43, **kw)
+    wg, wu, wd = hip.SeedDeltaWeight(gate), hip.SeedDeltaWeight(up), hip.SeedDeltaWeight(down)
+    xs = make_x(2048, 4, seed=12)
+    want = [hip.ffn_forward_host(wg, wu, wd, xs[i:i + 1], act) for i in range(4)]
+    assert hip.ffn_last_fused()
+    xd = torch.zeros((1, 2048), dtype=torch.float32, device="cuda")
+    yd = torch.zeros((1, 2048), dtype=torch.float32, device="cuda")
+    ye = torch.zeros((1, 2048), dtype=torch.float32, device="cuda")
+    xe = torch.from_numpy(xs[3:4]).cuda()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        hip.ffn_forward_device(wg, wu, wd, act, xd.data_ptr(), 2048, 1, yd.data_ptr(), 2048, 0, side.cuda_stream)
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            hip.ffn_forward_device(wg, wu, wd, act, xd.data_ptr(), 2048, 1, yd.data_ptr(), 2048, 0,
+                                   torch.cuda.current_stream().cuda_stream)
+            assert hip.ffn_last_fused()                  # the recorded block is the two-launch one
+        for i in range(3):
+            xd.copy_(torch.from_numpy(xs[i:i + 1]))
+            g.replay()
+            g.replay()
+            if i == 1:
+                hip.ffn_forward_device(wg, wu, wd, act, xe.data_ptr(), 2048, 1, ye.data_ptr(), 2048, 0, side.cuda_stream)
+            side.synchronize()
+            assert np.array_equal(bits(yd.cpu().numpy()), bits(want[i])), f"replay {i}"
+        assert np.array_equal(bits(ye.cpu().numpy()), bits(want[3]))
+    assert wg.nonfinite_count() == 0 and wu.nonfinite_count() == 0 and wd.nonfinite_count() == 0
+
+
 def test_glu_kernel_vs_oracle(hip):
     rng = np.random.default_rng(8)
     n = 100003

@@ -258,6 +258,45 @@ def test_fused_decode_matches_two_launch_path(hip, cfg):
         assert np.array_equal(bits(y_all[i:i + 1]), bits(w.forward_host(xs[i:i + 1], hip.FWD_NO_FUSE)))
 
 
+@pytest.mark.parametrize("cfg", ["cfg3_mistral_down_block32_k1536", "cfg2_gemma4b_gate_coo_k128",
+                                 "cfg1_gemma1b_gate_block16_k64"])
+def test_fused_decode_under_graph_capture(hip, cfg):
+    """The fused launch recorded into a HIP graph: a replay repeats its arguments, so captured launches
+    use the reserved hand-off tag and their consumers clear the granules they read. Replays with
+    changing inputs, replays back to back without synchronisation, and eager launches of the same
+    weight in between must all be bit-identical to the two-launch path."""
+    torch = pytest.importorskip("torch")
+    p = config_payload(cfg)
+    w = hip.SeedDeltaWeight(p)
+    xs = make_x(p.n_in, 5, seed=33)
+    want = [w.forward_host(xs[i:i + 1], hip.FWD_NO_FUSE) for i in range(5)]
+    xd = torch.zeros((1, p.n_in), dtype=torch.float32, device="cuda")
+    yd = torch.zeros((1, p.n_out), dtype=torch.float32, device="cuda")
+    xe = torch.from_numpy(xs[4:5]).cuda()
+    ye = torch.zeros((1, p.n_out), dtype=torch.float32, device="cuda")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        w.forward_device(xd.data_ptr(), p.n_in, 1, yd.data_ptr(), p.n_out, stream=side.cuda_stream)   # census, eager
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            w.forward_device(xd.data_ptr(), p.n_in, 1, yd.data_ptr(), p.n_out,
+                             stream=torch.cuda.current_stream().cuda_stream)
+        for i in range(4):
+            xd.copy_(torch.from_numpy(xs[i:i + 1]), non_blocking=False)
+            g.replay()
+            if i == 2:                       # an eager launch of the same weight between two replays
+                w.forward_device(xe.data_ptr(), p.n_in, 1, ye.data_ptr(), p.n_out, stream=side.cuda_stream)
+            side.synchronize()
+            assert np.array_equal(bits(yd.cpu().numpy()), bits(want[i])), f"{cfg} replay {i}"
+        assert np.array_equal(bits(ye.cpu().numpy()), bits(want[4]))
+        for _ in range(200):                 # back to back, no host synchronisation in between
+            g.replay()
+        side.synchronize()
+        assert np.array_equal(bits(yd.cpu().numpy()), bits(want[3]))
+    assert w.nonfinite_count() == 0
+
+
 def test_device_io_path_matches_host_io(hip):
     torch = pytest.importorskip("torch")
     p = make_payload(1024, 512, scheme="block", K=64, block=32, base=True, seed=8)
