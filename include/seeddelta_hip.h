@@ -136,7 +136,13 @@ int64_t sdh_weight_payload_bytes(const sdh_weight * w);
  * column stride ldy. `stream` is a hipStream_t (NULL = the library's own stream).
  * Semantics follow src/llama-seeddelta.cpp: invalid indices skipped (:693, :929-936),
  * out-of-range perm entries read element 0 (:524-527), scale applied only if != 1 (:645),
- * tall/wide base split on n_out >= n_in (:1073). */
+ * tall/wide base split on n_out >= n_in (:1073).
+ * HIP graphs: with device pointers the call may be made on a capturing stream. Call it once
+ * eagerly first (workspaces and the fused decode launch's one-time residency check need the
+ * host); a decode launch captured before that records the two-kernel path instead. Captured
+ * and eager calls on one handle may be mixed freely on one stream; calls on one handle from
+ * different streams or graph branches must be ordered by the caller (they share the handle's
+ * hand-off buffer). The same holds for sdh_ffn_forward / sdh_ffn_gate_up. */
 int sdh_forward(sdh_weight * w,
                 const float * x, int64_t ldx, int64_t n_tokens,
                 float * y, int64_t ldy,
