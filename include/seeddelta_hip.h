@@ -286,10 +286,12 @@ int  sdh_scan_create(uint32_t seed, sdh_scan ** out);
 void sdh_scan_destroy(sdh_scan * s);
 /* Start a new builder run on the same handle: re-seed the RNG, keep the device buffers and the last fit. */
 int  sdh_scan_reseed(sdh_scan * s, uint32_t seed);
-/* Forget the memoised Gaussian draws. The library keeps the eval_x * n_in normals of a metric pass keyed
- * on the full generator state, because across a sweep the same (state, count) recurs for every layer and
- * every K. No counterpart in the reference; bench.py calls it before the timed sweep so
- * that the sweep pays for every distinct draw itself. */
+/* Forget the memoised draws. The library keeps the results of the host routines that consume the
+ * generator stream — the eval_x * n_in normals of a metric pass (with one device copy shared by all
+ * handles), the shuffled row samples and the fit's row / permutation plan — keyed on the full generator
+ * state and their arguments, because across a sweep the same (state, arguments) recurs for every layer
+ * and every K. No counterpart in the reference; bench.py calls it before the timed sweep
+ * so that the sweep pays for every distinct draw itself. */
 void sdh_scan_memo_clear(void);
 /* Evaluate one candidate on W. Wg/Wu/Wd (the layer's three dense weights) are only read by the FFN
  * proxy and may be NULL. Draws from the scan's RNG exactly as the builder does (base fit, then the

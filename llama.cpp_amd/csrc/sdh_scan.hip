@@ -20,6 +20,10 @@
 // Host side: libstdc++'s std::mt19937 / std::shuffle / std::normal_distribution<float> — the same
 // library routines the reference calls, consumed in the same order.
 #include "sdh_internal.h"
+#include <atomic>
+#include <array>
+#include <chrono>
+#include <memory>
 
 #include <algorithm>
 #include <cmath>
@@ -51,6 +55,8 @@ struct DeviceDense {
     DenseView v{};
     void * alloc0 = nullptr, * alloc1 = nullptr;
     int64_t stored_bytes = 0;
+    uint64_t serial = next_serial();    // identity for caches (an address can be reused by a later tensor)
+    static uint64_t next_serial() { static std::atomic<uint64_t> n{0}; return ++n; }
 };
 
 // The stored type is a template parameter of every kernel that reads the weight: with a run-time
@@ -224,11 +230,15 @@ void scan_fit_kernel(DenseView W, int L, int tall, const FitJob * __restrict__ j
 // Same arithmetic and the same per-bin sample order as scan_fit_kernel, but instead of one random
 // one-byte gather per (bin, sample) — 64 cache lines per wave instruction, ~134 M L2 requests per fit at
 // Mistral dims — a workgroup copies the sampled row's block [in0, in0+L) into LDS with 16-byte loads
-// (4 rows per stage, double-buffered) and its 256 threads pick their elements there. The 16 workgroups
-// of a job re-read the same 4 KB row from L2, which is an eighth of the requests and coalesced.
+// (8 rows per stage, register-prefetched) and its threads pick their elements there. The workgroups
+// of a job re-read the same 4 KB row from L2, coalesced.
 constexpr int FIT_ROWS_PER_STAGE = 8;
 
-__global__ __launch_bounds__(256)
+// FT threads per workgroup, one bin each: the staging of a row is shared by FT bins, so FT = 1024 reads
+// each sampled row from L2 L/1024 times instead of L/256 times and keeps 16 waves per CU behind the
+// LDS round trips of a stage.
+template <int FT>
+__global__ __launch_bounds__(FT)
 void scan_fit_lds_q8_kernel(DenseView W, int L, int tall, const FitJob * __restrict__ jobs, const int * __restrict__ rows,
                             const int * __restrict__ perms, const float * __restrict__ ws, double * __restrict__ out /* [n_jobs][3][L] */) {
     extern __shared__ __align__(16) unsigned char fit_smem[];
@@ -245,26 +255,26 @@ void scan_fit_lds_q8_kernel(DenseView W, int L, int tall, const FitJob * __restr
     const int64_t in0 = tall ? 0 : (int64_t) job.b * L;
     const int64_t in1 = tall ? W.n_in : min((int64_t) W.n_in, in0 + L);
     const int span = (int) (in1 - in0);                                // valid elements of the block, a multiple of 32
-    for (int i = tid; i < L; i += 256) {
+    for (int i = tid; i < L; i += FT) {
         perm_s[i] = perms[job.perm_off + i];
         if (ws) wss[i] = i < span ? ws[in0 + i] : 0.0f;
     }
-    for (int i = tid; i < job.n_rows; i += 256) rows_s[i] = rows[job.rows_off + i];
+    for (int i = tid; i < job.n_rows; i += FT) rows_s[i] = rows[job.rows_off + i];
     __syncthreads();
-    const int u = blockIdx.x * 256 + tid;
+    const int u = blockIdx.x * FT + tid;
     const int nd = L >> 5;
 
     // a stage = R rows of the job: R*L/16 16-byte pieces and R*L/32 scales, fetched into registers
     // (fetch), consumed from LDS one stage later (commit): the fetch of stage k+1 is in flight while
-    // stage k is being accumulated. L <= 4096 (host check): at most 8 pieces and 4 scales per thread.
-    constexpr int MAXP = 8, MAXD = 4;
+    // stage k is being accumulated. L <= 4096 (host check): at most R*256/FT pieces and R*128/FT scales per thread.
+    constexpr int MAXP = R * 256 / FT, MAXD = (R * 128 + FT - 1) / FT;
     const int n_piece = R * (L >> 4), n_scale = R * nd;
     uint4 pq[MAXP];
     __half pd[MAXD];
     auto fetch = [&](int s0) {
 #pragma unroll
         for (int i = 0; i < MAXP; ++i) {
-            const int e = tid + 256 * i;
+            const int e = tid + FT * i;
             pq[i] = make_uint4(0, 0, 0, 0);
             if (e < n_piece) {
                 const int k = e >> (lg - 4), c = e & ((L >> 4) - 1);
@@ -276,7 +286,7 @@ void scan_fit_lds_q8_kernel(DenseView W, int L, int tall, const FitJob * __restr
         }
 #pragma unroll
         for (int i = 0; i < MAXD; ++i) {
-            const int e = tid + 256 * i;
+            const int e = tid + FT * i;
             pd[i] = __float2half(0.0f);
             if (e < n_scale) {
                 const int k = e >> (lg - 5), c = e & (nd - 1);
@@ -290,12 +300,12 @@ void scan_fit_lds_q8_kernel(DenseView W, int L, int tall, const FitJob * __restr
     auto commit = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < MAXP; ++i) {
-            const int e = tid + 256 * i;
+            const int e = tid + FT * i;
             if (e < n_piece) *reinterpret_cast<uint4 *>(qs + (size_t) buf * R * L + (size_t) e * 16) = pq[i];
         }
 #pragma unroll
         for (int i = 0; i < MAXD; ++i) {
-            const int e = tid + 256 * i;
+            const int e = tid + FT * i;
             if (e < n_scale) ds[(size_t) buf * R * nd + e] = pd[i];
         }
     };
@@ -786,7 +796,22 @@ struct Scan {
     std::vector<float> h_ws;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t stream = nullptr;       // one stream per handle: candidates prepared by different host threads overlap on the GPU
+    // proxy: the true gate/up dots and the W_down samples depend on the three dense tensors and the proxy
+    // seed only, not on the candidate: kept for the next K of the same tensor
+    struct ProxyTruth {
+        uint64_t g = 0, u = 0, d = 0; int64_t seed = -1, cap = -1; int nx = 0;
+        std::vector<double> gu; std::vector<float> wd;
+    } proxy_truth;
+    // dev: host wall time per phase of sdh_scan_tensor, printed at destroy when SDH_SCAN_TIMING is set
+    double t_phase[6] = {0, 0, 0, 0, 0, 0};   // fit, select-all + clamp, eval_w, eval_x, proxy, tail
+    long   n_cand = 0;
     explicit Scan(uint32_t seed) : rng(seed) {}
+};
+static bool scan_timing() { static const bool v = getenv("SDH_SCAN_TIMING") != nullptr; return v; }
+struct PhaseTimer {
+    double & acc; std::chrono::steady_clock::time_point t0;
+    explicit PhaseTimer(double & a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+    ~PhaseTimer() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
 };
 
 static void fit_dims(int64_t n_in, int64_t n_out, int64_t * L, int64_t * B) {
@@ -832,59 +857,110 @@ static void summarise(const std::vector<double> & rel, const std::vector<double>
     o[4] = nr.empty() ? 0.0 : c / n;
 }
 
+// ---- host routines that consume the mt19937 stream, memoised on the generator state ------------------
+// The evaluators draw eval_x * n_in Gaussians per pass (sd_eval.cpp:1084-1087, sd_ffn_proxy.cpp:77-80) at
+// ~26 ns each, shuffle iota(n_out) for every row sample (~80 us at n_out = 14336) and the fit shuffles
+// its rows and permutations — and the stream position each of them starts from depends only on the seed
+// and the tensor shapes: not on the layer, not on K. Across a sweep the same (state, arguments) recurs
+// for every layer and every K of a tensor kind, so a result — identical by construction — is computed
+// once and the generator is moved to the state it would have reached. Lookups compare the full mt19937
+// state (operator==) and the arguments.
+using MemoKey = std::array<int64_t, 8>;
+template <class V>
+class RngMemo {
+    struct Entry {
+        std::mt19937 before, after;
+        MemoKey key{};
+        bool ready = false;                 // false while the first caller is still computing
+        std::shared_ptr<const V> val;
+    };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::shared_ptr<Entry>> q;
+    const size_t cap;
+public:
+    explicit RngMemo(size_t cap_) : cap(cap_) {}
+    // make(rng) computes the value and advances rng
+    template <class F>
+    std::shared_ptr<const V> get(std::mt19937 & rng, const MemoKey & key, F && make) {
+        std::shared_ptr<Entry> mine;
+        {
+            std::unique_lock<std::mutex> lock(mu);
+            for (size_t i = 0; i < q.size(); ++i) {
+                if (q[i]->key == key && q[i]->before == rng) {
+                    const std::shared_ptr<Entry> hit = q[i];            // the deque may change while we wait
+                    cv.wait(lock, [&] { return hit->ready; });          // someone is computing exactly this
+                    rng = hit->after;
+                    return hit->val;
+                }
+            }
+            mine = std::make_shared<Entry>();
+            mine->before = rng;
+            mine->key = key;
+            q.push_back(mine);
+            while (q.size() > cap) q.pop_front();                       // holders keep evicted values alive
+        }
+        std::shared_ptr<const V> v = make(rng);
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            mine->after = rng;
+            mine->val = v;
+            mine->ready = true;
+        }
+        cv.notify_all();
+        return v;
+    }
+    void clear() {
+        std::lock_guard<std::mutex> lock(mu);
+        q.clear();
+    }
+};
+
 // the row sample every eval draws: iota, shuffle, truncate (sd_eval.cpp:138-141 and siblings)
-static std::vector<int> draw_rows(std::mt19937 & rng, int64_t n_out, int64_t want) {
-    std::vector<int64_t> all((size_t) n_out);
-    std::iota(all.begin(), all.end(), 0);
-    std::shuffle(all.begin(), all.end(), rng);
-    all.resize((size_t) std::min(want, n_out));
-    return std::vector<int>(all.begin(), all.end());
+static RngMemo<std::vector<int>> & rows_memo() {
+    static RngMemo<std::vector<int>> & memo = *new RngMemo<std::vector<int>>(256);      // never destroyed (no exit-time teardown)
+    return memo;
+}
+static std::shared_ptr<const std::vector<int>> draw_rows(std::mt19937 & rng, int64_t n_out, int64_t want) {
+    return rows_memo().get(rng, MemoKey{1, n_out, want}, [&](std::mt19937 & g) {
+        std::vector<int64_t> all((size_t) n_out);
+        std::iota(all.begin(), all.end(), 0);
+        std::shuffle(all.begin(), all.end(), g);
+        all.resize((size_t) std::min(want, n_out));
+        return std::make_shared<const std::vector<int>>(all.begin(), all.end());
+    });
 }
 
-// n draws of std::normal_distribution<float>(0,1) from rng, memoised on the generator state. The
-// evaluators draw eval_x * n_in Gaussians per pass (sd_eval.cpp:1084-1087, sd_ffn_proxy.cpp:77-80) at
-// ~26 ns each, and the stream position they start from depends only on the seed and the tensor shapes:
-// not on the layer, not on K. Across a sweep the same (state, n) recurs for every layer and every K of
-// a tensor kind, so the draws — identical by construction — are made once and the generator is moved
-// to the state it would have reached. Lookups compare the full mt19937 state (operator==).
-struct NormalMemo {
-    std::mt19937 before, after;
-    int64_t n = 0;
-    bool ready = false;                 // false while the first caller is still drawing
-    std::shared_ptr<const std::vector<float>> vals;
-};
-static std::mutex g_memo_mu;
-static std::condition_variable g_memo_cv;
-static std::deque<std::shared_ptr<NormalMemo>> g_memo;
-
-static std::shared_ptr<const std::vector<float>> draw_normals(std::mt19937 & rng, int64_t n) {
-    std::shared_ptr<NormalMemo> mine;
-    {
-        std::unique_lock<std::mutex> lock(g_memo_mu);
-        for (const auto & m : g_memo) {
-            if (m->n == n && m->before == rng) {
-                g_memo_cv.wait(lock, [&] { return m->ready; });      // someone is drawing exactly this: wait for it
-                rng = m->after;
-                return m->vals;
-            }
+// n draws of std::normal_distribution<float>(0,1), with a device copy made on first use and shared by
+// every handle (the x matrices of eval_x and of the proxy are 0.5-1.8 MB per pass at Mistral dims)
+struct Normals {
+    std::vector<float> v;
+    mutable std::mutex mu;
+    mutable float * dev = nullptr;
+    const float * device() const {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!dev && !v.empty()) {
+            float * p = nullptr;
+            if (hipMalloc((void **) &p, v.size() * sizeof(float)) != hipSuccess) return nullptr;
+            if (hipMemcpy(p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { (void) hipFree(p); return nullptr; }
+            dev = p;
         }
-        mine = std::make_shared<NormalMemo>();
-        mine->before = rng;
-        mine->n = n;
-        g_memo.push_back(mine);
-        while (g_memo.size() > 96) g_memo.pop_front();               // holders keep evicted entries alive
+        return dev;
     }
-    auto v = std::make_shared<std::vector<float>>((size_t) n);
-    std::normal_distribution<float> nd(0.0f, 1.0f);
-    for (int64_t i = 0; i < n; ++i) (*v)[(size_t) i] = nd(rng);
-    {
-        std::lock_guard<std::mutex> lock(g_memo_mu);
-        mine->after = rng;
-        mine->vals = v;
-        mine->ready = true;
-    }
-    g_memo_cv.notify_all();
-    return v;
+    ~Normals() { if (dev) (void) hipFree(dev); }
+};
+static RngMemo<Normals> & normals_memo() {
+    static RngMemo<Normals> & memo = *new RngMemo<Normals>(96);
+    return memo;
+}
+static std::shared_ptr<const Normals> draw_normals(std::mt19937 & rng, int64_t n) {
+    return normals_memo().get(rng, MemoKey{2, n}, [&](std::mt19937 & g) {
+        auto out = std::make_shared<Normals>();
+        out->v.resize((size_t) n);
+        std::normal_distribution<float> nd(0.0f, 1.0f);
+        for (int64_t i = 0; i < n; ++i) out->v[(size_t) i] = nd(g);
+        return std::shared_ptr<const Normals>(out);
+    });
 }
 
 // RNG consumption of the base fit (sd_eval.cpp:557-651), with or without the work
@@ -892,7 +968,7 @@ struct FitPlan {
     std::vector<FitJob> jobs; std::vector<int> rows; std::vector<int> perms;
 };
 
-static FitPlan plan_fit(std::mt19937 & rng, int64_t n_in, int64_t n_out, int64_t L, int64_t B, int64_t max_samples, int trials) {
+static FitPlan plan_fit_draw(std::mt19937 & rng, int64_t n_in, int64_t n_out, int64_t L, int64_t B, int64_t max_samples, int trials) {
     FitPlan pl;
     const bool tall = n_out >= n_in;
     trials = std::max(1, trials);
@@ -930,6 +1006,15 @@ static FitPlan plan_fit(std::mt19937 & rng, int64_t n_in, int64_t n_out, int64_t
         }
     }
     return pl;
+}
+static RngMemo<FitPlan> & fit_memo() {
+    static RngMemo<FitPlan> & memo = *new RngMemo<FitPlan>(32);
+    return memo;
+}
+static std::shared_ptr<const FitPlan> plan_fit(std::mt19937 & rng, int64_t n_in, int64_t n_out, int64_t L, int64_t B, int64_t max_samples, int trials) {
+    return fit_memo().get(rng, MemoKey{3, n_in, n_out, L, B, max_samples, trials}, [&](std::mt19937 & g) {
+        return std::make_shared<const FitPlan>(plan_fit_draw(g, n_in, n_out, L, B, max_samples, trials));
+    });
 }
 
 static DenseView view_or_null(const sdh_dense * d) {
@@ -1040,8 +1125,9 @@ int sdh_scan_create(uint32_t seed, sdh_scan ** out) {
 }
 
 void sdh_scan_memo_clear(void) {
-    std::lock_guard<std::mutex> lock(g_memo_mu);
-    g_memo.clear();
+    normals_memo().clear();
+    rows_memo().clear();
+    fit_memo().clear();
 }
 
 int sdh_scan_reseed(sdh_scan * h, uint32_t seed) {
@@ -1053,6 +1139,10 @@ int sdh_scan_reseed(sdh_scan * h, uint32_t seed) {
 void sdh_scan_destroy(sdh_scan * h) {
     if (!h) return;
     Scan * s = (Scan *) h;
+    if (scan_timing() && s->n_cand)
+        fprintf(stderr, "[sdh] scan handle %p: %ld candidates; ms per candidate: fit %.3f select-all %.3f eval_w %.3f eval_x %.3f proxy %.3f tail %.3f\n",
+                (void *) s, s->n_cand, 1e3 * s->t_phase[0] / s->n_cand, 1e3 * s->t_phase[1] / s->n_cand, 1e3 * s->t_phase[2] / s->n_cand,
+                1e3 * s->t_phase[3] / s->n_cand, 1e3 * s->t_phase[4] / s->n_cand, 1e3 * s->t_phase[5] / s->n_cand);
     if (s->ev0) (void) hipEventDestroy(s->ev0);
     if (s->ev1) (void) hipEventDestroy(s->ev1);
     if (s->stream) { (void) hipStreamSynchronize(s->stream); (void) hipStreamDestroy(s->stream); }
@@ -1105,6 +1195,8 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
     // ---- base fit -------------------------------------------------------------------------------------
     int64_t L = 0, B = 0;
     BaseView bv{};
+    ++s.n_cand;
+    std::unique_ptr<PhaseTimer> ph(new PhaseTimer(s.t_phase[0]));
     if (p.write_base && p.base_mode != 0) {
         fit_dims(n_in, n_out, &L, &B);
         if (!s.has_base || s.fit_of != (const void *) Wh || s.L != L || s.B != B) {
@@ -1116,7 +1208,8 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
     } else if (p.write_base) {
         fit_dims(n_in, n_out, &L, &B);
         if (L > 16384) { set_error("scan: base block length %lld too large", (long long) L); return SDH_ERR_UNSUPPORTED; }
-        FitPlan pl = plan_fit(s.rng, n_in, n_out, L, B, p.base_max_samples, p.base_perm_trials);
+        const std::shared_ptr<const FitPlan> plp = plan_fit(s.rng, n_in, n_out, L, B, p.base_max_samples, p.base_perm_trials);
+        const FitPlan & pl = *plp;
         const int n_jobs = (int) pl.jobs.size();
         if ((rc = s.jobs.put(pl.jobs, st)) || (rc = s.rows.put(pl.rows, st)) || (rc = s.perms.put(pl.perms, st))) return rc;
         if ((rc = s.dbl.ensure((size_t) n_jobs * 3 * L))) return rc;
@@ -1129,10 +1222,17 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
                                2 * FIT_ROWS_PER_STAGE * ((size_t) L + (size_t) (L >> 5) * 2) + (ws_dev ? (size_t) L * 4 : 0);
         static const bool fit_gather_only = getenv("SDH_SCAN_FIT_GATHER") != nullptr;      // A/B runs
         if (W.type == SDH_TYPE_Q8_0 && L >= 1024 && L <= 4096 && fit_lds <= 160 * 1024 && !fit_gather_only) {
-            static const bool attr_ok = hipFuncSetAttribute((const void *) scan_fit_lds_q8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+            static const bool fit_256 = getenv("SDH_SCAN_FIT_T256") != nullptr;               // A/B: the first shape
+            static const bool attr_ok =
+                hipFuncSetAttribute((const void *) scan_fit_lds_q8_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                hipFuncSetAttribute((const void *) scan_fit_lds_q8_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
             if (!attr_ok) { set_error("scan: raising the dynamic LDS limit failed"); return SDH_ERR_HIP; }
-            hipLaunchKernelGGL(scan_fit_lds_q8_kernel, dim3((unsigned) (L / threads), (unsigned) n_jobs), dim3(threads), fit_lds, st,
-                               W, (int) L, tall ? 1 : 0, s.jobs.p, s.rows.p, s.perms.p, ws_dev, s.dbl.p);
+            if (fit_256)
+                hipLaunchKernelGGL(scan_fit_lds_q8_kernel<256>, dim3((unsigned) (L / 256), (unsigned) n_jobs), dim3(256), fit_lds, st,
+                                   W, (int) L, tall ? 1 : 0, s.jobs.p, s.rows.p, s.perms.p, ws_dev, s.dbl.p);
+            else
+                hipLaunchKernelGGL(scan_fit_lds_q8_kernel<1024>, dim3((unsigned) (L / 1024), (unsigned) n_jobs), dim3(1024), fit_lds, st,
+                                   W, (int) L, tall ? 1 : 0, s.jobs.p, s.rows.p, s.perms.p, ws_dev, s.dbl.p);
         } else {
             SDH_LAUNCH_DT(W, scan_fit_kernel, dim3((unsigned) (L / threads), (unsigned) n_jobs), dim3(threads),
                           (size_t) L * sizeof(int), st, W, (int) L, tall ? 1 : 0, s.jobs.p, s.rows.p, s.perms.p, ws_dev, s.dbl.p);
@@ -1235,6 +1335,7 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
         return SDH_OK;
     };
     s.emitted = !metrics_only;
+    ph.reset(); ph.reset(new PhaseTimer(s.t_phase[1]));
     if (!metrics_only && (rc = select(nullptr, n_out))) return rc;
     out->delta_clamp_scale = 1.0;
     if (clamp_applies && K_eff > 0) {
@@ -1276,7 +1377,8 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
 
     // ---- metrics: em, [em_w], em_x, [em_x_w] — the order run_trial draws their samples in (:735-795) ----
     auto eval_w = [&](const float * ws, double * o5) -> int {
-        std::vector<int> rows = draw_rows(s.rng, n_out, p.eval_cols);
+        const std::shared_ptr<const std::vector<int>> rowsp = draw_rows(s.rng, n_out, p.eval_cols);
+        const std::vector<int> & rows = *rowsp;
         const int nr = (int) rows.size();
         int rc2;
         if ((rc2 = s.rows.put(rows, st)) || (rc2 = s.dbl.ensure((size_t) nr * 3))) return rc2;
@@ -1294,10 +1396,12 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
         return SDH_OK;
     };
     auto eval_x = [&](const float * x_scale_host, double * o5) -> int {
-        std::vector<int> rows = draw_rows(s.rng, n_out, p.eval_cols);
+        const std::shared_ptr<const std::vector<int>> rowsp = draw_rows(s.rng, n_out, p.eval_cols);
+        const std::vector<int> & rows = *rowsp;
         const int nr = (int) rows.size();
         const int nx = (int) p.eval_x;
-        const std::shared_ptr<const std::vector<float>> gauss = draw_normals(s.rng, (int64_t) nx * n_in);
+        const std::shared_ptr<const Normals> gaussp = draw_normals(s.rng, (int64_t) nx * n_in);
+        const std::vector<float> * gauss = &gaussp->v;
         std::vector<float> scaled;
         if (x_scale_host) {
             scaled.resize(gauss->size());
@@ -1305,23 +1409,29 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
                 for (int64_t i = 0; i < n_in; ++i)
                     scaled[(size_t) xi * (size_t) n_in + (size_t) i] = (*gauss)[(size_t) xi * (size_t) n_in + (size_t) i] * x_scale_host[i];   // sd_eval.cpp:1084-1087
         }
-        const std::vector<float> & xs = x_scale_host ? scaled : *gauss;
         int rc2;
-        if ((rc2 = s.rows.put(rows, st)) || (rc2 = s.xs.put(xs, st)) || (rc2 = s.dbl.ensure((size_t) nr * nx)) ||
+        const float * xs_dev = nullptr;         // unscaled draws: the copy shared by all handles
+        if (x_scale_host) {
+            if ((rc2 = s.xs.put(scaled, st))) return rc2;
+            xs_dev = s.xs.p;
+        } else if (!(xs_dev = gaussp->device())) {
+            set_error("scan: upload of the eval_x inputs failed"); return SDH_ERR_HIP;
+        }
+        if ((rc2 = s.rows.put(rows, st)) || (rc2 = s.dbl.ensure((size_t) nr * nx)) ||
             (rc2 = s.dbl2.ensure((size_t) nr * nx))) return rc2;
         const float * vdev = nullptr;
         if (p.write_base) {
             if ((rc2 = s.v.ensure((size_t) nx * (size_t) B * (size_t) L))) return rc2;
-            if ((rc2 = launch_base_apply_generic(s.xs.p, n_in, (int) n_in, (int) L, (int) B, tall, s.d1.p, s.d2.p, nullptr,
+            if ((rc2 = launch_base_apply_generic(xs_dev, n_in, (int) n_in, (int) L, (int) B, tall, s.d1.p, s.d2.p, nullptr,
                                                  s.perm1.p, nullptr, nx, s.v.p, st))) return rc2;
             vdev = s.v.p;
         }
         if (metrics_only && (rc2 = select(s.rows.p, nr))) return rc2;
         rs_dev = p.write_row_scale ? s.rs.p : nullptr;
-        SDH_LAUNCH_DT(W, scan_dense_dot_kernel, dim3((unsigned) nr, (unsigned) nx), dim3(256), 0, st, W, s.rows.p, nr, s.xs.p, s.dbl.p);
+        SDH_LAUNCH_DT(W, scan_dense_dot_kernel, dim3((unsigned) nr, (unsigned) nx), dim3(256), 0, st, W, s.rows.p, nr, xs_dev, s.dbl.p);
         hipLaunchKernelGGL(scan_delta_dot_kernel, dim3((unsigned) nr, (unsigned) nx), dim3(256), 0, st, (int) n_in, p.scheme,
                            (int) Ksel, (int) s.block, s.idx.p, s.val.p, rs_dev, vdev, (int) L, (int) B, tall ? 1 : 0,
-                           s.rows.p, nr, compact, s.xs.p, s.dbl2.p);
+                           s.rows.p, nr, compact, xs_dev, s.dbl2.p);
         SDH_HIP_CHECK(hipGetLastError());
         std::vector<double> yt((size_t) nr * nx), yh((size_t) nr * nx);
         SDH_HIP_CHECK(hipMemcpyAsync(yt.data(), s.dbl.p, yt.size() * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1340,10 +1450,12 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
         return SDH_OK;
     };
     out->has_w = ws_dev ? 1 : 0;
+    ph.reset(); ph.reset(new PhaseTimer(s.t_phase[2]));
     if (p.eval_cols > 0) {
         if ((rc = eval_w(nullptr, out->em))) return rc;
         if (ws_dev && (rc = eval_w(ws_dev, out->em_w))) return rc;
     }
+    ph.reset(); ph.reset(new PhaseTimer(s.t_phase[3]));
     if (p.eval_cols > 0 && p.eval_x > 0) {
         if ((rc = eval_x(nullptr, out->em_x))) return rc;
         out->has_x = 1;
@@ -1351,35 +1463,50 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
     }
 
     // ---- FFN proxy (sd_ffn_proxy.cpp:20-247): COO, no base, gate/up only ------------------------------
+    ph.reset(); ph.reset(new PhaseTimer(s.t_phase[4]));
     if (p.want_proxy && p.scheme == 0 && !p.write_base && p.eval_x > 0 && p.kind != 2 && Wg && Wu && Wd) {
         const DenseView G = view_or_null(Wg), U = view_or_null(Wu), D = view_or_null(Wd);
         const int64_t n_hidden = G.n_out, n_o = D.n_out;
         const int nx = (int) std::min<int64_t>(p.eval_x, 128);
         const int64_t cap = p.eval_cols > 0 ? p.eval_cols : 128;
         std::mt19937 prng((uint32_t) p.proxy_seed);
-        std::vector<int> hid = draw_rows(prng, n_hidden, std::min(n_hidden, cap));
-        std::vector<int> outs = draw_rows(prng, n_o, std::min(n_o, cap));
+        const std::shared_ptr<const std::vector<int>> hidp = draw_rows(prng, n_hidden, std::min(n_hidden, cap));
+        const std::shared_ptr<const std::vector<int>> outsp = draw_rows(prng, n_o, std::min(n_o, cap));
+        const std::vector<int> & hid = *hidp, & outs = *outsp;
         const int nh = (int) hid.size(), no = (int) outs.size();
-        const std::shared_ptr<const std::vector<float>> pxs = draw_normals(prng, (int64_t) nx * G.n_in);
-        const std::vector<float> & xs = *pxs;
-        if ((rc = s.rows.put(hid, st)) || (rc = s.cols.put(outs, st)) || (rc = s.xs.put(xs, st)) ||
+        const std::shared_ptr<const Normals> pxs = draw_normals(prng, (int64_t) nx * G.n_in);
+        const float * xs_dev = pxs->device();
+        if (!xs_dev) { set_error("scan: upload of the proxy inputs failed"); return SDH_ERR_HIP; }
+        Scan::ProxyTruth & pt = s.proxy_truth;
+        const uint64_t id_g = ((const DeviceDense *) Wg)->serial, id_u = ((const DeviceDense *) Wu)->serial, id_d = ((const DeviceDense *) Wd)->serial;
+        const bool have_truth = pt.g == id_g && pt.u == id_u && pt.d == id_d && pt.seed == (int64_t) p.proxy_seed && pt.cap == cap &&
+                                pt.nx == nx && pt.gu.size() == (size_t) nh * nx * 2 && pt.wd.size() == (size_t) no * nh;
+        if ((rc = s.rows.put(hid, st)) || (rc = s.cols.put(outs, st)) ||
             (rc = s.dbl.ensure((size_t) nh * nx * 2)) || (rc = s.dbl2.ensure((size_t) nh * nx)) ||
             (rc = s.gat.ensure((size_t) no * nh))) return rc;
         if (metrics_only && (rc = select(s.rows.p, nh))) return rc;     // the replaced tensor's sampled hidden rows
-        SDH_LAUNCH_DT(G, scan_dense_dot_kernel, dim3((unsigned) nh, (unsigned) nx), dim3(256), 0, st, G, s.rows.p, nh, s.xs.p, s.dbl.p);
-        SDH_LAUNCH_DT(U, scan_dense_dot_kernel, dim3((unsigned) nh, (unsigned) nx), dim3(256), 0, st, U, s.rows.p, nh, s.xs.p,
-                           s.dbl.p + (size_t) nh * nx);
+        if (!have_truth) {
+            SDH_LAUNCH_DT(G, scan_dense_dot_kernel, dim3((unsigned) nh, (unsigned) nx), dim3(256), 0, st, G, s.rows.p, nh, xs_dev, s.dbl.p);
+            SDH_LAUNCH_DT(U, scan_dense_dot_kernel, dim3((unsigned) nh, (unsigned) nx), dim3(256), 0, st, U, s.rows.p, nh, xs_dev,
+                               s.dbl.p + (size_t) nh * nx);
+            // W_down[out rows][hidden cols]
+            SDH_LAUNCH_DT(D, scan_gather_kernel, dim3((unsigned) ((no * nh + 255) / 256)), dim3(256), 0, st, D, s.cols.p, no, s.rows.p, nh, s.gat.p);
+        }
         hipLaunchKernelGGL(scan_delta_dot_kernel, dim3((unsigned) nh, (unsigned) nx), dim3(256), 0, st, (int) n_in, 0, (int) Ksel, 1,
-                           s.idx.p, s.val.p, (const float *) nullptr, (const float *) nullptr, 0, 0, 1, s.rows.p, nh, compact, s.xs.p, s.dbl2.p);
-        // W_down[out rows][hidden cols]
-        SDH_LAUNCH_DT(D, scan_gather_kernel, dim3((unsigned) ((no * nh + 255) / 256)), dim3(256), 0, st, D, s.cols.p, no, s.rows.p, nh, s.gat.p);
+                           s.idx.p, s.val.p, (const float *) nullptr, (const float *) nullptr, 0, 0, 1, s.rows.p, nh, compact, xs_dev, s.dbl2.p);
         SDH_HIP_CHECK(hipGetLastError());
-        std::vector<double> gu((size_t) nh * nx * 2), hat((size_t) nh * nx);
-        std::vector<float> wd((size_t) no * nh);
-        SDH_HIP_CHECK(hipMemcpyAsync(gu.data(), s.dbl.p, gu.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        std::vector<double> hat((size_t) nh * nx);
+        if (!have_truth) {
+            pt.seed = -1;                                  // invalid until the copies below have landed
+            pt.gu.resize((size_t) nh * nx * 2); pt.wd.resize((size_t) no * nh);
+            SDH_HIP_CHECK(hipMemcpyAsync(pt.gu.data(), s.dbl.p, pt.gu.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+            SDH_HIP_CHECK(hipMemcpyAsync(pt.wd.data(), s.gat.p, pt.wd.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+        }
         SDH_HIP_CHECK(hipMemcpyAsync(hat.data(), s.dbl2.p, hat.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-        SDH_HIP_CHECK(hipMemcpyAsync(wd.data(), s.gat.p, wd.size() * sizeof(float), hipMemcpyDeviceToHost, st));
         SDH_HIP_CHECK(hipStreamSynchronize(st));
+        if (!have_truth) { pt.g = id_g; pt.u = id_u; pt.d = id_d; pt.seed = (int64_t) p.proxy_seed; pt.cap = cap; pt.nx = nx; }
+        const std::vector<double> & gu = pt.gu;
+        const std::vector<float> & wd = pt.wd;
         std::vector<double> cs_all, l2_all, lnr_all;
         auto silu = [](double v) { return v / (1.0 + std::exp(-v)); };
         std::vector<double> at((size_t) nh), ah((size_t) nh);
@@ -1419,6 +1546,7 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
         out->proxy_available = 1;
     }
 
+    ph.reset(); ph.reset(new PhaseTimer(s.t_phase[5]));
     SDH_HIP_CHECK(hipEventRecord(s.ev1, st));
     SDH_HIP_CHECK(hipEventSynchronize(s.ev1));
     float ms = 0.0f;
