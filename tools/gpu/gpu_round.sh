@@ -1,6 +1,6 @@
 #!/bin/bash
 # one GPU-box session: parity tests, smoke, bench (fused eager / two-launch / graph), rocprof kernel
-# trace + HBM traffic counters. Usage: ./gpu_round.sh <tag>   (outputs under gpurun_out/)
+# trace + HBM traffic counters. Usage: ./tools/gpu/gpu_round.sh <tag>   (outputs under gpurun_out/)
 set -o pipefail
 TAG=${1:-r01}
 mkdir -p gpurun_out

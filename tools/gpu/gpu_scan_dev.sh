@@ -4,4 +4,4 @@ set -o pipefail
 mkdir -p gpurun_out
 timeout -k 10 600 python -u -m pytest tests/test_gpu_scan.py -m gpu -x -q --timeout 120 --timeout-method thread > gpurun_out/pytest_scan.log 2>&1
 rc=$?; tail -3 gpurun_out/pytest_scan.log; [ $rc -ne 0 ] && exit $rc
-./gpu_scan_time.sh
+./tools/gpu/gpu_scan_time.sh
