@@ -307,6 +307,17 @@ int  sdh_scan_skip(sdh_scan * s, int64_t n_in, int64_t n_out, const sdh_scan_par
  * GGUF (sd_build.cpp:1104-1236). */
 int  sdh_scan_fetch(sdh_scan * s, int32_t * idx, float * val, float * row_scale,
                     float * d2, float * h2, int32_t * perm1, int32_t * perm1_inv);
+/* The same outputs as the GGUF stores them: the builder's packing step (sd_build.cpp:1104-1236) run on
+ * the device before the copy, so half the bytes cross PCIe and no host pass is needed. idx_type
+ * SDH_TYPE_I16: int32 -> int16 with anything outside [-32768, 32767] -> -1 (:1132, :1162), SDH_TYPE_I32:
+ * as is; val_type SDH_TYPE_F16: ggml_fp32_to_fp16_row (ggml/src/ggml.c:457-462; round to nearest even,
+ * NaN -> sign | 0x7E00), SDH_TYPE_F32: as is; row_scale always F16 (:1188-1191); d2 F16 [B][L];
+ * perm1 int16 with out-of-range entries -> 0 when L <= 32768 (:1111, :1228), int32 otherwise
+ * (*perm1_type reports which; the caller's buffer must hold B*L int32 in the worst case).
+ * base_d1 / base_d3 are all ones in the builder's output (sd_eval.cpp:450-452) and are not returned.
+ * Any pointer may be NULL. */
+int  sdh_scan_fetch_packed(sdh_scan * s, int idx_type, void * idx, int val_type, void * val,
+                           uint16_t * row_scale_f16, uint16_t * d2_f16, void * perm1, int * perm1_type);
 
 /* ---- measurement hooks (no counterpart in the reference; used by bench.py) -------------------
  * sdh_profile_enable(1): from now on every sdh_forward brackets its dominant kernel (the

@@ -50,31 +50,6 @@ static float half_to_float(uint16_t h) {
     return f;
 }
 
-// f32 -> f16 bits, round to nearest even, NaN -> 0x7E00 (the result of ggml's GGML_FP32_TO_FP16)
-static uint16_t float_to_half(float fl) {
-    uint32_t f;
-    memcpy(&f, &fl, 4);
-    const uint32_t f32infty = 255u << 23, f16max = (127u + 16u) << 23, denorm_magic_u = ((127u - 15u) + (23u - 10u) + 1u) << 23;
-    const uint32_t sign = f & 0x80000000u;
-    uint16_t o;
-    f ^= sign;
-    if (f >= f16max) o = (f > f32infty) ? 0x7E00 : 0x7C00;
-    else if (f < (113u << 23)) {                       // f16 subnormal: let the float adder do the rounding
-        float t, dm;
-        memcpy(&t, &f, 4); memcpy(&dm, &denorm_magic_u, 4);
-        t += dm;
-        uint32_t tb;
-        memcpy(&tb, &t, 4);
-        o = (uint16_t) (tb - denorm_magic_u);
-    } else {
-        const uint32_t mant_odd = (f >> 13) & 1u;
-        f += ((uint32_t) (15 - 127) << 23) + 0xFFFu;
-        f += mant_odd;
-        o = (uint16_t) (f >> 13);
-    }
-    return (uint16_t) (o | (sign >> 16));
-}
-
 static inline size_t type_size(int type) {
     switch (type) {
         case SDH_TYPE_F32: case SDH_TYPE_I32: return 4;

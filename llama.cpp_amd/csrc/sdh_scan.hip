@@ -761,6 +761,25 @@ __global__ void scan_gather_kernel(DenseView W, const int * __restrict__ rows, i
     out[e] = c < W.n_in ? dense_at<DT>(W, rows[e / n_cols], c) : 0.0f;
 }
 
+// ---- kernels: the builder's packing step (tools/seeddelta-build/sd_build.cpp:1104-1236) -----------------
+// indices: int32 staging -> I16, anything outside [-32768, 32767] becomes -1 (:1132, :1162)
+__global__ __launch_bounds__(256)
+void scan_pack_i16_kernel(const int * __restrict__ in, int16_t * __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { const int v = in[i]; out[i] = (v < -32768 || v > 32767) ? (int16_t) -1 : (int16_t) v; }
+}
+// values: fp32 -> F16 as ggml_fp32_to_fp16_row does it (ggml/src/ggml.c:457-462): round to nearest even,
+// overflow to infinity, subnormals kept, every NaN -> sign | 0x7E00
+__global__ __launch_bounds__(256)
+void scan_pack_f16_kernel(const float * __restrict__ in, uint16_t * __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float f = in[i];
+    const uint32_t w = __float_as_uint(f);
+    const uint16_t h = __half_as_ushort(__float2half_rn(f));
+    out[i] = ((w & 0x7FFFFFFFu) > 0x7F800000u) ? (uint16_t) (((w >> 16) & 0x8000u) | 0x7E00u) : h;
+}
+
 // ---- host: scan state --------------------------------------------------------------------------------
 // Device scratch of a scan handle. Capacities grow geometrically and never shrink: hipFree synchronises the
 // whole device, and with 16 handles working through a K grid exact-size buffers were reallocated on
@@ -803,6 +822,7 @@ struct Scan {
     DevBuf<float> h2, d2, d1; DevBuf<int> inv, perm1;
     std::vector<float> h_h2, h_d2, h_ones; std::vector<int> h_perm1, h_inv;
     // scratch
+    DevBuf<uint16_t> packed;            // sdh_scan_fetch_packed: converted idx / val / row_scale
     DevBuf<int> rows, perms, cols; DevBuf<FitJob> jobs; DevBuf<double> dbl, dbl2; DevBuf<float> xs, v, gat, wsd;
     std::vector<float> h_ws;
     // host side of the result copies. Pageable on purpose: with pinned buffers the (then truly asynchronous)
@@ -1687,6 +1707,61 @@ int sdh_scan_fetch(sdh_scan * h, int32_t * idx, float * val, float * row_scale,
         if (h2) std::memcpy(h2, s.h_h2.data(), n * sizeof(float));
         if (perm1) std::memcpy(perm1, s.h_perm1.data(), n * sizeof(int32_t));
         if (perm1_inv) std::memcpy(perm1_inv, s.h_inv.data(), n * sizeof(int32_t));
+    }
+    return SDH_OK;
+}
+
+int sdh_scan_fetch_packed(sdh_scan * h, int idx_type, void * idx, int val_type, void * val, uint16_t * row_scale_f16,
+                          uint16_t * d2_f16, void * perm1, int * perm1_type) {
+    if (!h) { set_error("sdh_scan_fetch_packed: null handle"); return SDH_ERR_INVALID; }
+    Scan & s = *(Scan *) h;
+    if (s.n_out <= 0) { set_error("sdh_scan_fetch_packed: no candidate evaluated yet"); return SDH_ERR_INVALID; }
+    if ((idx || val || row_scale_f16) && !s.emitted) {
+        set_error("sdh_scan_fetch_packed: the candidate was evaluated with metrics_only, no payload was kept");
+        return SDH_ERR_INVALID;
+    }
+    if (idx && idx_type != SDH_TYPE_I16 && idx_type != SDH_TYPE_I32) { set_error("sdh_scan_fetch_packed: idx type must be I16 or I32"); return SDH_ERR_INVALID; }
+    if (val && val_type != SDH_TYPE_F16 && val_type != SDH_TYPE_F32) { set_error("sdh_scan_fetch_packed: val type must be F16 or F32"); return SDH_ERR_INVALID; }
+    if (row_scale_f16 && !s.has_rs) { set_error("sdh_scan_fetch_packed: candidate had no row scale"); return SDH_ERR_INVALID; }
+    hipStream_t st = s.stream;
+    const size_t n_idx = (size_t) s.n_out * (size_t) s.K, n_val = n_idx * (size_t) s.block, n_rs = (size_t) s.n_out;
+    // one scratch buffer of 16-bit words: [idx | val | row_scale] as far as they are converted
+    const size_t o_idx = 0, o_val = o_idx + (idx && idx_type == SDH_TYPE_I16 ? n_idx : 0),
+                 o_rs = o_val + (val && val_type == SDH_TYPE_F16 ? n_val : 0), total = o_rs + (row_scale_f16 ? n_rs : 0);
+    int rc;
+    if ((rc = s.packed.ensure(total ? total : 1))) return rc;
+    auto grid = [](size_t n) { return dim3((unsigned) ((n + 255) / 256)); };
+    if (idx && idx_type == SDH_TYPE_I16 && n_idx)
+        hipLaunchKernelGGL(scan_pack_i16_kernel, grid(n_idx), dim3(256), 0, st, s.idx.p, (int16_t *) (s.packed.p + o_idx), (int64_t) n_idx);
+    if (val && val_type == SDH_TYPE_F16 && n_val)
+        hipLaunchKernelGGL(scan_pack_f16_kernel, grid(n_val), dim3(256), 0, st, s.val.p, s.packed.p + o_val, (int64_t) n_val);
+    if (row_scale_f16)                                                   // row_scale is always F16 (:1188-1191)
+        hipLaunchKernelGGL(scan_pack_f16_kernel, grid(n_rs), dim3(256), 0, st, s.rs.p, s.packed.p + o_rs, (int64_t) n_rs);
+    SDH_HIP_CHECK(hipGetLastError());
+    if (idx) {
+        if (idx_type == SDH_TYPE_I16) SDH_HIP_CHECK(hipMemcpyAsync(idx, s.packed.p + o_idx, n_idx * 2, hipMemcpyDeviceToHost, st));
+        else                          SDH_HIP_CHECK(hipMemcpyAsync(idx, s.idx.p, n_idx * 4, hipMemcpyDeviceToHost, st));
+    }
+    if (val) {
+        if (val_type == SDH_TYPE_F16) SDH_HIP_CHECK(hipMemcpyAsync(val, s.packed.p + o_val, n_val * 2, hipMemcpyDeviceToHost, st));
+        else                          SDH_HIP_CHECK(hipMemcpyAsync(val, s.val.p, n_val * 4, hipMemcpyDeviceToHost, st));
+    }
+    if (row_scale_f16) SDH_HIP_CHECK(hipMemcpyAsync(row_scale_f16, s.packed.p + o_rs, n_rs * 2, hipMemcpyDeviceToHost, st));
+    SDH_HIP_CHECK(hipStreamSynchronize(st));
+    if (d2_f16 || perm1) {
+        if (!s.has_base) { set_error("sdh_scan_fetch_packed: candidate had no base"); return SDH_ERR_INVALID; }
+        const size_t n = (size_t) (s.L * s.B);
+        if (d2_f16) for (size_t i = 0; i < n; ++i) d2_f16[i] = float_to_half(s.h_d2[i]);
+        if (perm1) {
+            const bool small = s.L <= 32768;                             // perm type rule of :1111
+            if (perm1_type) *perm1_type = small ? SDH_TYPE_I16 : SDH_TYPE_I32;
+            if (small) {
+                int16_t * o = (int16_t *) perm1;
+                for (size_t i = 0; i < n; ++i) { const int v = s.h_perm1[i]; o[i] = (v < 0 || v > 32767) ? (int16_t) 0 : (int16_t) v; }   // :1228
+            } else {
+                std::memcpy(perm1, s.h_perm1.data(), n * sizeof(int32_t));
+            }
+        }
     }
     return SDH_OK;
 }

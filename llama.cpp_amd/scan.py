@@ -173,6 +173,30 @@ class ScanSession:
         return out
 
 
+    def fetch_packed(self, idx_dtype=np.int16, val_dtype=np.float16) -> dict:
+        """The last candidate's outputs as the GGUF stores them: the builder's packing step
+        (sd_build.cpp:1104-1236) runs on the device before the copy. Same keys as fetch() minus h2 /
+        perm1_inv; pack.pack_candidate accepts the result unchanged (its conversions are idempotent)."""
+        n_in, n_out, params, K_eff, n_blocks, L, B = self._last
+        block = params.scheme == "block"
+        idx = np.empty((n_out, n_blocks if block else K_eff), dtype=idx_dtype)
+        val = np.empty((n_out, n_blocks, params.block) if block else (n_out, K_eff), dtype=val_dtype)
+        rs = np.empty(n_out, dtype=np.float16) if params.row_scale else None
+        tcode = sd.SDH_TYPE
+        out = {"idx": idx, "val": val, "row_scale": rs}
+        ptr = lambda a: None if a is None else C.c_void_p(a.ctypes.data)   # noqa: E731
+        d2 = perm = None
+        ptype = C.c_int(0)
+        if params.base:
+            d2, perm = np.empty((B, L), np.float16), np.empty((B, L), np.int32)
+        sd._check(sd.load_library().sdh_scan_fetch_packed(self._h, tcode[np.dtype(idx_dtype)], ptr(idx), tcode[np.dtype(val_dtype)],
+                                                          ptr(val), ptr(rs), ptr(d2), ptr(perm), C.byref(ptype)), "sdh_scan_fetch_packed")
+        if params.base:
+            out["d2"] = d2
+            out["perm1"] = perm if ptype.value == tcode[np.dtype(np.int32)] else perm.view(np.int16).reshape(-1)[:B * L].reshape(B, L).copy()
+        return out
+
+
 # ---- report entry (sd_report.cpp:163-281; gating of sd_build.cpp:810-913 for a one-K schedule) -----------
 def ffn_score(entry: dict) -> float:
     """sd_report.cpp:72-88: min(cos_mean, cos_p05) of the first available of x_w, x, w, plain."""
@@ -795,7 +819,7 @@ def build_run(model: ModelFn, layers: Sequence[int], params: ScanParams, policy=
                     else:
                         guard.record_pass(kind)
                         if keep_staging:
-                            emitted[(layer, kind)] = (p, e["K"], session.fetch())
+                            emitted[(layer, kind)] = (p, e["K"], session.fetch_packed())       # packed on the device
                 entries.append(e)
     finally:
         session.close()

@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "sdh_forward", "sdh_nonfinite_count", "sdh_w0_tile", "sdh_ffn_forward", "sdh_ffn_gate_up", "sdh_ffn_last_fused", "sdh_glu",
     "sdh_profile_enable", "sdh_profile_read", "sdh_profile_span_begin", "sdh_profile_span_end",
     "sdh_dense_create", "sdh_dense_destroy", "sdh_dense_bytes",
-    "sdh_scan_create", "sdh_scan_destroy", "sdh_scan_reseed", "sdh_scan_tensor", "sdh_scan_skip", "sdh_scan_fetch", "sdh_scan_memo_clear", "sdh_imatrix_scale",
+    "sdh_scan_create", "sdh_scan_destroy", "sdh_scan_reseed", "sdh_scan_tensor", "sdh_scan_skip", "sdh_scan_fetch", "sdh_scan_fetch_packed", "sdh_scan_memo_clear", "sdh_imatrix_scale",
 ]
 
 
@@ -145,6 +145,8 @@ def load_library(path: str = LIB_PATH):
                                     C.POINTER(SdhScanParams), C.POINTER(SdhScanResult)]
     lib.sdh_scan_skip.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(SdhScanParams)]
     lib.sdh_scan_fetch.argtypes = [C.c_void_p] + [C.c_void_p] * 7
+    lib.sdh_scan_fetch_packed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.POINTER(C.c_int)]
     lib.sdh_scan_memo_clear.restype = None
     lib.sdh_imatrix_scale.argtypes = [C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p]
     _lib = lib

@@ -315,6 +315,61 @@ def test_k_grid_reuses_the_fit_and_autotune_schedule(hip):
     ev.close()
 
 
+@pytest.mark.parametrize("scheme,K,block,base", [("coo", 40, 32, True), ("block", 64, 16, True), ("coo", 24, 32, False)])
+def test_fetch_packed_equals_the_builders_packing_step(hip, scheme, K, block, base):
+    """sdh_scan_fetch_packed converts on the device; the bytes must equal the host packing of the
+    fp32 / int32 staging (pack.py restates sd_build.cpp:1104-1236) and the reference's own
+    ggml_fp32_to_fp16_row applied to the staging values, including overflow, subnormal and NaN inputs."""
+    import ctypes as C
+    import oracle_py as O
+    from llama_cpp_amd import pack as P
+    n_in, n_out = 640, 352
+    W = make_dense(n_in, n_out, "f32", seed=5, structure=0.3).copy()
+    W[3, :8] = [1e6, -1e6, 7e4, 65520.0, 3e-6, -2e-7, 6e-8, 1e-9]         # overflow, halfway to inf, f16 subnormals, underflow
+    W[5, 0] = np.nan
+    p = SC.ScanParams(scheme=scheme, K=K, block=block, base=base, row_scale=True, base_max_samples=128, base_perm_trials=2,
+                      eval_cols=0, eval_x=0)
+    s = SC.ScanSession(p.seed)
+    s.tensor(SC.DenseWeight(W), p, "ffn_gate", 0)
+    raw, packed = s.fetch(), s.fetch_packed()
+    want = P.pack_candidate(raw, n_in, n_out, scheme)
+    got = P.pack_candidate(packed, n_in, n_out, scheme)
+    for name in ("d_idx", "d_val", "b_idx", "b_val", "row_scale", "base_d2", "base_perm1"):
+        a, b = getattr(want, name), getattr(got, name)
+        assert (a is None) == (b is None), name
+        if a is not None:
+            assert a.dtype == b.dtype and a.shape == b.shape, name
+            assert np.array_equal(a.view(np.uint16) if a.dtype == np.float16 else a,
+                                  b.view(np.uint16) if b.dtype == np.float16 else b), name
+    assert packed["idx"].dtype == np.int16 and packed["val"].dtype == np.float16 and packed["row_scale"].dtype == np.float16
+    # the reference's converter on the same staging values
+    if not O.ref_available():
+        pytest.skip("oracle/_ref/libsdref.so not built")
+    lib = O.ref_lib()
+    lib.ggml_fp32_to_fp16_row.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    v32 = np.ascontiguousarray(raw["val"], dtype=np.float32).reshape(-1)
+    ref16 = np.empty(v32.size, dtype=np.uint16)
+    lib.ggml_fp32_to_fp16_row(v32.ctypes.data, ref16.ctypes.data, v32.size)
+    assert np.array_equal(ref16, packed["val"].view(np.uint16).reshape(-1))
+    # types kept as they are on request
+    wide = s.fetch_packed(np.int32, np.float32)
+    assert np.array_equal(wide["idx"], raw["idx"]) and np.array_equal(wide["val"].view(np.uint32), raw["val"].view(np.uint32))
+
+
+def test_fetch_packed_index_range_rule(hip):
+    """n_in > 32768: indices that do not fit int16 become -1 (sd_build.cpp:1132, :1162)."""
+    n_in, n_out = 40000, 24
+    rng = np.random.default_rng(2)
+    W = (0.01 * rng.standard_normal((n_out, n_in))).astype(np.float32)
+    W[:, 39000:39010] = 5.0                                              # winners beyond the int16 range
+    p = SC.ScanParams(scheme="coo", K=16, base=False, row_scale=False, eval_cols=0, eval_x=0)
+    s = SC.ScanSession(p.seed)
+    s.tensor(SC.DenseWeight(W), p, "ffn_down", 0)
+    raw, packed = s.fetch(), s.fetch_packed()
+    assert (raw["idx"] > 32767).sum() >= 10 * n_out
+    assert np.array_equal(packed["idx"], np.where(raw["idx"] > 32767, -1, raw["idx"]).astype(np.int16))
+
+
 def test_build_run_follows_the_builder_control_flow(hip):
     """One builder process over several layers on one RNG stream (sd_build.cpp:296-1102): policy
     resolution, disabled tensors, per-kind K, autotune, stack guard bookkeeping — and the metrics of
