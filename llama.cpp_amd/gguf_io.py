@@ -46,10 +46,13 @@ class GGUFReader:
             raise ValueError(f"{path}: GGUF version {self.version} not supported")
         n_tensors, n_kv = self._unpack("<QQ")
         self.kv: Dict[str, object] = {}
+        self.kv_spans: Dict[str, Tuple[int, int]] = {}                   # key -> byte range of the encoded pair
         for _ in range(n_kv):
+            start = self._pos
             key = self._string()
             (vt,) = self._unpack("<I")
             self.kv[key] = self._value(vt)
+            self.kv_spans[key] = (start, self._pos)
         self.alignment = int(self.kv.get("general.alignment", DEFAULT_ALIGNMENT))
         self.infos: Dict[str, Tuple[Tuple[int, ...], int, int]] = {}     # name -> (ne, ggml type, offset)
         for _ in range(n_tensors):
@@ -110,6 +113,17 @@ class GGUFReader:
             n *= v
         return n // per * size
 
+    def kv_raw(self, key: str) -> bytes:
+        """The key/value pair exactly as the file encodes it (copied through by the builder's writer)."""
+        a, b = self.kv_spans[key]
+        return bytes(self._mm[a:b])
+
+    def raw(self, name: str) -> Tuple[int, Tuple[int, ...], memoryview]:
+        """(ggml type, ne, bytes) of a tensor of any type, for copying it into another GGUF unchanged."""
+        ne, gtype, off = self.infos[name]
+        start = self.data_start + off
+        return gtype, ne, memoryview(self._mm)[start:start + self.nbytes(name)]
+
     def tensor(self, name: str) -> np.ndarray:
         """Zero-copy view of a tensor (numpy shape = reversed ne)."""
         ne, gtype, off = self.infos[name]
@@ -151,32 +165,39 @@ def _kv_bytes(key: str, value) -> bytes:
     raise TypeError(f"unsupported metadata value for {key}: {type(value)}")
 
 
-def write_gguf(path: str, kv: Dict[str, object], tensors: Dict[str, np.ndarray], q8_0: Tuple[str, ...] = (),
-               alignment: int = DEFAULT_ALIGNMENT) -> None:
-    """Write a GGUF v3 file. uint8 arrays named in `q8_0` are raw Q8_0 rows (n_rows, n_in//32*34)."""
+def write_gguf(path: str, kv: Dict[str, object], tensors: Dict[str, object], q8_0: Tuple[str, ...] = (),
+               alignment: int = DEFAULT_ALIGNMENT, kv_raw: Tuple[bytes, ...] = ()) -> None:
+    """Write a GGUF v3 file. A tensor is a numpy array (uint8 arrays named in `q8_0` are raw Q8_0 rows
+    (n_rows, n_in//32*34)) or a (ggml type, ne, bytes) triple from GGUFReader.raw, written unchanged.
+    `kv_raw` are already encoded key/value pairs (GGUFReader.kv_raw), written before `kv`."""
     infos, blobs, off = [], [], 0
     for name, a in tensors.items():
-        a = np.ascontiguousarray(a)
-        if name in q8_0:
-            gtype, ne = 8, (a.shape[1] // 34 * 32, a.shape[0])
+        if isinstance(a, tuple):
+            gtype, ne, raw = a
         else:
-            gtype, ne = GGML_OF_DTYPE[a.dtype], a.shape[::-1]
+            a = np.ascontiguousarray(a)
+            if name in q8_0:
+                gtype, ne = 8, (a.shape[1] // 34 * 32, a.shape[0])
+            else:
+                gtype, ne = GGML_OF_DTYPE[a.dtype], a.shape[::-1]
+            raw = a.tobytes()
         nb = name.encode("utf-8")
         infos.append(struct.pack("<Q", len(nb)) + nb + struct.pack("<I", len(ne)) + struct.pack("<" + "Q" * len(ne), *ne)
                      + struct.pack("<IQ", gtype, off))
-        raw = a.tobytes()
         pad = (-len(raw)) % alignment
-        blobs.append(raw + b"\x00" * pad)
+        blobs.append((raw, pad))
         off += len(raw) + pad
     kv = dict(kv)
     if alignment != DEFAULT_ALIGNMENT:
         kv["general.alignment"] = alignment
-    head = struct.pack("<IIQQ", MAGIC, 3, len(tensors), len(kv)) + b"".join(_kv_bytes(k, v) for k, v in kv.items()) + b"".join(infos)
+    head = struct.pack("<IIQQ", MAGIC, 3, len(tensors), len(kv) + len(kv_raw)) + b"".join(kv_raw) + \
+        b"".join(_kv_bytes(k, v) for k, v in kv.items()) + b"".join(infos)
     with open(path, "wb") as f:
         f.write(head)
         f.write(b"\x00" * ((-len(head)) % alignment))
-        for b in blobs:
-            f.write(b)
+        for raw, pad in blobs:
+            f.write(raw)
+            f.write(b"\x00" * pad)
 
 
 def load_seeddelta_context(path: str, n_layer: int = None):

@@ -119,5 +119,5 @@ def metadata(scheme: str, K: int, block: int, row_scale: bool, base: bool, strip
     for e in entries or []:
         pre = f"{KV_PREFIX}blk.{e['layer']}.{e['kind']}"
         kv.update({pre + ".enabled": bool(e["emit"]), pre + ".gating_pass": bool(e["gating_pass"]),
-                   pre + ".strip_dense": bool(e.get("strip_dense", False)), pre + ".K": max(0, int(e["K"]))})
+                   pre + ".strip_dense": bool(e.get("strip_dense", False)), pre + ".K": max(0, int(e.get("K", 0)))})
     return kv

@@ -664,6 +664,21 @@ def complete_entry(e: dict) -> dict:
     (single tile, K selector 'cycle', no autotune; sd_build.cpp:959-1021, :1060-1076)."""
     out = dict(e)
     k_stats = {"has": False, "min": 0, "max": 0, "mean": 0}
+    if "K" not in e:
+        # a tensor that never reached a trial (disabled, missing, no imatrix): the builder's entry keeps its
+        # zero-initialised fields (include/sd_report.h:11-70) next to the decision
+        int_keys = {"K_budget", "K", "block", "n_blocks", "base_L", "base_B", "tile_rows", "tile_rows_align", "k_total_per_tensor",
+                    "unique_k_count", "tiles_rounded_count", "tiles_dropped_count", "kselector_rank", "kselector_tiles_sampled",
+                    "ffn_proxy_eval_x", "ffn_proxy_eval_out", "ffn_proxy_seed", "autotune_selected_budget"}
+        bool_keys = {"has_w", "has_x", "ffn_proxy_available", "ffn_proxy_base_used", "k_custom_used", "autotune_enabled", "strip_dense"}
+        str_keys = {"ffn_proxy_reason", "ffn_proxy_scope", "kselector_mode"}
+        list_keys = {"k_levels", "k_per_tile", "autotune_attempts"}
+        for k in _ENTRY_ORDER:
+            if k in out:
+                continue
+            out[k] = (0 if k in int_keys else False if k in bool_keys else "" if k in str_keys else [] if k in list_keys
+                      else dict(k_stats) if k in ("k_requested_stats", "k_selected_stats") else 0.0)
+        return {k: out[k] for k in _ENTRY_ORDER}
     cost_delta = 0.0
     if e.get("emit"):
         cost_delta = max(0.0, e["gating_min_mean"] - e["gating_value"]) + max(0.0, e["gating_min_p05"] - e["gating_p05"])
@@ -735,8 +750,10 @@ class StackSafetyTracker:
 
 
 def build_run(model: ModelFn, layers: Sequence[int], params: ScanParams, policy=None, imatrix: Optional[Dict[str, np.ndarray]] = None,
-              imatrix_eps: float = 1e-8, imatrix_power: float = 1.0, stack_cost_cap: float = 0.0, strip_dense: bool = False,
-              have_tensor: Optional[Callable[[int, str], bool]] = None, keep_staging: bool = True) -> dict:
+              imatrix_eps: float = 1e-8, imatrix_power: float = 1.0, stack_cost_cap: float = math.inf, strip_dense: bool = False,
+              have_tensor: Optional[Callable[[int, str], bool]] = None, keep_staging: bool = True,
+              K_kind: Optional[Dict[str, int]] = None, skip: Optional[Callable[[int, str], bool]] = None,
+              fetch_dtypes=(np.int16, np.float16)) -> dict:
     """What one `llama-seeddelta-build --layers ... [--policy p.json]` process decides, tensor by tensor,
     on ONE running RNG stream: resolve the policy, adjust thresholds by the stack guard, fit / trial /
     autotune on the GPU, FFN proxy, stack cost accounting and cap. Returns the report entries and, for
@@ -759,7 +776,9 @@ def build_run(model: ModelFn, layers: Sequence[int], params: ScanParams, policy=
     try:
         for layer in layers:
             for kind in KINDS:
-                base_cfg = PL.Resolved(block=params.block, K_gate=params.K, K_up=params.K, K_down=params.K, strip_dense=strip_dense,
+                kk = K_kind or {}                    # --K-gate / --K-up / --K-down override --K per kind (sd_build.cpp:247-252)
+                base_cfg = PL.Resolved(block=params.block, K_gate=kk.get("ffn_gate", params.K), K_up=kk.get("ffn_up", params.K),
+                                       K_down=kk.get("ffn_down", params.K), strip_dense=strip_dense,
                                        enabled=True, metric="cos_x_w", gating_enabled=policy is not None)
                 base_cfg.min_mean, base_cfg.min_p05 = (0.25, 0.15) if kind == "ffn_down" else (0.45, 0.30)     # :304-311
                 cfg = PL.resolve(policy, layer, kind, base_cfg)
@@ -779,6 +798,8 @@ def build_run(model: ModelFn, layers: Sequence[int], params: ScanParams, policy=
                             "targets_used": {"tau_mean": min_mean, "tau_p05": min_p05}}
                 if have_tensor is not None and not have_tensor(layer, kind):
                     entries.append(stub("missing_tensor"))
+                    continue
+                if skip is not None and skip(layer, kind):     # already has delta tensors: no entry, no draws (sd_build.cpp:373-377)
                     continue
                 W = dense(layer, kind)
                 if not cfg.enabled:
@@ -814,12 +835,12 @@ def build_run(model: ModelFn, layers: Sequence[int], params: ScanParams, policy=
                 e["stack_cost_total"] = cost_running + (delta if e["emit"] else 0.0)
                 if e["emit"]:
                     cost_running = e["stack_cost_total"]
-                    if cost_running > stack_cost_cap:                                                          # :1084-1092 (cap 0 => any cost)
+                    if cost_running > stack_cost_cap:                                                          # :1084-1092; the CLI default is +inf: no cap (sd_cli.cpp:58)
                         e.update(emit=False, strip_dense=False, decision="stack_cost_cap", reject_reason="stack_cost_cap")
                     else:
                         guard.record_pass(kind)
                         if keep_staging:
-                            emitted[(layer, kind)] = (p, e["K"], session.fetch_packed())       # packed on the device
+                            emitted[(layer, kind)] = (p, e["K"], session.fetch_packed(*fetch_dtypes))       # packed on the device
                 entries.append(e)
     finally:
         session.close()
