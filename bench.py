@@ -349,7 +349,7 @@ def main():
 
     fwd_flags = seeddelta.FWD_NO_FUSE if args.no_fuse else 0
     fwd_flags |= int(os.environ.get("SDH_BENCH_FLAGS", "0"))        # dev: extra SDH_FWD_* bits (A/B runs)
-    fused = (T == 1 and not args.no_fuse)
+    fused = (T <= 4 and not args.no_fuse)       # 2..4 tokens: one launch too when the payload qualifies (else two kernels)
 
     def run_rotation(stream_ptr):
         for i in range(NP):
@@ -419,7 +419,8 @@ def main():
             kname = "decode_fused_kernel replayed from a hipGraph (base + residual in one launch)"
         elif fused:
             dur_s, n, how = span_ms / 1e3 / steps, steps, "HIP events around the timed region / steps"
-            kname = "decode_fused_kernel (base + residual in one launch)"
+            kname = "decode_fused_kernel (base + residual in one launch)" if T == 1 else \
+                "decode_fused_nt_kernel (2-4 tokens in one launch; shapes it does not cover run as two kernels)"
         else:
             seeddelta.profile_enable(True)
             sp = cur.cuda_stream

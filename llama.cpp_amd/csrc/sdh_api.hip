@@ -397,7 +397,7 @@ int sdh_weight_create(const sdh_weight_desc * desc, sdh_weight ** out) {
         // hand-off buffer of the fused decode kernel: [B][L] granules {value, epoch} (tag 0 = never
         // written; epochs start at 1)
         {
-            const size_t gb = (size_t) L * (size_t) B * sizeof(unsigned long long);
+            const size_t gb = (size_t) MAX_FUSED_TOKENS * (size_t) L * (size_t) B * sizeof(unsigned long long);
             hipError_t e = hipMalloc((void **) &w->handoff, gb);
             if (e == hipSuccess) e = hipMemset(w->handoff, 0, gb);
             if (e != hipSuccess) { set_error("hand-off alloc failed: %s", hipGetErrorString(e)); return fail(SDH_ERR_HIP); }
@@ -541,8 +541,8 @@ int sdh_forward(sdh_weight * h, const float * x, int64_t ldx, int64_t n_tokens,
             return SDH_OK;
         };
 
-        // batch-1 decode with a base: one fused launch when the payload qualifies
-        if (has_base && tc == 1 && !(flags & SDH_FWD_NO_FUSE)) {
+        // decode with a base, 1..4 tokens: one fused launch when the payload qualifies
+        if (has_base && tc >= 1 && tc <= MAX_FUSED_TOKENS && !(flags & SDH_FWD_NO_FUSE)) {
             int pair, rc = prof_begin(pair);
             if (rc != SDH_OK) return rc;
             rc = launch_decode_fused(*w, a, s);

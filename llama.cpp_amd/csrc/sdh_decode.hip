@@ -240,6 +240,138 @@ void decode_fused_kernel(const DeltaParams p, const BasePackDesc pd, const Fused
     }
 }
 
+// ---- small decode batches: 2..4 tokens in one launch -------------------------------------------------
+// Speculative / batched decode hands the op a few tokens at a time. Per token the fused launch would
+// repeat the 13 MB payload stream; the two-kernel path reads it once but pays the kernel boundary
+// (cfg3: T=2 14.9 us; Mistral gate COO K=128: T=2 14.8, T=4 19.8 us). Here the grid has B base workgroups PER TOKEN and every residual wave
+// forms the sums of its row for all tokens from one pass over the payload, then picks up n_tok x nbase
+// granules with one batch of loads. Granules of token t live at vg + t*B*L. NT is the compile-time
+// capacity (2 or 4), n_tok <= NT the tokens of this call: slots past n_tok re-read token 0 and are
+// dropped. Same per-token arithmetic as the one-token kernel, so a token's result does not depend on the
+// batch it arrives in. Measured: cfg3 T=2 12.2 us; Mistral gate T=2 9.9, T=4 15.4 us.
+template <int NB, int NT>
+__device__ __forceinline__ bool poll_granules_nt(const FusedArgs & fa, int o, int L, int B, int nbase, int n_tok, float (&vals)[NT][NB]) {
+    bool ok = false;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    do {
+        unsigned long long g[NT][NB];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) g[t][b] = granule_load(fa.vg, ((t < n_tok ? t : 0) * B + (b < nbase ? b : 0)) * L + o);
+        ok = true;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const bool used = (b < nbase) & (t < n_tok);
+                ok = ok & (((unsigned) (g[t][b] >> 32) == fa.epoch) | !used);
+                vals[t][b] = used ? __uint_as_float((unsigned) g[t][b]) : 0.0f;
+            }
+        if (ok) break;
+        __builtin_amdgcn_s_sleep(SDH_POLL_SLEEP);
+    } while (__builtin_amdgcn_s_memrealtime() - t0 < SPIN_TICKS);
+    return ok;
+}
+
+template <bool BLOCK, int STEPS, int LOG_E, int LOG_T, int NT>
+__global__ __launch_bounds__(1 << LOG_T, (1 << LOG_T) == 512 ? 6 : 1)    // 512 threads: <= 80 VGPRs, three workgroups per CU
+void decode_fused_nt_kernel(const DeltaParams p, const BasePackDesc pd, const FusedArgs fa, const int n_tok) {
+    using Ly = BaseLay<LOG_E, LOG_T>;
+    constexpr int L = Ly::L;
+    constexpr int E = Ly::E;
+    constexpr int WAVES = (1 << LOG_T) / 64;
+    __shared__ __align__(16) float lds[L];
+
+    if (fa.census) {                                   // residency self-test, as in decode_fused_kernel
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(&fa.census_ctr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            bool all = false;
+            while (__builtin_amdgcn_s_memrealtime() - t0 < 2 * SPIN_TICKS) {
+                if (__hip_atomic_load(&fa.census_ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= gridDim.x) { all = true; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (!all) __hip_atomic_fetch_add(&fa.census_ctr[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+
+    const int n_base_wg = p.B * n_tok;
+    if ((int) blockIdx.x < n_base_wg) {
+        const int t = (int) blockIdx.x / p.B, b = (int) blockIdx.x - t * p.B;
+        const int tid = threadIdx.x;
+        __builtin_amdgcn_s_setprio(SDH_BASE_PRIO);
+        float y[E];
+        base_transform<Ly, false, true>(p.x + (size_t) t * p.ldx, p.n_in, p.tall ? 0 : b * L, p.x_vec_ok != 0, pd, b, lds, tid, y);
+        unsigned long long * out = fa.vg + (size_t) (t * p.B + b) * L;
+        const unsigned long long tag = (unsigned long long) fa.epoch << 32;
+#pragma unroll
+        for (int r = 0; r < E; ++r)
+            __hip_atomic_store(out + Ly::idx(Ly::J - 1, tid, r),
+                               tag | (unsigned long long) __float_as_uint(y[r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+
+    const int ridx = residual_index((int) blockIdx.x, n_base_wg, fa.ncu);
+    if (ridx < 0) { shadow_linger(fa.linger); return; }
+    int * const done = reinterpret_cast<int *>(lds);
+    if (fa.reset) reset_begin(done);
+    for (int i = 0; i < fa.resid_delay; ++i) __builtin_amdgcn_s_sleep(8);
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int G = p.G;
+    const int l = lane & (G - 1);
+    const int o = (ridx * WAVES + wave) * (64 / G) + (lane / G);
+    const bool row_ok = o < p.n_out;
+    const int orow = row_ok ? o : 0;
+    const bool leader = row_ok && l == 0;
+    float scale = 1.0f;
+    if (leader && p.rs) scale = p.rs[o];
+
+    int xoff[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) xoff[t] = (t < n_tok ? t : 0) * (int) p.ldx;
+    float acc[NT];
+    delta_row_partial_nt<uint16_t, uint16_t, BLOCK, STEPS, NT>(p, p.x, xoff, orow, row_ok, l, G, acc);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = group_reduce(acc[t], G);
+
+    const int nbase = p.tall ? 1 : p.B;                 // host: nbase * NT <= 16
+    if (leader) {
+        float yh[NT];
+        bool ok;
+        if (nbase == 1) {
+            float vals[NT][1];
+            ok = poll_granules_nt<1, NT>(fa, o, L, p.B, nbase, n_tok, vals);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) yh[t] = p.tall ? vals[t][0] : 0.0f + vals[t][0];   // wide, B = 1: summed from 0.0f
+        } else {
+            constexpr int NBW = (NT <= 2) ? 8 : 4;
+            float vals[NT][NBW];
+            ok = poll_granules_nt<NBW, NT>(fa, o, L, p.B, nbase, n_tok, vals);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                yh[t] = 0.0f;                           // wide: sum_b v_b[o] from 0.0f in block order
+#pragma unroll
+                for (int b = 0; b < NBW; ++b) if (b < nbase) yh[t] += vals[t][b];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t < n_tok) {
+                float y = yh[t] + acc[t];
+                if (!ok) y = __uint_as_float(0x7FC00000u);
+                store_output(p, o, t, y, scale);
+            }
+        }
+    }
+    if (fa.reset && reset_last_wave(done, lane, WAVES)) {
+        const int rows = WAVES * (64 / G), row0 = ridx * rows, n = min(rows, p.n_out - row0);
+        for (int t = 0; t < n_tok; ++t) reset_granules(fa.vg + (size_t) t * p.B * L, row0, n, nbase, L, lane);
+    }
+}
+
 // ---- gate | up in one launch (gated FFN block, T = 1) ----------------------------------------------
 // Both tensors are tall base payloads of one shape (same n_in, n_out, L, B, row shape). The first 2B
 // workgroups run the base blocks of the gate, then of the up tensor; a residual wave computes row o
@@ -470,18 +602,82 @@ static int launch_steps(int steps, const DeltaParams & p, const BasePackDesc & p
     }
 }
 
+// ---- 2..4 tokens ------------------------------------------------------------------------------------
+template <bool BLOCK, int STEPS, int LOG_E, int LOG_T, int NT>
+static int launch_nt_inst(const DeltaParams & p, const BasePackDesc & pd, FusedArgs fa, int n_tok, unsigned grid, hipStream_t s) {
+    static FusedKernelInfo ki;
+    LibState & ls = lib();
+    if (ki.occ < 0) {
+        int occ = 0;
+        SDH_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, decode_fused_nt_kernel<BLOCK, STEPS, LOG_E, LOG_T, NT>, 1 << LOG_T, 0));
+        ki.occ = occ;
+    }
+    static const bool dbg = getenv("SDH_DEBUG") != nullptr;
+    if (ki.census_failed || (long long) grid > (long long) ki.occ * ls.num_cu) {
+        if (dbg) fprintf(stderr, "[sdh] %d-token decode declined: grid=%u occ=%d cus=%d census_failed=%d\n", n_tok, grid, ki.occ, ls.num_cu, (int) ki.census_failed);
+        return 1;
+    }
+    if (grid > ki.census_ok_grid && fa.epoch == CAPTURE_TAG) {
+        if (dbg) fprintf(stderr, "[sdh] %d-token decode declined: capture before the first eager launch (grid=%u)\n", n_tok, grid);
+        return 1;
+    }
+    if (grid > ki.census_ok_grid) {
+        if (!ls.census_ctr) SDH_HIP_CHECK(hipMalloc((void **) &ls.census_ctr, 16));
+        SDH_HIP_CHECK(hipMemsetAsync(ls.census_ctr, 0, 16, s));
+        FusedArgs ca = fa;
+        ca.census = 1;
+        ca.census_ctr = ls.census_ctr;
+        hipLaunchKernelGGL((decode_fused_nt_kernel<BLOCK, STEPS, LOG_E, LOG_T, NT>), dim3(grid), dim3(1 << LOG_T), 0, s, p, pd, ca, n_tok);
+        SDH_HIP_CHECK(hipGetLastError());
+        unsigned h[2] = {0, 0};
+        SDH_HIP_CHECK(hipMemcpyAsync(h, ls.census_ctr, sizeof(h), hipMemcpyDeviceToHost, s));
+        SDH_HIP_CHECK(hipStreamSynchronize(s));
+        if (dbg) fprintf(stderr, "[sdh] %d-token decode census: grid=%u arrived=%u failures=%u\n", n_tok, grid, h[0], h[1]);
+        if (h[0] != grid || h[1] != 0) { ki.census_failed = true; return 1; }
+        ki.census_ok_grid = grid;
+    }
+    fa.census = 0;
+    fa.census_ctr = nullptr;
+    hipLaunchKernelGGL((decode_fused_nt_kernel<BLOCK, STEPS, LOG_E, LOG_T, NT>), dim3(grid), dim3(1 << LOG_T), 0, s, p, pd, fa, n_tok);
+    SDH_HIP_CHECK(hipGetLastError());
+    return SDH_OK;
+}
+
+template <bool BLOCK, int LOG_E, int LOG_T>
+static int launch_nt_steps(int steps, int n_tok, const DeltaParams & p, const BasePackDesc & pd, const FusedArgs & fa, unsigned grid, hipStream_t s) {
+    if (n_tok <= 2) {
+        switch (steps) {
+            case 1: return launch_nt_inst<BLOCK, 1, LOG_E, LOG_T, 2>(p, pd, fa, n_tok, grid, s);
+            case 2: return launch_nt_inst<BLOCK, 2, LOG_E, LOG_T, 2>(p, pd, fa, n_tok, grid, s);
+            case 3: return launch_nt_inst<BLOCK, 3, LOG_E, LOG_T, 2>(p, pd, fa, n_tok, grid, s);
+            case 4: return launch_nt_inst<BLOCK, 4, LOG_E, LOG_T, 2>(p, pd, fa, n_tok, grid, s);
+            default: return 1;
+        }
+    }
+    // 3-4 tokens: rows of up to 2 steps per lane. With 3 steps the kernel needs > 80 VGPRs or spills, and
+    // measured slower than the two-kernel path (cfg3, T=4: 22.5 vs 18.7 us), which those shapes keep.
+    switch (steps) {
+        case 1: return launch_nt_inst<BLOCK, 1, LOG_E, LOG_T, 4>(p, pd, fa, n_tok, grid, s);
+        case 2: return launch_nt_inst<BLOCK, 2, LOG_E, LOG_T, 4>(p, pd, fa, n_tok, grid, s);
+        default: return 1;
+    }
+}
+
 // Returns SDH_OK if the fused kernel was launched, 1 if this payload / call does not qualify (the
 // caller then runs the two-kernel path), <0 on error.
 int launch_decode_fused(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s) {
     const bool is_block = (w.kind == SDH_OP_BASE_BLOCK);
     static const bool dbg = getenv("SDH_DEBUG") != nullptr;
 #define SDH_DECLINE(why) do { if (dbg) fprintf(stderr, "[sdh] fused decode declined: %s\n", why); return 1; } while (0)
-    if (a.T != 1 || a.exact_order) return 1;
+    if (a.T < 1 || a.T > MAX_FUSED_TOKENS || a.exact_order) return 1;
     if (w.kind != SDH_OP_BASE_BLOCK && w.kind != SDH_OP_BASE_COO) return 1;
     if (w.idx_type != SDH_TYPE_I16 || w.val_type != SDH_TYPE_F16) SDH_DECLINE("payload is not I16/F16");
     if (w.pack.wide32 || !w.handoff) SDH_DECLINE("base parameters are 32-bit");
     if (!(w.L == 1024 || w.L == 2048 || w.L == 4096)) SDH_DECLINE("L not in {1024,2048,4096}");
     if (!w.tall && w.B > 8) SDH_DECLINE("more than 8 base blocks per output");
+    const int n_tok = (int) a.T;
+    if (n_tok > 1 && !w.tall && w.B * (n_tok <= 2 ? 2 : 4) > 16) SDH_DECLINE("too many base granules per row for a multi-token launch");
+    if (n_tok > 1 && (a.ldx > INT32_MAX / 4 || !((((uintptr_t) a.x) % 16) == 0 && (a.ldx % 4) == 0))) SDH_DECLINE("token columns are not 16-byte aligned");
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cs) != hipSuccess) SDH_DECLINE("capture status unknown");
     const bool capturing = (cs != hipStreamCaptureStatusNone);
@@ -494,7 +690,7 @@ int launch_decode_fused(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s) 
     const int log_t = decode_log_t((int) w.L);
     const int rows_per_block = ((1 << log_t) / 64) * (64 / G);
     const int ncu = shadow_ncu();
-    const unsigned grid = shadow_grid((int) w.B, (p.n_out + rows_per_block - 1) / rows_per_block, ncu);
+    const unsigned grid = shadow_grid((int) w.B * n_tok, (p.n_out + rows_per_block - 1) / rows_per_block, ncu);
 
     FusedArgs fa{};
     fa.vg = reinterpret_cast<unsigned long long *>(w.handoff);
@@ -504,6 +700,15 @@ int launch_decode_fused(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s) 
     fa.resid_delay = resid_delay_units();
     fa.ncu = ncu;
     fa.linger = shadow_linger_ticks();
+    if (n_tok > 1) {
+        switch (w.L) {
+            case 1024: return is_block ? launch_nt_steps<true, 2, 8>(steps, n_tok, p, w.pack, fa, grid, s) : launch_nt_steps<false, 2, 8>(steps, n_tok, p, w.pack, fa, grid, s);
+            case 2048: return is_block ? launch_nt_steps<true, SDH_L2048_LOG_E, SDH_L2048_LOG_T>(steps, n_tok, p, w.pack, fa, grid, s)
+                                       : launch_nt_steps<false, SDH_L2048_LOG_E, SDH_L2048_LOG_T>(steps, n_tok, p, w.pack, fa, grid, s);
+            default:   return is_block ? launch_nt_steps<true, SDH_L4096_LOG_E, SDH_L4096_LOG_T>(steps, n_tok, p, w.pack, fa, grid, s)
+                                       : launch_nt_steps<false, SDH_L4096_LOG_E, SDH_L4096_LOG_T>(steps, n_tok, p, w.pack, fa, grid, s);
+        }
+    }
     switch (w.L) {
         case 1024: return is_block ? launch_steps<true, 2, 8>(steps, p, w.pack, fa, grid, s) : launch_steps<false, 2, 8>(steps, p, w.pack, fa, grid, s);
         case 2048: return is_block ? launch_steps<true, SDH_L2048_LOG_E, SDH_L2048_LOG_T>(steps, p, w.pack, fa, grid, s)

@@ -76,6 +76,24 @@ template <typename IDX_T> __device__ __forceinline__ int idx_to_i32(IDX_T raw);
 template <> __device__ __forceinline__ int idx_to_i32<uint16_t>(uint16_t raw) { return (int) (int16_t) raw; }
 template <> __device__ __forceinline__ int idx_to_i32<uint32_t>(uint32_t raw) { return (int) raw; }
 
+// The fast path's arithmetic, spelled out so that it does not depend on the compiler's contraction
+// choices: a run of 8 is one rounded multiply and seven fused multiply-adds, a row's partial sum is a
+// chain of rounded adds. Every kernel of the fast path (one token, several tokens, one or two launches)
+// goes through these two, which is what makes their results bit-identical to one another.
+template <typename VAL_T>
+__device__ __forceinline__ float dot8(const Vec8<VAL_T> & v, const float4 & a, const float4 & b) {
+    float ps = __fmul_rn(val_to_f32<VAL_T>(v.get(0)), a.x);
+    ps = __fmaf_rn(val_to_f32<VAL_T>(v.get(1)), a.y, ps);
+    ps = __fmaf_rn(val_to_f32<VAL_T>(v.get(2)), a.z, ps);
+    ps = __fmaf_rn(val_to_f32<VAL_T>(v.get(3)), a.w, ps);
+    ps = __fmaf_rn(val_to_f32<VAL_T>(v.get(4)), b.x, ps);
+    ps = __fmaf_rn(val_to_f32<VAL_T>(v.get(5)), b.y, ps);
+    ps = __fmaf_rn(val_to_f32<VAL_T>(v.get(6)), b.z, ps);
+    ps = __fmaf_rn(val_to_f32<VAL_T>(v.get(7)), b.w, ps);
+    return ps;
+}
+__device__ __forceinline__ float add_if(float acc, bool ok, float term) { return __fadd_rn(acc, ok ? term : 0.0f); }
+
 // One lane's share of one row's dot product on the vector path. STEPS = number of 8-element
 // steps each lane owns (compile time, so that every payload / index / activation load of the row
 // is issued before the first use: one HBM round trip for the payload and the indices, one L2
@@ -125,15 +143,7 @@ __device__ __forceinline__ float delta_row_partial(const DeltaParams & p, const 
             }
 #pragma unroll
             for (int u = 0; u < NS; ++u) {
-                float ps = val_to_f32<VAL_T>(vv[u].get(0)) * xa[u].x;
-                ps += val_to_f32<VAL_T>(vv[u].get(1)) * xa[u].y;
-                ps += val_to_f32<VAL_T>(vv[u].get(2)) * xa[u].z;
-                ps += val_to_f32<VAL_T>(vv[u].get(3)) * xa[u].w;
-                ps += val_to_f32<VAL_T>(vv[u].get(4)) * xb[u].x;
-                ps += val_to_f32<VAL_T>(vv[u].get(5)) * xb[u].y;
-                ps += val_to_f32<VAL_T>(vv[u].get(6)) * xb[u].z;
-                ps += val_to_f32<VAL_T>(vv[u].get(7)) * xb[u].w;
-                acc += ok[u] ? ps : 0.0f;
+                acc = add_if(acc, ok[u], dot8<VAL_T>(vv[u], xa[u], xb[u]));
             }
         } else {
             Vec8<IDX_T> ii[NS];
@@ -156,13 +166,109 @@ __device__ __forceinline__ float delta_row_partial(const DeltaParams & p, const 
             for (int u = 0; u < NS; ++u) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float pr = val_to_f32<VAL_T>(vv[u].get(j)) * xs[u][j];
-                    acc += okj[u][j] ? pr : 0.0f;
+                    acc = add_if(acc, okj[u][j], __fmul_rn(val_to_f32<VAL_T>(vv[u].get(j)), xs[u][j]));
                 }
             }
         }
     }
     return acc;
+}
+
+// The same partial sums for NT tokens at once (small decode batches): the payload of the row is loaded
+// once, the activations of every token are gathered with it, and each token's sum is formed by exactly
+// the operations delta_row_partial performs for that token alone. xoff[t]: element offset of token t's
+// column in x. Compile-time STEPS only.
+template <typename IDX_T, typename VAL_T, bool BLOCK, int STEPS, int NT>
+__device__ __forceinline__ void delta_row_partial_nt(const DeltaParams & p, const float * __restrict__ x, const int (&xoff)[NT],
+                                                     int orow, bool row_ok, int l, int G, float (&acc)[NT]) {
+    static_assert(STEPS > 0, "compile-time steps only");
+    constexpr int NS = STEPS;
+    const VAL_T * vrow = reinterpret_cast<const VAL_T *>(p.val) + (size_t) orow * p.Ktot;
+    const IDX_T * irow = reinterpret_cast<const IDX_T *>(p.idx) + (size_t) orow * (BLOCK ? p.nb : p.Ktot);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = 0.0f;
+    Vec8<VAL_T> vv[NS];
+    bool ok[NS];
+    int e0[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        const int e = (u * G + l) * 8;
+        ok[u] = row_ok & (e < p.Ktot);
+        e0[u] = ok[u] ? e : 0;
+    }
+    if constexpr (BLOCK) {
+        int blk[NS], off[NS], in0[NS];
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const int bi = e0[u] >> p.block_shift;
+            off[u] = e0[u] & (p.block - 1);
+            blk[u] = idx_to_i32<IDX_T>(irow[bi]);
+        }
+#pragma unroll
+        for (int u = 0; u < NS; ++u) vv[u].load(vrow + e0[u]);
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const int raw = (blk[u] << p.block_shift) + off[u];
+            ok[u] = ok[u] & ((unsigned) blk[u] < (unsigned) p.n_blk_in) & (raw < p.n_in);
+            in0[u] = ok[u] ? raw : 0;
+        }
+        // tokens two at a time: the activations of a pair are all in flight together, and a pair is what
+        // fits the register budget that keeps three 512-thread workgroups on a CU (residency of the launch)
+        constexpr int TP = NT < 2 ? NT : 2;
+#pragma unroll
+        for (int t0 = 0; t0 < NT; t0 += TP) {
+            float4 xa[TP][NS], xb[TP][NS];
+#pragma unroll
+            for (int t = 0; t < TP; ++t) {
+#pragma unroll
+                for (int u = 0; u < NS; ++u) {
+                    xa[t][u] = *reinterpret_cast<const float4 *>(x + xoff[t0 + t] + in0[u]);
+                    xb[t][u] = *reinterpret_cast<const float4 *>(x + xoff[t0 + t] + in0[u] + 4);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < TP; ++t) {
+#pragma unroll
+                for (int u = 0; u < NS; ++u) {
+                    acc[t0 + t] = add_if(acc[t0 + t], ok[u], dot8<VAL_T>(vv[u], xa[t][u], xb[t][u]));
+                }
+            }
+            if (t0 + TP < NT) __builtin_amdgcn_sched_barrier(0);     // keep the next pair's loads behind this pair's sums
+        }
+    } else {
+        Vec8<IDX_T> ii[NS];
+#pragma unroll
+        for (int u = 0; u < NS; ++u) ii[u].load(irow + e0[u]);
+#pragma unroll
+        for (int u = 0; u < NS; ++u) vv[u].load(vrow + e0[u]);
+        int ic[NS][8];
+        bool okj[NS][8];
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = idx_to_i32<IDX_T>(ii[u].get(j));
+                okj[u][j] = ok[u] & ((unsigned) i < (unsigned) p.n_in);
+                ic[u][j] = okj[u][j] ? i : 0;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float xs[NS][8];
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xs[u][j] = x[xoff[t] + ic[u][j]];
+            }
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    acc[t] = add_if(acc[t], okj[u][j], __fmul_rn(val_to_f32<VAL_T>(vv[u].get(j)), xs[u][j]));
+                }
+            }
+        }
+    }
 }
 
 // reduce over the G lanes that own a row (G a power of two, groups aligned); every lane of the

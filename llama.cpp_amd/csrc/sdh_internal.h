@@ -67,6 +67,7 @@ struct DeviceWeight {
     // epoch bumped per fused launch
     uint8_t * handoff = nullptr;
     unsigned epoch = 0;
+    // the hand-off buffer holds MAX_FUSED_TOKENS x B x L granules (small decode batches run as one launch)
     // accounting
     int64_t payload_bytes = 0;   // as stored in the GGUF
     // non-finite accounting: ring of per-call counters (no per-call memset on the hot path)
@@ -116,6 +117,8 @@ int launch_base_apply(const DeviceWeight & w, const float * x, int64_t ldx, int6
 int launch_base_apply_generic(const float * x, int64_t ldx, int n_in, int L, int B, bool tall,
                               const float * d1, const float * d2, const float * d3, const int * p1, const int * p2,
                               int64_t T, float * v, hipStream_t s);
+
+constexpr int MAX_FUSED_TOKENS = 4;
 
 struct DeltaLaunch {
     const float * x; int64_t ldx; int64_t T;

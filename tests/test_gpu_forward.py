@@ -297,6 +297,48 @@ def test_fused_decode_under_graph_capture(hip, cfg):
     assert w.nonfinite_count() == 0
 
 
+@pytest.mark.parametrize("cfg", ["cfg3_mistral_down_block32_k1536", "cfg2_gemma4b_gate_coo_k128", "cfg4_mistral_gate_block16_k128",
+                                 "cfg4_mistral_down_coo_k128", "cfg1_gemma1b_gate_block16_k64", "cfg1_gemma1b_down_block16_k128"])
+def test_small_batch_decode_is_one_launch_and_bit_identical(hip, cfg):
+    """2..4 tokens (speculative / batched decode): base workgroups per token and one pass over the payload
+    for all tokens, in one launch. Per token the arithmetic is the one-token kernel's, so every token's
+    output equals its own batch-1 result bit for bit (a batch never changes a token's result), call
+    after call, with strided token columns as well; against the oracle the fast-path tolerance holds."""
+    torch = pytest.importorskip("torch")
+    p = config_payload(cfg)
+    w = hip.SeedDeltaWeight(p)
+    xs = make_x(p.n_in, 12, seed=77)
+    single = np.concatenate([w.forward_host(xs[t:t + 1]) for t in range(12)], axis=0)
+    for T in (2, 3, 4):
+        for rep in range(3):
+            x = xs[rep * T:(rep + 1) * T]
+            y = w.forward_host(x)
+            assert np.array_equal(bits(y), bits(single[rep * T:(rep + 1) * T])), f"{cfg} T={T} call {rep}"
+            assert w.nonfinite_count() == 0
+        check_fast(p, x, y, O.forward(p, x, nth=8))
+        check_fast(p, x, w.forward_host(x, hip.FWD_NO_FUSE), O.forward(p, x, nth=8))
+    # device I/O with padded columns, back to back without synchronisation, then under graph capture
+    ldx, ldy = p.n_in + 8, p.n_out + 4
+    xd = torch.zeros((4, ldx), dtype=torch.float32, device="cuda")
+    xd[:, :p.n_in] = torch.from_numpy(xs[4:8]).cuda()
+    yd = torch.zeros((4, ldy), dtype=torch.float32, device="cuda")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for _ in range(20):
+            w.forward_device(xd.data_ptr(), ldx, 4, yd.data_ptr(), ldy, stream=side.cuda_stream)
+        side.synchronize()
+        assert np.array_equal(bits(yd.cpu().numpy()[:, :p.n_out]), bits(single[4:8]))
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            w.forward_device(xd.data_ptr(), ldx, 4, yd.data_ptr(), ldy, stream=torch.cuda.current_stream().cuda_stream)
+        xd[:, :p.n_in] = torch.from_numpy(xs[8:12]).cuda()
+        for _ in range(3):
+            g.replay()
+        side.synchronize()
+        assert np.array_equal(bits(yd.cpu().numpy()[:, :p.n_out]), bits(single[8:12]))
+    assert w.nonfinite_count() == 0
+
+
 def test_device_io_path_matches_host_io(hip):
     torch = pytest.importorskip("torch")
     p = make_payload(1024, 512, scheme="block", K=64, block=32, base=True, seed=8)
