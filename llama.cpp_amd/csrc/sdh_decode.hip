@@ -190,8 +190,9 @@ void decode_fused_kernel(const DeltaParams p, const BasePackDesc pd, const Fused
     // ---- residual role ------------------------------------------------------------------------
     // A short head start for the base workgroups: their parameter and activation loads head the
     // critical path of the launch, and issued together with the payload flood of ~1000 residual
-    // workgroups they queue behind it. ~1.2 us of delay costs the residual role nothing (it is done
-    // long before the base) and takes cfg3 from 9.9 to 8.9 us.
+    // workgroups they queue behind it. A short delay costs the residual role nothing (it is done
+    // long before the base). Measured on cfg3 with the streaming payload loads: 0 / 1 / 2 / 3 / 4 / 5 / 6 / 8
+    // units = 9.27 / 8.76 / 8.08 / 8.04 / 8.14 / 8.24 / 8.43 / 8.90 us; default 3 (~0.7 us).
     const int ridx = residual_index((int) blockIdx.x, p.B, fa.ncu);
     if (ridx < 0) { shadow_linger(fa.linger); return; }
     int * const done = reinterpret_cast<int *>(lds);
@@ -209,7 +210,7 @@ void decode_fused_kernel(const DeltaParams p, const BasePackDesc pd, const Fused
     if (leader && p.rs) scale = p.rs[o];
 
     SDH_STAMP(10);
-    float acc = delta_row_partial<uint16_t, uint16_t, BLOCK, STEPS>(p, p.x, orow, row_ok, l, G);
+    float acc = delta_row_partial<uint16_t, uint16_t, BLOCK, STEPS, true>(p, p.x, orow, row_ok, l, G);
     acc = group_reduce(acc, G);
     SDH_STAMP(11);
 
@@ -333,7 +334,7 @@ void decode_fused_nt_kernel(const DeltaParams p, const BasePackDesc pd, const Fu
 #pragma unroll
     for (int t = 0; t < NT; ++t) xoff[t] = (t < n_tok ? t : 0) * (int) p.ldx;
     float acc[NT];
-    delta_row_partial_nt<uint16_t, uint16_t, BLOCK, STEPS, NT>(p, p.x, xoff, orow, row_ok, l, G, acc);
+    delta_row_partial_nt<uint16_t, uint16_t, BLOCK, STEPS, NT, true>(p, p.x, xoff, orow, row_ok, l, G, acc);
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = group_reduce(acc[t], G);
 
@@ -451,8 +452,8 @@ void decode_pair_kernel(const PairArgs a) {
     if (leader && a.p[0].rs) sg = a.p[0].rs[o];
     if (leader && a.p[1].rs) su = a.p[1].rs[o];
 
-    float accg = delta_row_partial<uint16_t, uint16_t, BLOCK, STEPS>(a.p[0], a.p[0].x, orow, row_ok, l, G);
-    float accu = delta_row_partial<uint16_t, uint16_t, BLOCK, STEPS>(a.p[1], a.p[0].x, orow, row_ok, l, G);
+    float accg = delta_row_partial<uint16_t, uint16_t, BLOCK, STEPS, true>(a.p[0], a.p[0].x, orow, row_ok, l, G);
+    float accu = delta_row_partial<uint16_t, uint16_t, BLOCK, STEPS, true>(a.p[1], a.p[0].x, orow, row_ok, l, G);
     accg = group_reduce(accg, G);
     accu = group_reduce(accu, G);
 
@@ -525,7 +526,7 @@ static unsigned shadow_grid(int nb, int n_res, int ncu) {
     return (unsigned) (ncu * (1 + full) + (tail ? nb + tail : 0));
 }
 static int resid_delay_units() {
-    static const int v = [] { const char * e = getenv("SDH_DECODE_DELAY"); return e ? atoi(e) : 5; }();
+    static const int v = [] { const char * e = getenv("SDH_DECODE_DELAY"); return e ? atoi(e) : 3; }();
     return v < 0 ? 0 : (v > 64 ? 64 : v);
 }
 
