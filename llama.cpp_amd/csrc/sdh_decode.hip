@@ -702,6 +702,10 @@ int launch_decode_fused(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s) 
     fa.ncu = ncu;
     fa.linger = shadow_linger_ticks();
     if (n_tok > 1) {
+        // several tokens: the residual role is the longer chain (its activation gathers scale with the tokens:
+        // Mistral gate COO, T=4: 14.5 us without a head start, 14.8 / 15.4 / 16.3 with 3 / 6 / 10 units)
+        static const bool delay_forced = getenv("SDH_DECODE_DELAY") != nullptr;
+        if (!delay_forced) fa.resid_delay = 0;
         switch (w.L) {
             case 1024: return is_block ? launch_nt_steps<true, 2, 8>(steps, n_tok, p, w.pack, fa, grid, s) : launch_nt_steps<false, 2, 8>(steps, n_tok, p, w.pack, fa, grid, s);
             case 2048: return is_block ? launch_nt_steps<true, SDH_L2048_LOG_E, SDH_L2048_LOG_T>(steps, n_tok, p, w.pack, fa, grid, s)
