@@ -199,7 +199,7 @@ int sdh_device_synchronize(void) {
 }
 
 // Validation follows try_add_seeddelta (src/llama-context.cpp:145-268).
-int sdh_weight_create(const sdh_weight_desc * desc, sdh_weight ** out) {
+static int sdh_weight_create_impl(const sdh_weight_desc * desc, sdh_weight ** out) {
     if (!desc || !out) { set_error("null argument"); return SDH_ERR_INVALID; }
     *out = nullptr;
     if (!lib().inited) { set_error("sdh_init not called"); return SDH_ERR_NO_DEVICE; }
@@ -468,7 +468,7 @@ static int nf_slot(DeviceWeight * w, hipStream_t s, int * slot_out) {
     return SDH_OK;
 }
 
-int sdh_forward(sdh_weight * h, const float * x, int64_t ldx, int64_t n_tokens,
+static int sdh_forward_impl(sdh_weight * h, const float * x, int64_t ldx, int64_t n_tokens,
                 float * y, int64_t ldy, int flags, void * stream) {
     if (!h || !x || !y) { set_error("null argument"); return SDH_ERR_INVALID; }
     if (!lib().inited) { set_error("sdh_init not called"); return SDH_ERR_NO_DEVICE; }
@@ -676,7 +676,7 @@ static int ffn_gate_up(sdh_weight * hg, sdh_weight * hu, int act, const float * 
 
 int sdh_ffn_last_fused(void) { return lib().ffn_last_fused; }
 
-int sdh_ffn_gate_up(sdh_weight * hg, sdh_weight * hu, int act, const float * x, int64_t ldx, int64_t n_tokens,
+static int sdh_ffn_gate_up_impl(sdh_weight * hg, sdh_weight * hu, int act, const float * x, int64_t ldx, int64_t n_tokens,
                     float * h, int64_t ldh, int flags, void * stream) {
     int rc = ffn_check(hg, hu, act, x, h);
     if (rc != SDH_OK) return rc;
@@ -706,7 +706,7 @@ int sdh_ffn_gate_up(sdh_weight * hg, sdh_weight * hu, int act, const float * x, 
     return SDH_OK;
 }
 
-int sdh_ffn_forward(sdh_weight * hg, sdh_weight * hu, sdh_weight * hd, int act,
+static int sdh_ffn_forward_impl(sdh_weight * hg, sdh_weight * hu, sdh_weight * hd, int act,
                     const float * x, int64_t ldx, int64_t n_tokens, float * y, int64_t ldy,
                     int flags, void * stream) {
     int rc = ffn_check(hg, hu, act, x, y);
@@ -804,7 +804,7 @@ int sdh_profile_read(double * total_ms, int64_t * launches) {
     return SDH_OK;
 }
 
-int sdh_w0_tile(sdh_weight * h, int64_t o0, int64_t o1, int64_t i0, int64_t i1,
+static int sdh_w0_tile_impl(sdh_weight * h, int64_t o0, int64_t o1, int64_t i0, int64_t i1,
                 float * out, int flags, void * stream) {
     if (!h || !out) { set_error("null argument"); return SDH_ERR_INVALID; }
     DeviceWeight * w = reinterpret_cast<DeviceWeight *>(h);
@@ -833,6 +833,32 @@ int sdh_w0_tile(sdh_weight * h, int64_t o0, int64_t o1, int64_t i0, int64_t i1,
         return rc;
     }
     return launch_w0_tile(*w, o0, o1, i0, i1, out, s);
+}
+
+// ---- the ABI is C: nothing is thrown across it (host allocations can fail) ---------------------------
+int sdh_weight_create(const sdh_weight_desc * desc, sdh_weight ** out) {
+    SDH_NO_THROW(sdh_weight_create_impl(desc, out));
+}
+
+int sdh_forward(sdh_weight * h, const float * x, int64_t ldx, int64_t n_tokens,
+                float * y, int64_t ldy, int flags, void * stream) {
+    SDH_NO_THROW(sdh_forward_impl(h, x, ldx, n_tokens, y, ldy, flags, stream));
+}
+
+int sdh_ffn_gate_up(sdh_weight * hg, sdh_weight * hu, int act, const float * x, int64_t ldx, int64_t n_tokens,
+                    float * h, int64_t ldh, int flags, void * stream) {
+    SDH_NO_THROW(sdh_ffn_gate_up_impl(hg, hu, act, x, ldx, n_tokens, h, ldh, flags, stream));
+}
+
+int sdh_ffn_forward(sdh_weight * hg, sdh_weight * hu, sdh_weight * hd, int act,
+                    const float * x, int64_t ldx, int64_t n_tokens, float * y, int64_t ldy,
+                    int flags, void * stream) {
+    SDH_NO_THROW(sdh_ffn_forward_impl(hg, hu, hd, act, x, ldx, n_tokens, y, ldy, flags, stream));
+}
+
+int sdh_w0_tile(sdh_weight * h, int64_t o0, int64_t o1, int64_t i0, int64_t i1,
+                float * out, int flags, void * stream) {
+    SDH_NO_THROW(sdh_w0_tile_impl(h, o0, o1, i0, i1, out, flags, stream));
 }
 
 } // extern "C"

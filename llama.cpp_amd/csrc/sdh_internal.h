@@ -2,6 +2,8 @@
 // gfx950 (MI355X) only. Nothing here crosses the C ABI.
 #pragma once
 #include <cstring>
+#include <exception>
+#include <new>
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -177,3 +179,11 @@ inline uint16_t float_to_half(float fl) {
 
 
 } // namespace sdh
+
+// C ABI boundary: turn anything thrown by host code (std::bad_alloc from a vector, ...) into a status
+#define SDH_NO_THROW(call)                                                                              \
+    try { return (call); }                                                                              \
+    catch (const std::bad_alloc &) { ::sdh::set_error("out of host memory"); return SDH_ERR_HIP; }      \
+    catch (const std::exception & e) { ::sdh::set_error("internal error: %s", e.what()); return SDH_ERR_HIP; } \
+    catch (...) { ::sdh::set_error("internal error"); return SDH_ERR_HIP; }
+

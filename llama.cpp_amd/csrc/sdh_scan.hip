@@ -924,6 +924,7 @@ public:
                 if (q[i]->key == key && q[i]->before == rng) {
                     const std::shared_ptr<Entry> hit = q[i];            // the deque may change while we wait
                     cv.wait(lock, [&] { return hit->ready; });          // someone is computing exactly this
+                    if (!hit->val) break;                               // its computation failed: compute here
                     rng = hit->after;
                     return hit->val;
                 }
@@ -934,7 +935,18 @@ public:
             q.push_back(mine);
             while (q.size() > cap) q.pop_front();                       // holders keep evicted values alive
         }
-        std::shared_ptr<const V> v = make(rng);
+        std::shared_ptr<const V> v;
+        try {
+            v = make(rng);
+        } catch (...) {                                                 // e.g. bad_alloc: release the waiters, forget the entry
+            {
+                std::lock_guard<std::mutex> lock(mu);
+                mine->ready = true;
+                for (size_t i = 0; i < q.size(); ++i) if (q[i] == mine) { q.erase(q.begin() + (long) i); break; }
+            }
+            cv.notify_all();
+            throw;
+        }
         {
             std::lock_guard<std::mutex> lock(mu);
             mine->after = rng;
@@ -1102,7 +1114,7 @@ using namespace sdh;
 
 extern "C" {
 
-int sdh_dense_create(const sdh_tensor * W, sdh_dense ** out) {
+static int sdh_dense_create_impl(const sdh_tensor * W, sdh_dense ** out) {
     if (!W || !out || !W->data) { set_error("sdh_dense_create: null argument"); return SDH_ERR_INVALID; }
     LibState & ls = lib();
     if (!ls.inited) { set_error("sdh_init() has not been called"); return SDH_ERR_NO_DEVICE; }
@@ -1221,7 +1233,7 @@ void sdh_scan_destroy(sdh_scan * h) {
     delete s;
 }
 
-int sdh_scan_skip(sdh_scan * h, int64_t n_in, int64_t n_out, const sdh_scan_params * p) {
+static int sdh_scan_skip_impl(sdh_scan * h, int64_t n_in, int64_t n_out, const sdh_scan_params * p) {
     if (!h || !p || n_in <= 0 || n_out <= 0) { set_error("sdh_scan_skip: bad argument"); return SDH_ERR_INVALID; }
     Scan & s = *(Scan *) h;
     if (p->write_base) {
@@ -1238,7 +1250,7 @@ int sdh_scan_skip(sdh_scan * h, int64_t n_in, int64_t n_out, const sdh_scan_para
     return SDH_OK;
 }
 
-int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, const sdh_dense * Wu,
+static int sdh_scan_tensor_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, const sdh_dense * Wu,
                     const sdh_dense * Wd, const sdh_scan_params * pp, sdh_scan_result * out) {
     if (!h || !Wh || !pp || !out) { set_error("sdh_scan_tensor: null argument"); return SDH_ERR_INVALID; }
     Scan & s = *(Scan *) h;
@@ -1682,7 +1694,7 @@ int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, co
     return SDH_OK;
 }
 
-int sdh_scan_fetch(sdh_scan * h, int32_t * idx, float * val, float * row_scale,
+static int sdh_scan_fetch_impl(sdh_scan * h, int32_t * idx, float * val, float * row_scale,
                    float * d2, float * h2, int32_t * perm1, int32_t * perm1_inv) {
     if (!h) { set_error("sdh_scan_fetch: null handle"); return SDH_ERR_INVALID; }
     Scan & s = *(Scan *) h;
@@ -1711,7 +1723,7 @@ int sdh_scan_fetch(sdh_scan * h, int32_t * idx, float * val, float * row_scale,
     return SDH_OK;
 }
 
-int sdh_scan_fetch_packed(sdh_scan * h, int idx_type, void * idx, int val_type, void * val, uint16_t * row_scale_f16,
+static int sdh_scan_fetch_packed_impl(sdh_scan * h, int idx_type, void * idx, int val_type, void * val, uint16_t * row_scale_f16,
                           uint16_t * d2_f16, void * perm1, int * perm1_type) {
     if (!h) { set_error("sdh_scan_fetch_packed: null handle"); return SDH_ERR_INVALID; }
     Scan & s = *(Scan *) h;
@@ -1764,6 +1776,30 @@ int sdh_scan_fetch_packed(sdh_scan * h, int idx_type, void * idx, int val_type, 
         }
     }
     return SDH_OK;
+}
+
+// ---- the ABI is C: nothing is thrown across it (host allocations can fail) ---------------------------
+int sdh_dense_create(const sdh_tensor * W, sdh_dense ** out) {
+    SDH_NO_THROW(sdh_dense_create_impl(W, out));
+}
+
+int sdh_scan_skip(sdh_scan * h, int64_t n_in, int64_t n_out, const sdh_scan_params * p) {
+    SDH_NO_THROW(sdh_scan_skip_impl(h, n_in, n_out, p));
+}
+
+int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, const sdh_dense * Wu,
+                    const sdh_dense * Wd, const sdh_scan_params * pp, sdh_scan_result * out) {
+    SDH_NO_THROW(sdh_scan_tensor_impl(h, Wh, Wg, Wu, Wd, pp, out));
+}
+
+int sdh_scan_fetch(sdh_scan * h, int32_t * idx, float * val, float * row_scale,
+                   float * d2, float * h2, int32_t * perm1, int32_t * perm1_inv) {
+    SDH_NO_THROW(sdh_scan_fetch_impl(h, idx, val, row_scale, d2, h2, perm1, perm1_inv));
+}
+
+int sdh_scan_fetch_packed(sdh_scan * h, int idx_type, void * idx, int val_type, void * val, uint16_t * row_scale_f16,
+                          uint16_t * d2_f16, void * perm1, int * perm1_type) {
+    SDH_NO_THROW(sdh_scan_fetch_packed_impl(h, idx_type, idx, val_type, val, row_scale_f16, d2_f16, perm1, perm1_type));
 }
 
 } // extern "C"
