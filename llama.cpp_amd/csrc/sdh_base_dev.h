@@ -80,15 +80,32 @@ __device__ __forceinline__ void base_stages(float (&y)[Ly::E]) {
     constexpr int E = Ly::E, LOG_E = Ly::LOG_E;
     constexpr int b0 = JJ * LOG_E;
     constexpr int b1 = (b0 + LOG_E < Ly::N) ? b0 + LOG_E : Ly::N;
+    // Two butterflies per v_pk_add_f32: the same IEEE additions (u - w == u + (-w) exactly), half the VALU
+    // instructions of the stages. The transform of one block runs on one CU and is VALU-issue bound there
+    // (8 waves on 4 SIMDs); hipcc packs only about half of the scalar form by itself. cfg3: 8.06 -> 7.81 us.
+    static_assert(E % 2 == 0, "E is a power of two >= 2");
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int bit = b0; bit < b1; ++bit) {
         const int rb = 1 << (bit - Ly::shift(JJ));
+        if (rb == 1) {
 #pragma unroll
-        for (int r = 0; r < E; ++r) {
-            if ((r & rb) == 0) {
-                const float u = y[r], w = y[r | rb];
-                y[r] = u + w;
-                y[r | rb] = u - w;
+            for (int r = 0; r < E; r += 2) {
+                const f32x2 uu = {y[r], y[r]};
+                const f32x2 ww = {y[r + 1], -y[r + 1]};
+                const f32x2 o = uu + ww;                 // (u + w, u + (-w)) == (u + w, u - w) exactly
+                y[r] = o.x; y[r + 1] = o.y;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < E; r += 2) {
+                if ((r & rb) == 0) {
+                    const f32x2 a = {y[r], y[r + 1]};
+                    const f32x2 b = {y[r | rb], y[(r | rb) + 1]};
+                    const f32x2 p = a + b, m = a - b;
+                    y[r] = p.x; y[r + 1] = p.y;
+                    y[r | rb] = m.x; y[(r | rb) + 1] = m.y;
+                }
             }
         }
     }
