@@ -142,13 +142,16 @@ __device__ __forceinline__ void shadow_linger(int ticks) {
     while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long) ticks) __builtin_amdgcn_s_sleep(16);      // 100 MHz ticks
 }
 
-template <bool BLOCK, int STEPS, int LOG_E, int LOG_T>
-__global__ __launch_bounds__(1 << LOG_T)
+// RW: waves per workgroup. The base role always runs on the first 2^LOG_T threads; RW = 2^LOG_T / 64 + 1
+// is the "exclusive base CU" shape (see launch_decode_fused): one more residual row per workgroup, so
+// that the rows fit on the CUs that carry no base workgroup.
+template <bool BLOCK, int STEPS, int LOG_E, int LOG_T, int RW = (1 << LOG_T) / 64>
+__global__ __launch_bounds__(RW * 64)
 void decode_fused_kernel(const DeltaParams p, const BasePackDesc pd, const FusedArgs fa) {
     using Ly = BaseLay<LOG_E, LOG_T>;
     constexpr int L = Ly::L;
     constexpr int E = Ly::E;
-    constexpr int WAVES = (1 << LOG_T) / 64;
+    constexpr int WAVES = RW;
     __shared__ __align__(16) float lds[L];             // one transpose buffer: occupancy over barriers (two buffers: 7.80 vs 7.80 us)
 
     if (fa.census) {                                   // residency self-test, see header comment
@@ -169,6 +172,7 @@ void decode_fused_kernel(const DeltaParams p, const BasePackDesc pd, const Fused
         // ---- base role: one block of the base transform, published write-through + flag --------
         const int b = blockIdx.x;
         const int tid = threadIdx.x;
+        if constexpr (RW * 64 > (1 << LOG_T)) { if (tid >= (1 << LOG_T)) return; }   // whole extra waves leave: barriers count live waves
         __builtin_amdgcn_s_setprio(SDH_BASE_PRIO);     // the base blocks are the critical path of the launch
         float y[E];
         base_transform<Ly, false, true>(p.x, p.n_in, p.tall ? 0 : b * L, p.x_vec_ok != 0, pd, b, lds, tid, y);
@@ -543,19 +547,19 @@ struct FusedKernelInfo {
     bool census_failed = false;
 };
 
-template <bool BLOCK, int STEPS, int LOG_E, int LOG_T>
+template <bool BLOCK, int STEPS, int LOG_E, int LOG_T, int RW>
 static FusedKernelInfo & kernel_info() {
     static FusedKernelInfo info;
     return info;
 }
 
-template <bool BLOCK, int STEPS, int LOG_E, int LOG_T>
+template <bool BLOCK, int STEPS, int LOG_E, int LOG_T, int RW = (1 << LOG_T) / 64>
 static int launch_inst(const DeltaParams & p, const BasePackDesc & pd, FusedArgs fa, unsigned grid, hipStream_t s) {
-    FusedKernelInfo & ki = kernel_info<BLOCK, STEPS, LOG_E, LOG_T>();
+    FusedKernelInfo & ki = kernel_info<BLOCK, STEPS, LOG_E, LOG_T, RW>();
     LibState & ls = lib();
     if (ki.occ < 0) {
         int occ = 0;
-        SDH_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, decode_fused_kernel<BLOCK, STEPS, LOG_E, LOG_T>, 1 << LOG_T, 0));
+        SDH_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, decode_fused_kernel<BLOCK, STEPS, LOG_E, LOG_T, RW>, RW * 64, 0));
         ki.occ = occ;
     }
     static const bool dbg = getenv("SDH_DEBUG") != nullptr;
@@ -576,7 +580,7 @@ static int launch_inst(const DeltaParams & p, const BasePackDesc & pd, FusedArgs
         FusedArgs ca = fa;
         ca.census = 1;
         ca.census_ctr = ls.census_ctr;
-        hipLaunchKernelGGL((decode_fused_kernel<BLOCK, STEPS, LOG_E, LOG_T>), dim3(grid), dim3(1 << LOG_T), 0, s, p, pd, ca);
+        hipLaunchKernelGGL((decode_fused_kernel<BLOCK, STEPS, LOG_E, LOG_T, RW>), dim3(grid), dim3(RW * 64), 0, s, p, pd, ca);
         SDH_HIP_CHECK(hipGetLastError());
         unsigned h[2] = {0, 0};
         SDH_HIP_CHECK(hipMemcpyAsync(h, ls.census_ctr, sizeof(h), hipMemcpyDeviceToHost, s));
@@ -587,18 +591,18 @@ static int launch_inst(const DeltaParams & p, const BasePackDesc & pd, FusedArgs
     }
     fa.census = 0;
     fa.census_ctr = nullptr;
-    hipLaunchKernelGGL((decode_fused_kernel<BLOCK, STEPS, LOG_E, LOG_T>), dim3(grid), dim3(1 << LOG_T), 0, s, p, pd, fa);
+    hipLaunchKernelGGL((decode_fused_kernel<BLOCK, STEPS, LOG_E, LOG_T, RW>), dim3(grid), dim3(RW * 64), 0, s, p, pd, fa);
     SDH_HIP_CHECK(hipGetLastError());
     return SDH_OK;
 }
 
-template <bool BLOCK, int LOG_E, int LOG_T>
+template <bool BLOCK, int LOG_E, int LOG_T, int RW = (1 << LOG_T) / 64>
 static int launch_steps(int steps, const DeltaParams & p, const BasePackDesc & pd, const FusedArgs & fa, unsigned grid, hipStream_t s) {
     switch (steps) {
-        case 1: return launch_inst<BLOCK, 1, LOG_E, LOG_T>(p, pd, fa, grid, s);
-        case 2: return launch_inst<BLOCK, 2, LOG_E, LOG_T>(p, pd, fa, grid, s);
-        case 3: return launch_inst<BLOCK, 3, LOG_E, LOG_T>(p, pd, fa, grid, s);
-        case 4: return launch_inst<BLOCK, 4, LOG_E, LOG_T>(p, pd, fa, grid, s);
+        case 1: return launch_inst<BLOCK, 1, LOG_E, LOG_T, RW>(p, pd, fa, grid, s);
+        case 2: return launch_inst<BLOCK, 2, LOG_E, LOG_T, RW>(p, pd, fa, grid, s);
+        case 3: return launch_inst<BLOCK, 3, LOG_E, LOG_T, RW>(p, pd, fa, grid, s);
+        case 4: return launch_inst<BLOCK, 4, LOG_E, LOG_T, RW>(p, pd, fa, grid, s);
         default: return 1;
     }
 }
@@ -689,8 +693,26 @@ int launch_decode_fused(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s) 
 #undef SDH_DECLINE
     p.G = G;
     const int log_t = decode_log_t((int) w.L);
-    const int rows_per_block = ((1 << log_t) / 64) * (64 / G);
-    const int ncu = shadow_ncu();
+    int rows_per_block = ((1 << log_t) / 64) * (64 / G);
+    int ncu = shadow_ncu();
+    // Exclusive base CUs (experiment, SDH_DECODE_EXCLUSIVE=1; default off). The dispatcher deals blockIdx
+    // round-robin over the CUs, so ids = b mod CUs of the later wraps can be left empty (they sleep ~1 us,
+    // holding their slot until the dispatch is over) and the base workgroups have their CUs to themselves;
+    // with 9 waves per workgroup the rows of cfg3 (4096 one-row waves) still fit two workgroups per
+    // remaining CU (504 slots), so nothing is unbalanced. In the STAMPED build this takes the base chain
+    // from 6.4 to 3.9 us and the launch from 8.0 to 5.7 us in-kernel; in the product build it measures
+    // 7.93 against 7.78 us per token: the slow chain beside residual workgroups is largely an artefact of
+    // the stamp stores queueing behind the payload loads of the same CU. Kept for the next look at this.
+    bool exclusive = false;
+#if SDH_L4096_LOG_T == 9
+    {
+        static const bool excl_off = [] { const char * e = getenv("SDH_DECODE_EXCLUSIVE"); return !(e && atoi(e) == 1); }();
+        const int slots = 2 * (lib().num_cu - (int) w.B), rpw = 64 / G;
+        const int wg8 = (p.n_out + 8 * rpw - 1) / (8 * rpw), wg9 = (p.n_out + 9 * rpw - 1) / (9 * rpw);
+        exclusive = !excl_off && n_tok == 1 && w.L == 4096 && ncu == 0 && (int) w.B < lib().num_cu / 4 && wg8 > slots && wg9 <= slots;
+        if (exclusive) { rows_per_block = 9 * rpw; ncu = lib().num_cu; }
+    }
+#endif
     const unsigned grid = shadow_grid((int) w.B * n_tok, (p.n_out + rows_per_block - 1) / rows_per_block, ncu);
 
     FusedArgs fa{};
@@ -701,6 +723,14 @@ int launch_decode_fused(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s) 
     fa.resid_delay = resid_delay_units();
     fa.ncu = ncu;
     fa.linger = shadow_linger_ticks();
+    if (exclusive) {
+        static const int excl_linger = [] { const char * e = getenv("SDH_DECODE_EXCL_LINGER"); return e ? atoi(e) : 100; }();
+        fa.linger = excl_linger;
+#if SDH_L4096_LOG_T == 9
+        return is_block ? launch_steps<true, SDH_L4096_LOG_E, SDH_L4096_LOG_T, 9>(steps, p, w.pack, fa, grid, s)
+                        : launch_steps<false, SDH_L4096_LOG_E, SDH_L4096_LOG_T, 9>(steps, p, w.pack, fa, grid, s);
+#endif
+    }
     if (n_tok > 1) {
         // several tokens: the residual role is the longer chain (its activation gathers scale with the tokens:
         // Mistral gate COO, T=4: 14.5 us without a head start, 14.8 / 15.4 / 16.3 with 3 / 6 / 10 units)
