@@ -853,7 +853,11 @@ int launch_decode_pair(DeviceWeight & g, DeviceWeight & u, int act, const uint16
     static const bool force_reset = getenv("SDH_DECODE_FORCE_RESET") != nullptr;
     a.reset = (capturing || force_reset) ? 1 : 0;
     a.act = act; a.gelu_tab = gelu_tab; a.h = h;
-    a.resid_delay = resid_delay_units();
+    // the pair's residual role streams two payloads and is the longer chain: no head start by default
+    // (FFN block, Mistral layer: 12.10 / 12.22 / 12.24 / 12.39 us per layer with 0 / 1 / 2 / 3 units when
+    // both launches shared one setting)
+    static const int pair_delay = [] { const char * e = getenv("SDH_DECODE_PAIR_DELAY"); return e ? atoi(e) : 0; }();
+    a.resid_delay = pair_delay < 0 ? 0 : (pair_delay > 64 ? 64 : pair_delay);
     a.ncu = ncu;
     a.linger = shadow_linger_ticks();
     switch (g.L) {
