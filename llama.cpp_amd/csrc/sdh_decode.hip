@@ -36,6 +36,7 @@
 #include "sdh_base_dev.h"
 #include "sdh_delta_dev.h"
 
+#include <algorithm>
 #include <type_traits>
 
 namespace sdh {
@@ -384,6 +385,121 @@ void decode_fused_nt_kernel(const DeltaParams p, const BasePackDesc pd, const Fu
     }
 }
 
+// ---- 2..4 tokens, COO, activations staged in LDS -------------------------------------------------------
+// For COO payloads the multi-token launch above is bound by the L1 request rate of its activation gathers
+// (one scattered 4-byte request per entry per token). When 16 * n_in bytes fit in LDS the residual
+// workgroups first copy x token-interleaved into LDS (xs4[i] = x_0..3[i], tokens past n_tok zero), and a
+// row entry then costs one 16-byte LDS read for all four tokens. Dynamic LDS: max(4 L, 16 n_in) + 16 bytes.
+template <int STEPS, int LOG_E, int LOG_T>
+__global__ __launch_bounds__(1 << LOG_T)
+void decode_fused_nt_xlds_kernel(const DeltaParams p, const BasePackDesc pd, const FusedArgs fa, const int n_tok) {
+    using Ly = BaseLay<LOG_E, LOG_T>;
+    constexpr int L = Ly::L;
+    constexpr int E = Ly::E;
+    constexpr int WAVES = (1 << LOG_T) / 64;
+    constexpr int THREADS = 1 << LOG_T;
+    extern __shared__ __align__(16) float xlds[];
+
+    if (fa.census) {
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(&fa.census_ctr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            bool all = false;
+            while (__builtin_amdgcn_s_memrealtime() - t0 < 2 * SPIN_TICKS) {
+                if (__hip_atomic_load(&fa.census_ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= gridDim.x) { all = true; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (!all) __hip_atomic_fetch_add(&fa.census_ctr[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+
+    const int n_base_wg = p.B * n_tok;
+    if ((int) blockIdx.x < n_base_wg) {
+        const int t = (int) blockIdx.x / p.B, b = (int) blockIdx.x - t * p.B;
+        const int tid = threadIdx.x;
+        __builtin_amdgcn_s_setprio(SDH_BASE_PRIO);
+        float y[E];
+        base_transform<Ly, false, true>(p.x + (size_t) t * p.ldx, p.n_in, p.tall ? 0 : b * L, p.x_vec_ok != 0, pd, b, xlds, tid, y);
+        unsigned long long * out = fa.vg + (size_t) (t * p.B + b) * L;
+        const unsigned long long tag = (unsigned long long) fa.epoch << 32;
+#pragma unroll
+        for (int r = 0; r < E; ++r)
+            __hip_atomic_store(out + Ly::idx(Ly::J - 1, tid, r),
+                               tag | (unsigned long long) __float_as_uint(y[r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+
+    const int ridx = residual_index((int) blockIdx.x, n_base_wg, fa.ncu);
+    if (ridx < 0) { shadow_linger(fa.linger); return; }
+    float4 * const xs4 = reinterpret_cast<float4 *>(xlds);
+    int * const done = reinterpret_cast<int *>(xlds + 4 * (size_t) p.n_in);      // behind the staged activations
+    for (int i = 0; i < fa.resid_delay; ++i) __builtin_amdgcn_s_sleep(8);
+    {   // stage x: 4 inputs x 4 tokens per thread and pass (host: n_in % 4 == 0, columns 16-byte aligned)
+        const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int i4 = threadIdx.x; i4 < (p.n_in >> 2); i4 += THREADS) {
+            const float4 a = *reinterpret_cast<const float4 *>(p.x + 4 * (size_t) i4);
+            const float4 b = n_tok > 1 ? *reinterpret_cast<const float4 *>(p.x + (size_t) p.ldx + 4 * (size_t) i4) : z;
+            const float4 c = n_tok > 2 ? *reinterpret_cast<const float4 *>(p.x + 2 * (size_t) p.ldx + 4 * (size_t) i4) : z;
+            const float4 d = n_tok > 3 ? *reinterpret_cast<const float4 *>(p.x + 3 * (size_t) p.ldx + 4 * (size_t) i4) : z;
+            xs4[4 * i4 + 0] = make_float4(a.x, b.x, c.x, d.x);
+            xs4[4 * i4 + 1] = make_float4(a.y, b.y, c.y, d.y);
+            xs4[4 * i4 + 2] = make_float4(a.z, b.z, c.z, d.z);
+            xs4[4 * i4 + 3] = make_float4(a.w, b.w, c.w, d.w);
+        }
+        if (threadIdx.x == 0) *done = 0;
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int G = p.G;
+    const int l = lane & (G - 1);
+    const int o = (ridx * WAVES + wave) * (64 / G) + (lane / G);
+    const bool row_ok = o < p.n_out;
+    const int orow = row_ok ? o : 0;
+    const bool leader = row_ok && l == 0;
+    float scale = 1.0f;
+    if (leader && p.rs) scale = p.rs[o];
+
+    float acc[4];
+    delta_row_partial_coo_lds4<uint16_t, uint16_t, STEPS, true>(p, xs4, orow, row_ok, l, G, acc);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = group_reduce(acc[t], G);
+
+    const int nbase = p.tall ? 1 : p.B;                 // host: nbase <= 4 for this kernel
+    if (leader) {
+        float yh[4];
+        bool ok;
+        if (nbase == 1) {
+            float vals[4][1];
+            ok = poll_granules_nt<1, 4>(fa, o, L, p.B, nbase, n_tok, vals);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) yh[t] = p.tall ? vals[t][0] : 0.0f + vals[t][0];
+        } else {
+            float vals[4][4];
+            ok = poll_granules_nt<4, 4>(fa, o, L, p.B, nbase, n_tok, vals);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                yh[t] = 0.0f;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) if (b < nbase) yh[t] += vals[t][b];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t < n_tok) {
+                float y = yh[t] + acc[t];
+                if (!ok) y = __uint_as_float(0x7FC00000u);
+                store_output(p, o, t, y, scale);
+            }
+        }
+    }
+    if (fa.reset && reset_last_wave(done, lane, WAVES)) {
+        const int rows = WAVES * (64 / G), row0 = ridx * rows, n = min(rows, p.n_out - row0);
+        for (int t = 0; t < n_tok; ++t) reset_granules(fa.vg + (size_t) t * p.B * L, row0, n, nbase, L, lane);
+    }
+}
+
 // ---- gate | up in one launch (gated FFN block, T = 1) ----------------------------------------------
 // Both tensors are tall base payloads of one shape (same n_in, n_out, L, B, row shape). The first 2B
 // workgroups run the base blocks of the gate, then of the up tensor; a residual wave computes row o
@@ -675,6 +791,57 @@ static int launch_nt_steps(int steps, int n_tok, const DeltaParams & p, const Ba
     }
 }
 
+// COO, activations staged in LDS (decode_fused_nt_xlds_kernel)
+template <int STEPS, int LOG_E, int LOG_T>
+static int launch_ntx_inst(const DeltaParams & p, const BasePackDesc & pd, FusedArgs fa, int n_tok, unsigned grid, size_t lds, hipStream_t s) {
+    static FusedKernelInfo ki;
+    static size_t occ_lds = 0;
+    LibState & ls = lib();
+    static const bool attr_ok = hipFuncSetAttribute((const void *) decode_fused_nt_xlds_kernel<STEPS, LOG_E, LOG_T>,
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    if (!attr_ok) return 1;
+    if (ki.occ < 0 || lds > occ_lds) {                  // residency depends on the LDS request: keep the largest seen
+        int occ = 0;
+        SDH_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, decode_fused_nt_xlds_kernel<STEPS, LOG_E, LOG_T>, 1 << LOG_T, lds));
+        ki.occ = occ; occ_lds = lds; ki.census_ok_grid = 0;
+    }
+    static const bool dbg = getenv("SDH_DEBUG") != nullptr;
+    if (ki.census_failed || (long long) grid > (long long) ki.occ * ls.num_cu) {
+        if (dbg) fprintf(stderr, "[sdh] %d-token LDS decode declined: grid=%u occ=%d cus=%d lds=%zu census_failed=%d\n", n_tok, grid, ki.occ, ls.num_cu, lds, (int) ki.census_failed);
+        return 1;
+    }
+    if (grid > ki.census_ok_grid && fa.epoch == CAPTURE_TAG) return 1;
+    if (grid > ki.census_ok_grid) {
+        if (!ls.census_ctr) SDH_HIP_CHECK(hipMalloc((void **) &ls.census_ctr, 16));
+        SDH_HIP_CHECK(hipMemsetAsync(ls.census_ctr, 0, 16, s));
+        FusedArgs ca = fa;
+        ca.census = 1;
+        ca.census_ctr = ls.census_ctr;
+        hipLaunchKernelGGL((decode_fused_nt_xlds_kernel<STEPS, LOG_E, LOG_T>), dim3(grid), dim3(1 << LOG_T), occ_lds, s, p, pd, ca, n_tok);
+        SDH_HIP_CHECK(hipGetLastError());
+        unsigned h[2] = {0, 0};
+        SDH_HIP_CHECK(hipMemcpyAsync(h, ls.census_ctr, sizeof(h), hipMemcpyDeviceToHost, s));
+        SDH_HIP_CHECK(hipStreamSynchronize(s));
+        if (dbg) fprintf(stderr, "[sdh] %d-token LDS decode census: grid=%u arrived=%u failures=%u\n", n_tok, grid, h[0], h[1]);
+        if (h[0] != grid || h[1] != 0) { ki.census_failed = true; return 1; }
+        ki.census_ok_grid = grid;
+    }
+    fa.census = 0;
+    fa.census_ctr = nullptr;
+    hipLaunchKernelGGL((decode_fused_nt_xlds_kernel<STEPS, LOG_E, LOG_T>), dim3(grid), dim3(1 << LOG_T), lds, s, p, pd, fa, n_tok);
+    SDH_HIP_CHECK(hipGetLastError());
+    return SDH_OK;
+}
+
+template <int LOG_E, int LOG_T>
+static int launch_ntx_steps(int steps, int n_tok, const DeltaParams & p, const BasePackDesc & pd, const FusedArgs & fa, unsigned grid, size_t lds, hipStream_t s) {
+    switch (steps) {
+        case 1: return launch_ntx_inst<1, LOG_E, LOG_T>(p, pd, fa, n_tok, grid, lds, s);
+        case 2: return launch_ntx_inst<2, LOG_E, LOG_T>(p, pd, fa, n_tok, grid, lds, s);
+        default: return 1;
+    }
+}
+
 // Returns SDH_OK if the fused kernel was launched, 1 if this payload / call does not qualify (the
 // caller then runs the two-kernel path), <0 on error.
 int launch_decode_fused(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s) {
@@ -747,6 +914,18 @@ int launch_decode_fused(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s) 
         // Mistral gate COO, T=4: 14.5 us without a head start, 14.8 / 15.4 / 16.3 with 3 / 6 / 10 units)
         static const bool delay_forced = getenv("SDH_DECODE_DELAY") != nullptr;
         if (!delay_forced) fa.resid_delay = 0;
+        // COO with x small enough for LDS: stage it token-interleaved (one LDS read per entry for all tokens)
+        static const bool xlds_off = [] { const char * e = getenv("SDH_DECODE_XLDS"); return e && atoi(e) == 0; }();
+        const size_t xlds_bytes = std::max((size_t) w.L * 4, (size_t) p.n_in * 16) + 16;
+        if (!xlds_off && !is_block && steps <= 2 && (p.n_in % 4) == 0 && xlds_bytes <= 72 * 1024 && (w.tall || w.B <= 4)) {
+            int rc = 1;
+            switch (w.L) {
+                case 1024: rc = launch_ntx_steps<2, 8>(steps, n_tok, p, w.pack, fa, grid, xlds_bytes, s); break;
+                case 2048: rc = launch_ntx_steps<SDH_L2048_LOG_E, SDH_L2048_LOG_T>(steps, n_tok, p, w.pack, fa, grid, xlds_bytes, s); break;
+                default:   rc = launch_ntx_steps<SDH_L4096_LOG_E, SDH_L4096_LOG_T>(steps, n_tok, p, w.pack, fa, grid, xlds_bytes, s); break;
+            }
+            if (rc != 1) return rc;                    // launched or failed; 1: does not fit, try the plain multi-token launch
+        }
         switch (w.L) {
             case 1024: return is_block ? launch_nt_steps<true, 2, 8>(steps, n_tok, p, w.pack, fa, grid, s) : launch_nt_steps<false, 2, 8>(steps, n_tok, p, w.pack, fa, grid, s);
             case 2048: return is_block ? launch_nt_steps<true, SDH_L2048_LOG_E, SDH_L2048_LOG_T>(steps, n_tok, p, w.pack, fa, grid, s)

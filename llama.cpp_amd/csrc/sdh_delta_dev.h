@@ -287,6 +287,53 @@ __device__ __forceinline__ void delta_row_partial_nt(const DeltaParams & p, cons
     }
 }
 
+// COO rows against activations staged token-interleaved in LDS: xs4[i] = (x_0[i], x_1[i], x_2[i], x_3[i]).
+// One 16-byte LDS read per entry replaces one scattered 4-byte global gather per entry per token, which is
+// what bounds the multi-token COO launch (L1 request rate). Per token the products and the order of the
+// adds are those of delta_row_partial, so results stay bit-identical to the one-token kernel.
+template <typename IDX_T, typename VAL_T, int STEPS, bool STREAM = false>
+__device__ __forceinline__ void delta_row_partial_coo_lds4(const DeltaParams & p, const float4 * __restrict__ xs4,
+                                                           int orow, bool row_ok, int l, int G, float (&acc)[4]) {
+    constexpr int NS = STEPS;
+    const VAL_T * vrow = reinterpret_cast<const VAL_T *>(p.val) + (size_t) orow * p.Ktot;
+    const IDX_T * irow = reinterpret_cast<const IDX_T *>(p.idx) + (size_t) orow * p.Ktot;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = 0.0f;
+    Vec8<VAL_T> vv[NS];
+    Vec8<IDX_T> ii[NS];
+    bool ok[NS];
+    int e0[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        const int e = (u * G + l) * 8;
+        ok[u] = row_ok & (e < p.Ktot);
+        e0[u] = ok[u] ? e : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < NS; ++u) ii[u].template load<STREAM>(irow + e0[u]);
+#pragma unroll
+    for (int u = 0; u < NS; ++u) vv[u].template load<STREAM>(vrow + e0[u]);
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        float4 xv[8];
+        bool okj[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = idx_to_i32<IDX_T>(ii[u].get(j));
+            okj[j] = ok[u] & ((unsigned) i < (unsigned) p.n_in);
+            xv[j] = xs4[okj[j] ? i : 0];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = val_to_f32<VAL_T>(vv[u].get(j));
+            acc[0] = add_if(acc[0], okj[j], __fmul_rn(v, xv[j].x));
+            acc[1] = add_if(acc[1], okj[j], __fmul_rn(v, xv[j].y));
+            acc[2] = add_if(acc[2], okj[j], __fmul_rn(v, xv[j].z));
+            acc[3] = add_if(acc[3], okj[j], __fmul_rn(v, xv[j].w));
+        }
+    }
+}
+
 // reduce over the G lanes that own a row (G a power of two, groups aligned); every lane of the
 // group ends with the sum. (A DPP row-shift + v_readlane form of this reduction measured slower in the
 // fused decode launch, 7.78 vs 7.65 us on cfg3, and was dropped.)
