@@ -114,6 +114,12 @@ int          sdh_init(int device);
 int          sdh_abi_version(void);
 const char * sdh_last_error(void);
 int          sdh_device_synchronize(void);
+/* Streams. Every entry point that takes a `stream` takes a hipStream_t and uses exactly that stream; NULL is
+ * HIP's legacy default stream, as in every HIP API, so a caller that produces x or consumes y on the default
+ * stream is ordered with the call. Only calls with SDH_FWD_HOST_IO treat NULL differently: they are synchronous
+ * (copy in, run, copy out, wait) and then run on the library's private non-blocking stream, which this getter
+ * returns (NULL before sdh_init). No counterpart in the reference (its op is CPU-only). */
+void *       sdh_library_stream(void);
 
 /* ---- weights -------------------------------------------------------------------------
  * sdh_weight_create: validate a payload exactly as try_add_seeddelta does
@@ -133,7 +139,8 @@ int64_t sdh_weight_payload_bytes(const sdh_weight * w);
 /* sdh_forward — replaces the body of the reference's custom-op callback for this payload:
  *   y[o + t*ldy] = row_scale[o] * ( W0(x[:,t])[o] + sum_r val[r,o] * x[idx[r,o] + t*ldx] )
  * x: F32 [n_in, n_tokens] with column stride ldx (elements); y: F32 [n_out, n_tokens] with
- * column stride ldy. `stream` is a hipStream_t (NULL = the library's own stream).
+ * column stride ldy. `stream` is a hipStream_t (NULL = the legacy default stream; with SDH_FWD_HOST_IO
+ * NULL = the library's private stream, see sdh_library_stream).
  * Semantics follow src/llama-seeddelta.cpp: invalid indices skipped (:693, :929-936),
  * out-of-range perm entries read element 0 (:524-527), scale applied only if != 1 (:645),
  * tall/wide base split on n_out >= n_in (:1073).

@@ -29,6 +29,15 @@ LibState & lib() {
 
 static std::mutex g_mu;
 
+// Which stream a call runs on. Device I/O: exactly the caller's handle, and NULL is HIP's legacy default
+// stream, as in every HIP API — so work the caller queued on that stream (the producer of x, the consumer
+// of y) is ordered with ours. Host I/O calls are synchronous (copy in, run, copy out, wait) and own their
+// ordering, so NULL there means the library's private non-blocking stream (sdh_library_stream()).
+static inline hipStream_t resolve_stream(void * stream, int flags) {
+    if ((flags & SDH_FWD_HOST_IO) && !stream) return lib().stream;
+    return (hipStream_t) stream;
+}
+
 // ---- host-side tensor helpers ---------------------------------------------------------------
 static inline bool present(const sdh_tensor & t) { return t.data != nullptr; }
 
@@ -191,6 +200,8 @@ int sdh_init(int device) {
     s.inited = true;
     return SDH_OK;
 }
+
+void * sdh_library_stream(void) { return lib().inited ? (void *) lib().stream : nullptr; }
 
 int sdh_device_synchronize(void) {
     if (!lib().inited) { set_error("sdh_init not called"); return SDH_ERR_NO_DEVICE; }
@@ -479,7 +490,7 @@ static int sdh_forward_impl(sdh_weight * h, const float * x, int64_t ldx, int64_
         return SDH_ERR_INVALID;
     }
     if (n_tokens == 0) return SDH_OK;
-    hipStream_t s = stream ? (hipStream_t) stream : lib().stream;
+    hipStream_t s = resolve_stream(stream, flags);
     const bool host_io = (flags & SDH_FWD_HOST_IO) != 0;
     const bool has_base = (w->kind == SDH_OP_BASE_COO || w->kind == SDH_OP_BASE_BLOCK);
 
@@ -611,7 +622,7 @@ int sdh_glu(int act, const float * g, const float * u, float * y, int64_t n, voi
     if (!ls.inited) { set_error("sdh_init not called"); return SDH_ERR_NO_DEVICE; }
     if (!g || !u || !y || n < 0 || (act != SDH_ACT_SILU && act != SDH_ACT_GELU)) { set_error("sdh_glu: bad argument"); return SDH_ERR_INVALID; }
     if (act == SDH_ACT_GELU) { int rc = ensure_gelu_table(ls); if (rc != SDH_OK) return rc; }
-    return launch_glu(act, ls.gelu_tab, g, u, y, n, stream ? (hipStream_t) stream : ls.stream);
+    return launch_glu(act, ls.gelu_tab, g, u, y, n, (hipStream_t) stream);
 }
 
 // FFN workspace: sections of `floats` each, 16-byte aligned, grown on demand
@@ -685,7 +696,7 @@ static int sdh_ffn_gate_up_impl(sdh_weight * hg, sdh_weight * hu, int act, const
     const int64_t n_embd = g->n_in, n_ff = g->n_out;
     if (n_tokens < 0 || ldx < n_embd || ldh < n_ff) { set_error("bad shape"); return SDH_ERR_INVALID; }
     if (n_tokens == 0) return SDH_OK;
-    hipStream_t s = stream ? (hipStream_t) stream : ls.stream;
+    hipStream_t s = resolve_stream(stream, flags);
     const bool host_io = (flags & SDH_FWD_HOST_IO) != 0;
     const size_t T = (size_t) n_tokens;
     const bool dense_h = !host_io && ldh == n_ff;                // h can be written in place
@@ -722,7 +733,7 @@ static int sdh_ffn_forward_impl(sdh_weight * hg, sdh_weight * hu, sdh_weight * h
     }
     if (n_tokens < 0 || ldx < n_embd || ldy < d->n_out) { set_error("bad shape"); return SDH_ERR_INVALID; }
     if (n_tokens == 0) return SDH_OK;
-    hipStream_t s = stream ? (hipStream_t) stream : ls.stream;
+    hipStream_t s = resolve_stream(stream, flags);
     const bool host_io = (flags & SDH_FWD_HOST_IO) != 0;
     const size_t T = (size_t) n_tokens;
     const size_t sec[5] = {host_io ? T * (size_t) n_embd : 0, host_io ? T * (size_t) d->n_out : 0,
@@ -776,14 +787,14 @@ int sdh_profile_span_begin(void * stream) {
         SDH_HIP_CHECK(hipEventCreate(&s.span_ev[1]));
     }
     s.span_forwards = 0;
-    SDH_HIP_CHECK(hipEventRecord(s.span_ev[0], stream ? (hipStream_t) stream : s.stream));
+    SDH_HIP_CHECK(hipEventRecord(s.span_ev[0], (hipStream_t) stream));
     return SDH_OK;
 }
 
 int sdh_profile_span_end(void * stream, double * elapsed_ms, int64_t * forwards) {
     LibState & s = lib();
     if (!s.inited || !s.span_ev[0]) { set_error("sdh_profile_span_begin not called"); return SDH_ERR_INVALID; }
-    SDH_HIP_CHECK(hipEventRecord(s.span_ev[1], stream ? (hipStream_t) stream : s.stream));
+    SDH_HIP_CHECK(hipEventRecord(s.span_ev[1], (hipStream_t) stream));
     SDH_HIP_CHECK(hipEventSynchronize(s.span_ev[1]));
     float ms = 0.0f;
     SDH_HIP_CHECK(hipEventElapsedTime(&ms, s.span_ev[0], s.span_ev[1]));
@@ -817,7 +828,7 @@ static int sdh_w0_tile_impl(sdh_weight * h, int64_t o0, int64_t o1, int64_t i0, 
         set_error("tile out of range");
         return SDH_ERR_INVALID;
     }
-    hipStream_t s = stream ? (hipStream_t) stream : lib().stream;
+    hipStream_t s = resolve_stream(stream, flags);
     const size_t bytes = (size_t) (o1 - o0) * (size_t) (i1 - i0) * 4;
     if (bytes == 0) return SDH_OK;
     if (flags & SDH_FWD_HOST_IO) {

@@ -30,7 +30,7 @@ FWD_DEVICE_IO, FWD_HOST_IO, FWD_ZERO_NONFINITE, FWD_EXACT_ORDER, FWD_W0_MFMA, FW
 
 # every symbol include/seeddelta_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
-    "sdh_init", "sdh_abi_version", "sdh_last_error", "sdh_device_synchronize",
+    "sdh_init", "sdh_abi_version", "sdh_last_error", "sdh_device_synchronize", "sdh_library_stream",
     "sdh_weight_create", "sdh_weight_destroy", "sdh_weight_op_kind", "sdh_weight_payload_bytes",
     "sdh_forward", "sdh_nonfinite_count", "sdh_w0_tile", "sdh_ffn_forward", "sdh_ffn_gate_up", "sdh_ffn_last_fused", "sdh_glu",
     "sdh_profile_enable", "sdh_profile_read", "sdh_profile_span_begin", "sdh_profile_span_end",
@@ -111,6 +111,7 @@ def load_library(path: str = LIB_PATH):
     lib.sdh_init.argtypes = [C.c_int]
     lib.sdh_abi_version.restype = C.c_int
     lib.sdh_last_error.restype = C.c_char_p
+    lib.sdh_library_stream.restype = C.c_void_p
     lib.sdh_weight_create.argtypes = [C.POINTER(SdhWeightDesc), C.POINTER(C.c_void_p)]
     lib.sdh_weight_destroy.argtypes = [C.c_void_p]
     lib.sdh_weight_destroy.restype = None
@@ -167,6 +168,11 @@ def init(device: int = 0):
     lib = load_library()
     _check(lib.sdh_init(device), "sdh_init")
     _inited_device = device
+
+
+def library_stream() -> int:
+    """The library's private non-blocking stream (what host-I/O calls with stream NULL run on)."""
+    return int(load_library().sdh_library_stream() or 0)
 
 
 def profile_enable(on: bool):

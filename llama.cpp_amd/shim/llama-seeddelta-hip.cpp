@@ -55,8 +55,21 @@ struct payload_key_hash {
     }
 };
 
-std::mutex g_mu;
-std::unordered_map<payload_key, sdh_weight *, payload_key_hash> g_payloads;
+// A cache entry is tied to the CONTENT it was uploaded from, not only to the host addresses: the model that
+// owned those addresses may have been freed and another one mapped in their place (sequential loads in one
+// process). Each hit re-checks a fingerprint of the payload tensors (shapes, types, owning buffer and sampled
+// bytes: a few hundred bytes per call against a ~30 us submit-and-wait); on a mismatch the stale device copy
+// is dropped and the payload uploaded again. llama_seeddelta_hip_release_all() remains the deterministic way
+// (call it when a model is freed).
+struct payload_entry {
+    sdh_weight * w = nullptr;
+    uint64_t     fingerprint = 0;
+};
+
+std::mutex g_mu;        // payload cache, FFN node list, library init
+std::mutex g_call_mu;   // one evaluation at a time: contexts that share a model share its sdh_weight handles
+                        // (hand-off granules, non-finite ring, workspace) and the library's host-I/O staging
+std::unordered_map<payload_key, payload_entry, payload_key_hash> g_payloads;
 bool g_inited = false;
 std::atomic<int64_t> g_nonfinite_total{0};
 std::atomic_flag g_nonfinite_warned = ATOMIC_FLAG_INIT;
@@ -115,6 +128,30 @@ node_payload sources_of(const ggml_tensor * dst) {
     return n;
 }
 
+uint64_t fingerprint_of(const ggml_tensor * const * all, int n) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void * p, size_t len) {
+        const uint8_t * b = (const uint8_t *) p;
+        for (size_t i = 0; i < len; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    };
+    for (int i = 0; i < n; ++i) {
+        const ggml_tensor * t = all[i];
+        if (!t || !t->data) { mix(&i, sizeof(i)); continue; }
+        mix(t->ne, sizeof(t->ne));
+        mix(t->nb, sizeof(t->nb));
+        mix(&t->type, sizeof(t->type));
+        const void * buf = (t->view_src ? t->view_src : t)->buffer;
+        mix(&buf, sizeof(buf));
+        const size_t nbytes = ggml_nbytes(t);
+        const uint8_t * d = (const uint8_t *) t->data;
+        const size_t win = nbytes < 64 ? nbytes : 64;
+        mix(d, win);                                           // head, tail and three interior windows
+        mix(d + nbytes - win, win);
+        for (int k = 1; k <= 3; ++k) mix(d + (nbytes - win) / 4 * k, win);
+    }
+    return h;
+}
+
 sdh_weight * resident_payload(const node_payload & n) {
     const ggml_tensor * idx = n.b_idx ? n.b_idx : n.d_idx;
     payload_key key;
@@ -133,9 +170,14 @@ sdh_weight * resident_payload(const node_payload & n) {
         }
         g_inited = true;
     }
+    const uint64_t fp = fingerprint_of(all, 10);
     auto it = g_payloads.find(key);
     if (it != g_payloads.end()) {
-        return it->second;
+        if (it->second.fingerprint == fp) {
+            return it->second.w;
+        }
+        sdh_weight_destroy(it->second.w);                      // same addresses, different contents: another model
+        g_payloads.erase(it);
     }
     sdh_weight_desc d;
     std::memset(&d, 0, sizeof(d));
@@ -150,7 +192,10 @@ sdh_weight * resident_payload(const node_payload & n) {
     if (sdh_weight_create(&d, &w) != SDH_OK) {
         die("sdh_weight_create");
     }
-    g_payloads.emplace(key, w);
+    payload_entry e;
+    e.w = w;
+    e.fingerprint = fp;
+    g_payloads.emplace(key, e);
     return w;
 }
 
@@ -252,6 +297,7 @@ void seeddelta_hip_op(ggml_tensor * dst, int ith, int /*nth*/, void * userdata) 
     }
     GGML_ASSERT(dst->type == GGML_TYPE_F32 && dst->nb[0] == sizeof(float) && dst->nb[1] % sizeof(float) == 0);
 
+    std::lock_guard<std::mutex> call_lock(g_call_mu);
     sdh_weight * w = resident_payload(n);
     int64_t ldx = n_in;
     const float * xs = packed_x(n.x, n_in, n_tok, &ldx);
@@ -305,6 +351,7 @@ void seeddelta_hip_ffn_op(ggml_tensor * dst, int ith, int /*nth*/, void * userda
         return;
     }
     GGML_ASSERT(dst->type == GGML_TYPE_F32 && dst->nb[0] == sizeof(float) && dst->nb[1] % sizeof(float) == 0);
+    std::lock_guard<std::mutex> call_lock(g_call_mu);
     sdh_weight * wg = resident_payload(payload_of(f->gate, x));
     sdh_weight * wu = resident_payload(payload_of(f->up, x));
     // ffn_down reads the [n_ff, n_tokens] activation: only its row count enters the payload key
@@ -363,9 +410,10 @@ ggml_tensor * llama_seeddelta_hip_ffn(
 
 // Exported for teardown paths and tests: frees every device-resident payload.
 extern "C" void llama_seeddelta_hip_release_all(void) {
+    std::lock_guard<std::mutex> call_lock(g_call_mu);
     std::lock_guard<std::mutex> lock(g_mu);
     for (auto & kv : g_payloads) {
-        sdh_weight_destroy(kv.second);
+        sdh_weight_destroy(kv.second.w);
     }
     g_payloads.clear();
     for (ffn_node * f : g_ffn_nodes) {

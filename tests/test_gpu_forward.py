@@ -405,3 +405,29 @@ def test_prefill_w0_mfma_path(hip, dims, scheme, T):
     err = np.abs(y.astype(np.float64) - y_ref.astype(np.float64))
     assert np.all(err <= bound), f"max err/bound = {np.max(err / bound):.3g}"
     assert np.max(err / bound) > 1e-4      # the MFMA path really ran (it is not bit-exact)
+
+
+def test_null_stream_is_the_default_stream(hip):
+    """Device I/O with stream NULL runs on HIP's legacy default stream (include/seeddelta_hip.h, Streams): x is
+    produced and y consumed on torch's default stream with NO host synchronisation around the call. A library
+    that re-routed NULL to a private stream would read x before the producer finished."""
+    torch = pytest.importorskip("torch")
+    p = config_payload("cfg4_mistral_down_coo_k128")
+    w = hip.SeedDeltaWeight(p)
+    xs = make_x(p.n_in, 4, seed=9)
+    want = [w.forward_host(xs[i:i + 1]) for i in range(4)]
+    big = torch.randn((8192, 8192), device="cuda")
+    xd = torch.zeros((1, p.n_in), dtype=torch.float32, device="cuda")
+    yd = torch.zeros((1, p.n_out), dtype=torch.float32, device="cuda")
+    src = [torch.from_numpy(xs[i:i + 1]).cuda() for i in range(4)]
+    outs = []
+    torch.cuda.synchronize()
+    for i in range(4):
+        _ = big @ big                                  # keeps the default stream busy ahead of the producer
+        xd.copy_(src[i] * 1.0)                         # producer of x, default stream
+        w.forward_device(xd.data_ptr(), p.n_in, 1, yd.data_ptr(), p.n_out, stream=0)
+        outs.append(yd.clone())                        # consumer of y, default stream
+    torch.cuda.synchronize()
+    for i in range(4):
+        assert np.array_equal(bits(outs[i].cpu().numpy()), bits(want[i])), i
+    assert hip.library_stream() != 0
