@@ -1,18 +1,20 @@
 #!/usr/bin/env python3
 """bench.py — SeedDelta FFN decode throughput on MI355X (BASELINE.json metric, config 3).
 
-A "step" is one pass of the hot path over one batch of synthetic input: one token (T=1) through the
-SeedDelta op of one FFN tensor — by default Mistral-7B ``blk.23.ffn_down`` (14336 -> 4096), block32
-K=1536 (nb=48), base L=4096 B=4, row_scale: 13,189,120 algorithmic bytes per step.
-Inputs are resident in HBM when the timed region starts. To keep the 256 MB Infinity Cache from
-serving the payload, the loop rotates over ``--payloads`` (default 32 => 420 MB) distinct payloads and
-activations.
+The unit of work is one token (T=1) through the SeedDelta op of one FFN tensor — by default Mistral-7B
+``blk.23.ffn_down`` (14336 -> 4096), block32 K=1536 (nb=48), base L=4096 B=4, row_scale: 13,189,120
+algorithmic bytes per token. Inputs are resident in HBM when the timed region starts. To
+keep the 256 MB Infinity Cache from serving the payload, the loop rotates over ``--payloads`` (default 32
+=> 420 MB) distinct payloads and activations, and a "step" is ONE ROTATION: ``--payloads`` tokens, one
+launch each (``config.tokens_per_step``). ``--steps K --warmup W`` are honoured exactly as given.
 
   python bench.py --gpus N --steps K --warmup W
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the FFN path does not shard — one model
-fits one GPU — so ranks run independent replicas ("replicas only", weak scaling), no data-path
-collective; the reported value is all ranks' steps / max-over-ranks time.
+N > 1: one rank per GPU, either launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the
+environment) or, when ``--gpus N`` is given without them, spawned by this script as N fresh child processes
+before anything touches a GPU. The FFN path does not shard — one model fits one GPU — so ranks run
+independent replicas ("replicas only", weak scaling), no data-path collective; the reported value is all
+ranks' tokens / max-over-ranks time. The scan leg shards (strong scaling, one all_gather).
 
 Prints ONE JSON line on rank 0 with the throughput, a ``roofline`` object for the dominant kernel
 (payload-streaming residual kernel; duration from HIP events recorded by the library on the launch
@@ -40,8 +42,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8192)
-    ap.add_argument("--warmup", type=int, default=512)
+    ap.add_argument("--steps", type=int, default=256, help="timed steps; one step = one rotation over --payloads distinct payloads")
+    ap.add_argument("--warmup", type=int, default=16, help="untimed warm-up steps (rotations)")
     ap.add_argument("--workload", default="cfg3_mistral_down_block32_k1536")
     ap.add_argument("--payloads", type=int, default=32, help="distinct payloads rotated per loop (cache honesty)")
     ap.add_argument("--tokens", type=int, default=1, help="tokens per step (1 = decode)")
@@ -54,6 +56,8 @@ def parse_args():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-scan", action="store_true", help="skip the scan (candidates/s) leg")
     ap.add_argument("--no-ffn", action="store_true", help="skip the gated-FFN-block leg")
+    ap.add_argument("--no-prefill", action="store_true", help="skip the prefill (T=512) leg")
+    ap.add_argument("--prefill-reps", type=int, default=20)
     ap.add_argument("--ffn-layers", type=int, default=16, help="distinct synthetic Mistral-7B layers rotated in the FFN-block leg")
     ap.add_argument("--scan-layers", type=int, default=32, help="synthetic Mistral-7B layers in the scan job")
     ap.add_argument("--scan-payload-sample", type=int, default=48,
@@ -144,18 +148,9 @@ def run_scan(args, rank, world, dev):
             c.variant = v
             cands.append(c)
     cost = lambda c: (2.0 if c.variant else 1.0) + c.K / 1536.0       # noqa: E731
-    # all trials of one (layer, tensor) stay on one rank: its dense weight is uploaded once
-    groups = {}
-    for c in cands:
-        groups.setdefault((c.layer, SC.KIND_ID[c.kind]), []).append(c)
-    load, owner = [0.0] * world, {}
-    for g in sorted(groups, key=lambda g: (-sum(cost(c) for c in groups[g]), g)):     # same greedy deal on every rank
-        r = min(range(world), key=lambda i: (load[i], i))
-        load[r] += sum(cost(c) for c in groups[g])
-        owner[g] = r
-    own = lambda c: owner[(c.layer, SC.KIND_ID[c.kind])]             # noqa: E731
-    mine = [c for c in cands if own(c) == rank]
-    counts = [sum(1 for c in cands if own(c) == r) for r in range(world)]
+    # all trials of one (layer, tensor) stay on one rank: its dense weight is uploaded once;
+    # the same deal the world-size-2 gloo test exercises (tests/test_scan_host.py)
+    mine, counts = SC.shard_groups(cands, rank, world, cost)
     ev = SC.Evaluator(scan_model, variants[0], max_resident=3 * max(1, args.scan_layers), dims_of=scan_dims)
     for c in mine:                                                    # weights resident before the clock starts
         for k in (SC.KINDS if c.kind != "ffn_down" else (c.kind,)):
@@ -217,11 +212,32 @@ def run_scan(args, rank, world, dev):
     return out
 
 
+def timed_on_stream(fn, reps, stream, seeddelta, warm=None):
+    """Run fn() reps times on `stream` (an explicit, non-default torch stream whose handle every library call
+    receives) and time the region twice: HIP events recorded by the library ON THAT STREAM (sdh_profile_span_*)
+    and the synchronised host clock. Returns (event_ms, host_ms). The two must agree: events on another stream
+    would time host enqueue, not the kernels (the flaw of the round-1 FFN figure)."""
+    import torch
+    for _ in range(max(2, reps // 8) if warm is None else warm):
+        fn()
+    stream.synchronize()
+    torch.cuda.synchronize()
+    seeddelta.profile_span_begin(stream.cuda_stream)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    ev_ms, _ = seeddelta.profile_span_end(stream.cuda_stream)       # waits for the closing event
+    stream.synchronize()
+    host_ms = (time.perf_counter() - t0) * 1e3
+    return ev_ms, host_ms
+
+
 def run_ffn(args, dev):
     """Gated FFN block at T=1: one Mistral-7B layer = gate, up (4096->14336) and down
     (14336->4096), COO K=128 with base, SiLU. Compares sdh_ffn_forward (gate|up in one launch, h kept on
     the device, then down) with the same three nodes + activation issued one by one. Layers rotate so
-    that the payloads (17 MB per layer) do not stay in the 256 MB Infinity Cache."""
+    that the payloads (17 MB per layer) do not stay in the 256 MB Infinity Cache. Everything is launched and
+    timed on one explicit stream."""
     import torch
     from llama_cpp_amd import seeddelta
     from llama_cpp_amd.payload import make_payload
@@ -240,7 +256,10 @@ def run_ffn(args, dev):
     g = torch.empty((1, n_ff), dtype=torch.float32, device=dev)
     u = torch.empty((1, n_ff), dtype=torch.float32, device=dev)
     h = torch.empty((1, n_ff), dtype=torch.float32, device=dev)
-    sp = torch.cuda.current_stream().cuda_stream
+    torch.cuda.synchronize()
+    st = torch.cuda.Stream(device=dev)
+    sp = st.cuda_stream
+    assert sp != 0
 
     def block():
         for wg, wu, wd in layers:
@@ -253,33 +272,91 @@ def run_ffn(args, dev):
             seeddelta.glu_device(seeddelta.ACT_SILU, g.data_ptr(), u.data_ptr(), h.data_ptr(), n_ff, sp)
             wd.forward_device(h.data_ptr(), n_ff, 1, y.data_ptr(), n_embd, 0, sp)
 
-    def timed(fn, reps):
-        for _ in range(max(2, reps // 8)):
-            fn()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) * 1e3 / (reps * NL)        # us per layer
-
     reps = max(8, 2048 // NL)
-    us_block = timed(block, reps)
+    ev_b, host_b = timed_on_stream(block, reps, st, seeddelta)
     fused = seeddelta.ffn_last_fused()
-    us_nodes = timed(nodes, reps)
+    ev_n, host_n = timed_on_stream(nodes, reps, st, seeddelta)
+    us_block, us_nodes = ev_b * 1e3 / (reps * NL), ev_n * 1e3 / (reps * NL)
     for ws in layers:
         for w in ws:
             w.close()
-    return {"metric": "gated FFN block decode, layers/s (Mistral-7B layer, COO K=128 + base, SiLU, T=1)",
-            "value": 1e6 / us_block, "unit": "layers/s", "us_per_layer": us_block,
-            "us_per_layer_node_by_node": us_nodes, "speedup_vs_node_by_node": us_nodes / us_block,
-            "gate_up_single_launch": bool(fused), "distinct_layers": NL,
-            "algorithmic_bytes_per_layer": alg,
-            "roofline": {"bound": "hbm", "achieved": alg / us_block / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / us_block / 1e3 / HBM_PEAK_GBS, "traffic": None,
-                         "note": "two launches per layer (gate|up, down): launch-latency bound like the single-tensor decode"}}
+    out = {"metric": "gated FFN block decode, layers/s (Mistral-7B layer, COO K=128 + base, SiLU, T=1)",
+           "value": 1e6 / us_block, "unit": "layers/s", "us_per_layer": us_block,
+           "us_per_layer_host_clock": host_b * 1e3 / (reps * NL),
+           "us_per_layer_node_by_node": us_nodes, "us_per_layer_node_by_node_host_clock": host_n * 1e3 / (reps * NL),
+           "speedup_vs_node_by_node": us_nodes / us_block,
+           "gate_up_single_launch": bool(fused), "distinct_layers": NL,
+           "algorithmic_bytes_per_layer": alg,
+           "timing": "HIP events recorded by the library on the explicit launch stream; host clock (synchronised) beside it",
+           "roofline": {"bound": "hbm", "achieved": alg / us_block / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": alg / us_block / 1e3 / HBM_PEAK_GBS, "traffic": None,
+                        "note": "two launches per layer (gate|up, down): launch-latency bound like the single-tensor decode"}}
+    # the event span can only be shorter than the host clock by the enqueue lead; a large gap means mis-timing
+    out["timing_consistent"] = bool(us_block <= out["us_per_layer_host_clock"] * 1.02 and us_block >= 0.80 * out["us_per_layer_host_clock"])
+    return out
+
+
+PREFILL_WORKLOADS = ("cfg4_mistral_gate_coo_k128", "cfg4_mistral_gate_block16_k128",
+                     "cfg4_mistral_down_coo_k128", "cfg4_mistral_down_block16_k128")
+MFMA_F16_PEAK_TFLOPS = 2500.0      # dense f16/bf16 MFMA (MI355X_MICROARCH.md); never the 2:1-sparsity figure
+VALU_F32_PEAK_TFLOPS = 157.3
+
+
+def run_prefill(args, dev):
+    """Prefill leg (config 4): Mistral-7B gate / down, K=128, COO vs block16, base on, one ubatch of T=512
+    tokens per call. Per workload: the default path (FWHT base + sparse x dense residual) and the W0-on-MFMA
+    base (SDH_FWD_W0_MFMA), each timed on one explicit stream with the library's events. Rooflines: HBM for the
+    algorithmic bytes (payload as stored + 4*T*(n_in+n_out)); fp32 VALU for the residual's
+    multiply-adds (2*K*n_out*T); dense f16 MFMA for the W0 contraction (2*n_in*n_out*T)."""
+    import torch
+    from llama_cpp_amd import seeddelta
+    from llama_cpp_amd.payload import config_payload
+    T = 512
+    st = torch.cuda.Stream(device=dev)
+    sp = st.cuda_stream
+    pmc = None
+    ppath = os.path.join(ROOT, "profiles", "r02_prefill_pmc.json")
+    if os.path.exists(ppath):
+        with open(ppath) as fh:
+            pmc = json.load(fh)
+    legs = {}
+    for name in PREFILL_WORKLOADS:
+        p = config_payload(name)
+        w = seeddelta.SeedDeltaWeight(p)
+        alg = p.algorithmic_bytes(T)
+        K = p.d_idx.shape[1] if p.d_idx is not None else p.b_idx.shape[1] * p.b_val.shape[2]
+        n_in, n_out = p.n_in, p.n_out
+        del p
+        g = torch.Generator(device="cpu").manual_seed(5)
+        x = torch.randn((T, n_in), generator=g, dtype=torch.float32).to(dev)
+        y = torch.empty((T, n_out), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        leg = {"algorithmic_bytes": alg, "tokens": T}
+        for tag, flags in (("default", 0), ("w0_mfma", seeddelta.FWD_W0_MFMA)):
+            fn = lambda: w.forward_device(x.data_ptr(), n_in, T, y.data_ptr(), n_out, flags=flags, stream=sp)   # noqa: E731
+            ev_ms, host_ms = timed_on_stream(fn, args.prefill_reps, st, seeddelta, warm=3)
+            ms = ev_ms / args.prefill_reps
+            d = {"ms": ms, "ms_host_clock": host_ms / args.prefill_reps, "tok_per_s": T / ms * 1e3,
+                 "hbm": {"achieved": alg / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / ms / 1e6 / HBM_PEAK_GBS},
+                 "residual_valu": {"achieved": 2.0 * K * n_out * T / ms / 1e9, "peak": VALU_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": 2.0 * K * n_out * T / ms / 1e9 / VALU_F32_PEAK_TFLOPS}}
+            if tag == "w0_mfma":
+                fl = 2.0 * n_in * n_out * T
+                d["mfma"] = {"achieved": fl / ms / 1e9, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": fl / ms / 1e9 / MFMA_F16_PEAK_TFLOPS,
+                             "note": "whole call (W0 contraction + residual epilogue) against the dense f16 MFMA peak"}
+            leg[tag] = d
+        if pmc and name in pmc:
+            leg["pmc"] = pmc[name]
+        legs[name] = leg
+        w.close()
+        del x, y
+        torch.cuda.empty_cache()
+    return {"metric": "prefill ubatch (T=512) per tensor, Mistral-7B K=128", "workloads": legs,
+            "timing": "HIP events recorded by the library on the explicit launch stream / reps",
+            "reference_cpu_seconds": {"cfg4_mistral_gate_coo_k128": 1.21, "cfg4_mistral_gate_block16_k128": 0.83,
+                                      "cfg4_mistral_down_coo_k128": 0.35, "cfg4_mistral_down_block16_k128": 0.24,
+                                      "source": "SURVEY.md §8a, compiled reference, 8 threads, build container"}}
 
 
 def scan_cpu_baseline(budget_s):
@@ -305,8 +382,30 @@ def scan_cpu_baseline(budget_s):
                       f"row loop on {cores} threads"}
 
 
+def spawn_ranks(n: int) -> int:
+    """--gpus N without a launcher: start N child ranks (fresh interpreters, one per GPU) BEFORE this process
+    makes any GPU call, pass them the rendezvous through the environment torch.distributed.run would set, wait,
+    and return the worst exit status. Rank 0 prints the JSON line on the shared stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for pr in procs:
+        rc = max(rc, abs(pr.wait()))
+    return rc
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     import torch
     import llama_cpp_amd  # noqa: F401
     from llama_cpp_amd import seeddelta
@@ -356,25 +455,29 @@ def main():
             weights[i].forward_device(xs[i].data_ptr(), n_in, T, ys[i].data_ptr(), n_out, flags=fwd_flags,
                                       stream=stream_ptr)
 
-    steps = max(NP, (args.steps // NP) * NP)
-    warm = max(NP, (args.warmup // NP) * NP)
-    cur = torch.cuda.current_stream()
+    # one step = one rotation over the NP distinct payloads; the driver's --steps / --warmup are taken as given
+    steps = max(1, args.steps)
+    warm = max(0, args.warmup)
+    launches = steps * NP
+    cur = torch.cuda.Stream(device=dev)         # explicit launch stream: kernels, span events and graphs all live on it
+    sp = cur.cuda_stream
+    assert sp != 0
 
     graph = None
     if args.launch == "graph":
-        run_rotation(cur.cuda_stream)           # workspaces + the fused kernel's residency census, outside capture
-        torch.cuda.synchronize()
+        run_rotation(sp)                        # workspaces + the fused kernel's residency census, outside capture
+        cur.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, stream=cur):
             run_rotation(torch.cuda.current_stream().cuda_stream)
 
-    def loop(n_steps):
+    def loop(n_rot):
         if graph is not None:
-            for _ in range(n_steps // NP):
-                graph.replay()
+            with torch.cuda.stream(cur):
+                for _ in range(n_rot):
+                    graph.replay()
         else:
-            sp = cur.cuda_stream
-            for _ in range(n_steps // NP):
+            for _ in range(n_rot):
                 run_rotation(sp)
 
     def barrier():
@@ -382,15 +485,16 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
+    run_rotation(sp)                            # one-time set-up (census) is not a warm-up step
     loop(warm)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     # the timed region is also bracketed by two HIP events recorded by the library on the launch stream
-    seeddelta.profile_span_begin(cur.cuda_stream)
+    seeddelta.profile_span_begin(sp)
     t0 = time.perf_counter()
     loop(steps)
-    span_ms, _ = seeddelta.profile_span_end(cur.cuda_stream)
+    span_ms, _ = seeddelta.profile_span_end(sp)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -401,8 +505,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # roofline of the dominant kernel. Fused decode = ONE kernel per step, so its average launch
-    # duration is the HIP-event span of the timed region / steps (back-to-back launch period; the
+    # roofline of the dominant kernel. Fused decode = ONE kernel per token, so its average launch
+    # duration is the HIP-event span of the timed region / launches (back-to-back launch period; the
     # rocprofv3 kernel-trace average under profiles/ is the cross-check). Two-launch path: the
     # residual kernel is bracketed per launch by the library's event pairs in a second, untimed pass.
     roof = None
@@ -414,17 +518,16 @@ def main():
                 traffic = json.load(fh).get("hbm_bytes_per_launch")
         if fused and graph is not None:
             # events recorded around hipGraphLaunch calls do not bracket the replayed kernels here (measured:
-            # 1.8 us "per step" against 9.3 us on the host clock), so graph mode reports the host clock
-            dur_s, n, how = elapsed / steps, steps, "host clock around the timed region (synchronised) / steps"
+            # 1.8 us "per launch" against 9.3 us on the host clock), so graph mode reports the host clock
+            dur_s, n, how = elapsed / launches, launches, "host clock around the timed region (synchronised) / launches"
             kname = "decode_fused_kernel replayed from a hipGraph (base + residual in one launch)"
         elif fused:
-            dur_s, n, how = span_ms / 1e3 / steps, steps, "HIP events around the timed region / steps"
+            dur_s, n, how = span_ms / 1e3 / launches, launches, "HIP events on the launch stream around the timed region / launches"
             kname = "decode_fused_kernel (base + residual in one launch)" if T == 1 else \
                 "decode_fused_nt_kernel (2-4 tokens in one launch; shapes it does not cover run as two kernels)"
         else:
             seeddelta.profile_enable(True)
-            sp = cur.cuda_stream
-            for _ in range(max(1, min(steps, 4096) // NP)):
+            for _ in range(max(1, min(launches, 4096) // NP)):
                 run_rotation(sp)
             torch.cuda.synchronize()
             ms, n = seeddelta.profile_read()
@@ -464,6 +567,11 @@ def main():
         ffn = run_ffn(args, dev)
         torch.cuda.empty_cache()
 
+    prefill = None
+    if not args.no_prefill and rank == 0 and world == 1:
+        prefill = run_prefill(args, dev)
+        torch.cuda.empty_cache()
+
     scan = None
     if not args.no_scan:
         scan = run_scan(args, rank, world, dev)
@@ -471,14 +579,15 @@ def main():
             scan["cpu_baseline"] = scan_cpu_baseline(args.cpu_seconds)
 
     if rank == 0:
-        value = world * steps * T / elapsed
+        value = world * launches * T / elapsed
         line = {
             "metric": "SeedDelta FFN decode tok/s (Mistral-7B)", "value": value, "unit": "tok/s",
             "n_gpus": world, "steps": steps, "warmup": warm,
             "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "tokens_per_step": T, "n_in": n_in, "n_out": n_out,
-                       "distinct_payloads": NP, "launch": args.launch,
+            "config": {"workload": args.workload, "tokens_per_step": NP * T, "launches_per_step": NP,
+                       "step": "one rotation over the distinct payloads", "tokens_per_launch": T,
+                       "n_in": n_in, "n_out": n_out, "distinct_payloads": NP, "launch": args.launch,
                        "parallelism": "replicas only" if world > 1 else "single GPU"},
             "roofline": roof, "cpu_baseline": cpu,
         }
@@ -486,6 +595,8 @@ def main():
             line["pcie_inclusive"] = host_io
         if ffn is not None:
             line["ffn_block"] = ffn
+        if prefill is not None:
+            line["prefill"] = prefill
         if scan is not None:
             line["scan"] = scan
         print(json.dumps(line), flush=True)

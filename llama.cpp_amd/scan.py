@@ -411,6 +411,26 @@ def shard(cands: Sequence[Candidate], rank: int, world: int, cost: Callable[[Can
     return mine
 
 
+def shard_groups(cands: Sequence[Candidate], rank: int, world: int, cost: Callable[[Candidate], float],
+                 group_key: Optional[Callable[[Candidate], tuple]] = None) -> Tuple[List[Candidate], List[int]]:
+    """The deal the multi-GPU sweep uses: all trials of one (layer, tensor) go to ONE rank — its
+    dense weight is uploaded once and the K grid shares fit, dequant and sort — and the groups are dealt
+    heaviest first to the least-loaded rank (ties -> lowest rank). Every rank computes the same deal without
+    communication. Returns (this rank's candidates in the order of `cands`, candidates per rank)."""
+    key = group_key or (lambda c: (c.layer, KIND_ID[c.kind]))
+    groups: Dict[tuple, List[Candidate]] = {}
+    for c in cands:
+        groups.setdefault(key(c), []).append(c)
+    load, owner = [0.0] * world, {}
+    for g in sorted(groups, key=lambda g: (-sum(cost(c) for c in groups[g]), g)):
+        r = min(range(world), key=lambda i: (load[i], i))
+        load[r] += sum(cost(c) for c in groups[g])
+        owner[g] = r
+    mine = [c for c in cands if owner[key(c)] == rank]
+    counts = [sum(len(groups[g]) for g in groups if owner[g] == r) for r in range(world)]
+    return mine, counts
+
+
 RECORD_LEN = 40
 
 
