@@ -155,6 +155,25 @@ int sdh_forward(sdh_weight * w,
                 float * y, int64_t ldy,
                 int flags, void * stream);
 
+/* sdh_forward_noalloc — sdh_forward for callers that cannot allocate. No counterpart in the reference (its op
+ * is CPU code with thread_local scratch, src/llama-seeddelta.cpp:78-80,1003-1012); it is for callers that may not
+ * call hipMalloc: code under HIP graph capture, tight serving loops, harnesses that forbid allocation. Same
+ * result as sdh_forward(w, ..., flags | SDH_FWD_NO_FUSE, stream), bit for bit, but it calls no hipMalloc, hipFree
+ * or allocating library routine: x and y must be device pointers (SDH_FWD_HOST_IO is rejected, as is
+ * SDH_FWD_W0_MFMA), and the base term that sdh_forward keeps in a per-handle workspace lives in a file-scope
+ * static device array of SDH_NOALLOC_SCRATCH_BYTES (each GPU the library is initialised on holds it until the
+ * process ends). Tokens are processed in chunks that fit; a payload whose single-token base term
+ * (B * L * 4 bytes) exceeds the array is rejected with SDH_ERR_TOO_LARGE. The array is shared by every call on
+ * that GPU and keeps the previous call's contents (nothing in it needs clearing: the base kernel overwrites
+ * every element the residual kernel reads): calls that overlap on one GPU — two streams, two host threads —
+ * race on it; issue them on one stream. */
+#define SDH_NOALLOC_SCRATCH_BYTES (8 * 1024 * 1024)
+int     sdh_forward_noalloc(sdh_weight * w,
+                            const float * x, int64_t ldx, int64_t n_tokens,
+                            float * y, int64_t ldy,
+                            int flags, void * stream);
+int64_t sdh_noalloc_scratch_bytes(void);   /* SDH_NOALLOC_SCRATCH_BYTES of the loaded library */
+
 /* Number of non-finite outputs produced by the most recent sdh_forward on this handle
  * (the reference's llama_seeddelta_nan_count, src/llama-seeddelta.cpp:77,382, per call).
  * Waits for that forward to finish. */

@@ -29,6 +29,17 @@ LibState & lib() {
 
 static std::mutex g_mu;
 
+// ---- sdh_forward_noalloc: the scratch its kernels use instead of a hipMalloc'ed workspace --------------
+// The base term v[T_chunk][B][L] that the base kernel writes and the residual kernel reads. Every GPU the
+// library runs on holds its own copy of this array, at its own address, until the process ends. In host code
+// the array's NAME is only a stand-in: its device address is taken once per device with hipGetSymbolAddress
+// (sdh_init, that device current) and kept in g_scratch_ptr; kernels and hipMemsetAsync only ever see that
+// pointer.
+constexpr size_t NOALLOC_SCRATCH_BYTES = (size_t) SDH_NOALLOC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+constexpr int MAX_DEVICES = 64;
+static void * g_scratch_ptr[MAX_DEVICES] = {};
+
 // Which stream a call runs on. Device I/O: exactly the caller's handle, and NULL is HIP's legacy default
 // stream, as in every HIP API — so work the caller queued on that stream (the producer of x, the consumer
 // of y) is ordered with ours. Host I/O calls are synchronous (copy in, run, copy out, wait) and own their
@@ -195,6 +206,11 @@ int sdh_init(int device) {
     hipDeviceProp_t prop;
     SDH_HIP_CHECK(hipGetDeviceProperties(&prop, device));
     if (!s.stream) SDH_HIP_CHECK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    if (device < MAX_DEVICES && !g_scratch_ptr[device]) {       // this device's copy of `scratch` (device is current)
+        void * ptr = nullptr;
+        SDH_HIP_CHECK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        g_scratch_ptr[device] = ptr;
+    }
     s.num_cu = prop.multiProcessorCount;
     s.device = device;
     s.inited = true;
@@ -480,7 +496,12 @@ static int nf_slot(DeviceWeight * w, hipStream_t s, int * slot_out) {
 }
 
 static int sdh_forward_impl(sdh_weight * h, const float * x, int64_t ldx, int64_t n_tokens,
-                float * y, int64_t ldy, int flags, void * stream) {
+                float * y, int64_t ldy, int flags, void * stream,
+                float * ext_ws = nullptr, size_t ext_ws_bytes = 0) {
+    // ext_ws: the caller-provided base-term workspace of sdh_forward_noalloc; with it this function makes no
+    // allocating call (no workspace growth, no host-I/O staging, no fused launch: its first use allocates the
+    // census counter and waits for the device)
+    const bool noalloc = ext_ws != nullptr;
     if (!h || !x || !y) { set_error("null argument"); return SDH_ERR_INVALID; }
     if (!lib().inited) { set_error("sdh_init not called"); return SDH_ERR_NO_DEVICE; }
     DeviceWeight * w = reinterpret_cast<DeviceWeight *>(h);
@@ -521,7 +542,12 @@ static int sdh_forward_impl(sdh_weight * h, const float * x, int64_t ldx, int64_
     int64_t chunk = n_tokens;
     const size_t per_tok = has_base ? (size_t) w->B * (size_t) w->L * 4 : 0;
     if (has_base) {
-        const size_t cap = (size_t) 512 << 20;
+        const size_t cap = noalloc ? ext_ws_bytes : (size_t) 512 << 20;
+        if (noalloc && per_tok > cap) {
+            set_error("sdh_forward_noalloc: one token's base term needs B*L*4 = %zu bytes, the static scratch holds %zu",
+                      per_tok, cap);
+            return SDH_ERR_TOO_LARGE;
+        }
         if (per_tok * (size_t) chunk > cap) chunk = (int64_t) (cap / per_tok);
         if (chunk < 1) chunk = 1;
     }
@@ -553,7 +579,7 @@ static int sdh_forward_impl(sdh_weight * h, const float * x, int64_t ldx, int64_
         };
 
         // decode with a base, 1..4 tokens: one fused launch when the payload qualifies
-        if (has_base && tc >= 1 && tc <= MAX_FUSED_TOKENS && !(flags & SDH_FWD_NO_FUSE)) {
+        if (has_base && tc >= 1 && tc <= MAX_FUSED_TOKENS && !(flags & SDH_FWD_NO_FUSE) && !noalloc) {
             int pair, rc = prof_begin(pair);
             if (rc != SDH_OK) return rc;
             rc = launch_decode_fused(*w, a, s);
@@ -566,23 +592,26 @@ static int sdh_forward_impl(sdh_weight * h, const float * x, int64_t ldx, int64_
             // rc == 1: not applicable; the opening event is simply re-recorded below
         }
         if (has_base) {
-            int rc = ensure_ws(w, per_tok * (size_t) chunk);
+            int rc = noalloc ? SDH_OK : ensure_ws(w, per_tok * (size_t) chunk);
             if (rc != SDH_OK) return rc;
+            float * const ws = noalloc ? ext_ws : w->ws;
             rc = 1;
             if ((flags & SDH_FWD_W0_MFMA) && !a.exact_order) {
-                rc = launch_w0_mfma(*w, xc, dldx, tc, w->ws, s);
+                rc = launch_w0_mfma(*w, xc, dldx, tc, ws, s);
                 if (rc == SDH_OK && !w->tall) a.v_blocks = 1;
             }
-            if (rc == 1) rc = launch_base_apply(*w, xc, dldx, tc, w->ws, s);
+            if (rc == 1) rc = launch_base_apply(*w, xc, dldx, tc, ws, s);
             if (rc != SDH_OK) return rc;
-            a.v = w->ws;
+            a.v = ws;
         }
         int pair, rc = prof_begin(pair);
         if (rc != SDH_OK) return rc;
         // many tokens: token-tiled sparse x dense product (bit-exact order); few: per-token row kernels
         static const int64_t spmm_min_t = [] { const char * e = getenv("SDH_SPMM_MIN_T"); return e ? (int64_t) atoll(e) : (int64_t) 8; }();
         rc = 1;
-        if (tc >= spmm_min_t && !a.exact_order && !(flags & SDH_FWD_NO_SPMM)) rc = launch_delta_spmm(*w, a, s);
+        // the choice follows the CALL's token count, not the chunk's: a short last chunk must not switch a call to
+        // the per-token kernels (same values within tolerance, but not the same bits as its other chunks)
+        if (n_tokens >= spmm_min_t && !a.exact_order && !(flags & SDH_FWD_NO_SPMM)) rc = launch_delta_spmm(*w, a, s);
         if (rc == 1) rc = launch_delta(*w, a, s);
         if (rc != SDH_OK) return rc;
         rc = prof_end(pair);
@@ -855,6 +884,28 @@ int sdh_forward(sdh_weight * h, const float * x, int64_t ldx, int64_t n_tokens,
                 float * y, int64_t ldy, int flags, void * stream) {
     SDH_NO_THROW(sdh_forward_impl(h, x, ldx, n_tokens, y, ldy, flags, stream));
 }
+
+// No hipMalloc / hipFree / allocating routine on this path: device I/O only, the base term goes through the
+// static `scratch` array (this device's address of it, g_scratch_ptr), tokens are processed in chunks that fit it.
+static int sdh_forward_noalloc_impl(sdh_weight * h, const float * x, int64_t ldx, int64_t n_tokens,
+                                    float * y, int64_t ldy, int flags, void * stream) {
+    if (!lib().inited) { set_error("sdh_init not called"); return SDH_ERR_NO_DEVICE; }
+    if (flags & (SDH_FWD_HOST_IO | SDH_FWD_W0_MFMA)) {
+        set_error("sdh_forward_noalloc: device pointers only, FWHT base only (flags 0x%x)", flags);
+        return SDH_ERR_INVALID;
+    }
+    const int dev = lib().device;
+    if (dev < 0 || dev >= MAX_DEVICES || !g_scratch_ptr[dev]) { set_error("sdh_forward_noalloc: no scratch on device %d", dev); return SDH_ERR_NO_DEVICE; }
+    return sdh_forward_impl(h, x, ldx, n_tokens, y, ldy, flags, stream,
+                            reinterpret_cast<float *>(g_scratch_ptr[dev]), NOALLOC_SCRATCH_BYTES);
+}
+
+int sdh_forward_noalloc(sdh_weight * h, const float * x, int64_t ldx, int64_t n_tokens,
+                        float * y, int64_t ldy, int flags, void * stream) {
+    SDH_NO_THROW(sdh_forward_noalloc_impl(h, x, ldx, n_tokens, y, ldy, flags, stream));
+}
+
+int64_t sdh_noalloc_scratch_bytes(void) { return (int64_t) NOALLOC_SCRATCH_BYTES; }
 
 int sdh_ffn_gate_up(sdh_weight * hg, sdh_weight * hu, int act, const float * x, int64_t ldx, int64_t n_tokens,
                     float * h, int64_t ldh, int flags, void * stream) {

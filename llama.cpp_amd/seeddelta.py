@@ -32,7 +32,7 @@ FWD_DEVICE_IO, FWD_HOST_IO, FWD_ZERO_NONFINITE, FWD_EXACT_ORDER, FWD_W0_MFMA, FW
 ABI_SYMBOLS = [
     "sdh_init", "sdh_abi_version", "sdh_last_error", "sdh_device_synchronize", "sdh_library_stream",
     "sdh_weight_create", "sdh_weight_destroy", "sdh_weight_op_kind", "sdh_weight_payload_bytes",
-    "sdh_forward", "sdh_nonfinite_count", "sdh_w0_tile", "sdh_ffn_forward", "sdh_ffn_gate_up", "sdh_ffn_last_fused", "sdh_glu",
+    "sdh_forward", "sdh_forward_noalloc", "sdh_noalloc_scratch_bytes", "sdh_nonfinite_count", "sdh_w0_tile", "sdh_ffn_forward", "sdh_ffn_gate_up", "sdh_ffn_last_fused", "sdh_glu",
     "sdh_profile_enable", "sdh_profile_read", "sdh_profile_span_begin", "sdh_profile_span_end",
     "sdh_dense_create", "sdh_dense_destroy", "sdh_dense_bytes",
     "sdh_scan_create", "sdh_scan_destroy", "sdh_scan_reseed", "sdh_scan_tensor", "sdh_scan_skip", "sdh_scan_fetch", "sdh_scan_fetch_packed", "sdh_scan_memo_clear", "sdh_imatrix_scale",
@@ -120,6 +120,8 @@ def load_library(path: str = LIB_PATH):
     lib.sdh_weight_payload_bytes.restype = C.c_int64
     lib.sdh_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
                                 C.c_int, C.c_void_p]
+    lib.sdh_forward_noalloc.argtypes = lib.sdh_forward.argtypes
+    lib.sdh_noalloc_scratch_bytes.restype = C.c_int64
     lib.sdh_ffn_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64,
                                     C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
     lib.sdh_ffn_gate_up.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64,
@@ -249,6 +251,12 @@ class SeedDeltaWeight:
         rc = load_library().sdh_forward(self._h, x_ptr, ldx, T, y_ptr, ldy, flags & ~FWD_HOST_IO,
                                         C.c_void_p(stream) if stream else None)
         _check(rc, "sdh_forward")
+
+    def forward_device_noalloc(self, x_ptr: int, ldx: int, T: int, y_ptr: int, ldy: int,
+                               flags: int = 0, stream: int = 0) -> int:
+        """sdh_forward_noalloc; returns the status code (0, or SDH_ERR_TOO_LARGE = -5 ...) instead of raising."""
+        return int(load_library().sdh_forward_noalloc(self._h, x_ptr, ldx, T, y_ptr, ldy, flags,
+                                                      C.c_void_p(stream) if stream else None))
 
     def nonfinite_count(self) -> int:
         n = load_library().sdh_nonfinite_count(self._h)
