@@ -221,6 +221,29 @@ int sdh_ffn_last_fused(void);
  * ggml_swiglu_split / ggml_geglu_split on F32, ggml/src/ggml-cpu/vec.cpp:416, vec.h:1430). */
 int sdh_glu(int act, const float * g, const float * u, float * y, int64_t n, void * stream);
 
+/* ---- a stack of gated FFN blocks in ONE launch (decode, one token) -----------------------------------------
+ * y = FFN_{n-1}( ... FFN_1( FFN_0(x) ) ),  FFN_l(v) = down_l( act(gate_l(v)) * up_l(v) ): the node sequence of
+ * build_ffn (src/llama-graph.cpp:826-932) for n_layers consecutive blocks, evaluated by one persistent grid that
+ * hands its intermediate vectors from phase to phase on the device (no launch per tensor, no launch per layer;
+ * DESIGN.md §3 "FFN stack"). With n_layers = 1 it is sdh_ffn_forward at one token as a single launch. It is the
+ * decode form for runs of SeedDelta layers whose blocks follow one another directly, and the vehicle of
+ * bench.py's `ffn_stack` leg; a model with attention between its FFN blocks calls it with n_layers = 1 per layer.
+ * Results are bit-identical to the same layers evaluated one by one with sdh_ffn_forward on the fast path.
+ * All layers must share one shape: tall gate/up [n_embd -> n_ff], wide down, base present with L in {1024, 2048,
+ * 4096} and at most 4 blocks, I16/F16 payload with K (or nb*block) a multiple of 8 up to 1024, one scheme;
+ * otherwise create returns SDH_ERR_UNSUPPORTED and the caller evaluates layer by layer. x, y: device pointers,
+ * n_embd floats. The handles must outlive the stack. One call at a time per stack (it owns its hand-off buffers);
+ * not capturable into a HIP graph (SDH_ERR_UNSUPPORTED on a capturing stream). sdh_ffn_stack_status waits for the
+ * last call and returns the number of non-finite node outputs (counted and, with SDH_FWD_ZERO_NONFINITE, zeroed per
+ * node as in sdh_ffn_forward) and of hand-off waits that timed out (0 unless the grid could not run concurrently). */
+typedef struct sdh_ffn_stack sdh_ffn_stack;
+int     sdh_ffn_stack_create(sdh_weight * const * gate, sdh_weight * const * up, sdh_weight * const * down, int n_layers,
+                             sdh_ffn_stack ** out);
+void    sdh_ffn_stack_destroy(sdh_ffn_stack * s);
+int     sdh_ffn_stack_forward(sdh_ffn_stack * s, int act, const float * x, float * y, int flags, void * stream);
+int     sdh_ffn_stack_status(sdh_ffn_stack * s, int64_t * nonfinite, int64_t * timeouts);
+int64_t sdh_ffn_stack_payload_bytes(const sdh_ffn_stack * s);
+
 /* Regenerate a tile of the dense base W0 (bit-exact integer XOR indexing into the per-block
  * table G_b = FWHT(d2_b)): out[(o-o0) + (i-i0)*(o1-o0)] = W0[o,i] for o in [o0,o1), i in [i0,i1).
  * `out` is a device or host pointer according to `flags` (SDH_FWD_HOST_IO). Used by the

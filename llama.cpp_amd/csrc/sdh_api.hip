@@ -782,6 +782,46 @@ static int sdh_ffn_forward_impl(sdh_weight * hg, sdh_weight * hu, sdh_weight * h
     return SDH_OK;
 }
 
+// ---- persistent FFN stack ---------------------------------------------------------------------------------------
+int sdh_ffn_stack_create(sdh_weight * const * gate, sdh_weight * const * up, sdh_weight * const * down, int n_layers,
+                         sdh_ffn_stack ** out) {
+    if (!gate || !up || !down || !out) { set_error("null argument"); return SDH_ERR_INVALID; }
+    *out = nullptr;
+    if (!lib().inited) { set_error("sdh_init not called"); return SDH_ERR_NO_DEVICE; }
+    FfnStack * st = nullptr;
+    auto run = [&]() -> int { return stack_create(gate, up, down, n_layers, &st); };
+    int rc;
+    try { rc = run(); } catch (...) { set_error("internal error"); return SDH_ERR_HIP; }
+    if (rc == SDH_OK) *out = reinterpret_cast<sdh_ffn_stack *>(st);
+    return rc;
+}
+
+void sdh_ffn_stack_destroy(sdh_ffn_stack * h) {
+    if (!h) return;
+    (void) hipDeviceSynchronize();
+    stack_free(reinterpret_cast<FfnStack *>(h));
+}
+
+int sdh_ffn_stack_forward(sdh_ffn_stack * h, int act, const float * x, float * y, int flags, void * stream) {
+    if (!h || !x || !y) { set_error("null argument"); return SDH_ERR_INVALID; }
+    LibState & ls = lib();
+    if (!ls.inited) { set_error("sdh_init not called"); return SDH_ERR_NO_DEVICE; }
+    if (act != SDH_ACT_SILU && act != SDH_ACT_GELU) { set_error("unknown activation %d", act); return SDH_ERR_INVALID; }
+    if (flags & ~SDH_FWD_ZERO_NONFINITE) { set_error("sdh_ffn_stack_forward: device pointers, fast path only (flags 0x%x)", flags); return SDH_ERR_INVALID; }
+    if (act == SDH_ACT_GELU) { int rc = ensure_gelu_table(ls); if (rc != SDH_OK) return rc; }
+    return stack_forward(reinterpret_cast<FfnStack *>(h), act, ls.gelu_tab, x, y, (flags & SDH_FWD_ZERO_NONFINITE) != 0, (hipStream_t) stream);
+}
+
+int sdh_ffn_stack_status(sdh_ffn_stack * h, int64_t * nonfinite, int64_t * timeouts) {
+    if (!h) { set_error("null argument"); return SDH_ERR_INVALID; }
+    return stack_status(reinterpret_cast<FfnStack *>(h), nonfinite, timeouts);
+}
+
+int64_t sdh_ffn_stack_payload_bytes(const sdh_ffn_stack * h) {
+    if (!h) { set_error("null argument"); return SDH_ERR_INVALID; }
+    return stack_bytes(reinterpret_cast<const FfnStack *>(h));
+}
+
 int64_t sdh_nonfinite_count(sdh_weight * h) {
     if (!h) { set_error("null weight"); return SDH_ERR_INVALID; }
     DeviceWeight * w = reinterpret_cast<DeviceWeight *>(h);

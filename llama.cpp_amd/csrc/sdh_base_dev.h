@@ -261,6 +261,78 @@ __device__ __forceinline__ void base_transform(const float * __restrict__ xt, in
     }
 }
 
+// ---- the same transform with its inputs already in registers (persistent FFN stack, sdh_stack.hip) -------
+// There a base workgroup runs one transform per layer: the block's parameters are requested BEFORE the
+// activations exist (they are handed over by other workgroups), then the activations arrive in registers.
+// BasePrm holds what base_transform loads up front; base_transform_core is the rest of base_transform,
+// operation for operation (so the result is bit-identical to it).
+template <class Ly>
+struct BasePrm {
+    float s1[Ly::E], s2[Ly::E], s3[Ly::E];
+    int   g1[Ly::E], g2[Ly::E];
+};
+
+template <class Ly, bool P32>
+__device__ __forceinline__ void base_prm_load(BasePrm<Ly> & q, const BasePackDesc & pd, int b, int tid) {
+    constexpr int E = Ly::E, JL = Ly::J - 1;
+    const uint8_t * pk = pd.pack + (size_t) b * pd.blk_stride;
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        q.g1[r] = pd.off_p1 >= 0 ? base_param_i<P32>(pk + pd.off_p1, E * tid + r) : 0;
+        q.g2[r] = pd.off_p2 >= 0 ? base_param_i<P32>(pk + pd.off_p2, E * tid + r) : 0;
+        q.s1[r] = pd.off_d1 >= 0 ? base_param_f<P32>(pk + pd.off_d1, E * tid + r) : 1.0f;
+        q.s2[r] = pd.off_d2 >= 0 ? base_param_f<P32>(pk + pd.off_d2, Ly::idx(JL, tid, r)) : 1.0f;
+        q.s3[r] = pd.off_d3 >= 0 ? base_param_f<P32>(pk + pd.off_d3, Ly::idx(JL, tid, r)) : 1.0f;
+    }
+}
+
+// y: the block's input in layout 0 (thread tid holds elements [E*tid, E*tid + E), zero past the end of x).
+// On return y[r] holds output element idx(J-1, tid, r). lds: L floats (one buffer).
+template <class Ly>
+__device__ __forceinline__ void base_transform_core(float (&y)[Ly::E], const BasePrm<Ly> & q, const BasePackDesc & pd,
+                                                    float * lds, int tid) {
+#pragma clang fp contract(off)
+    constexpr int E = Ly::E, JL = Ly::J - 1;
+    const bool has_p1 = pd.off_p1 >= 0, has_d2 = pd.off_d2 >= 0, has_d1 = pd.off_d1 >= 0,
+               has_d3 = pd.off_d3 >= 0, has_p2 = pd.off_p2 >= 0;
+    if (has_d1) {
+#pragma unroll
+        for (int r = 0; r < E; ++r) y[r] = y[r] * q.s1[r];
+    }
+    if (has_p1) {
+        base_lds_write<Ly, 0>(lds, y, tid);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < E; ++r) y[r] = lds[Ly::phys(q.g1[r])];
+    }
+    base_fwht<Ly, 0, true>(y, lds, lds, tid);
+    if (!has_d2 && !has_p2) {                                // depth 1 (:537-544)
+        if (has_d3) {
+#pragma unroll
+            for (int r = 0; r < E; ++r) y[r] = y[r] * q.s3[r];
+        }
+        return;
+    }
+    if (has_d2) {
+#pragma unroll
+        for (int r = 0; r < E; ++r) y[r] = y[r] * q.s2[r];
+    }
+    __syncthreads();
+    base_lds_write<Ly, JL>(lds, y, tid);
+    __syncthreads();
+    if (has_p2) {
+#pragma unroll
+        for (int r = 0; r < E; ++r) y[r] = lds[Ly::phys(q.g2[r])];
+    } else {
+        base_lds_read<Ly, 0>(y, lds, tid);
+    }
+    base_fwht<Ly, (Ly::J & 1), true>(y, lds, lds, tid);
+    if (has_d3) {
+#pragma unroll
+        for (int r = 0; r < E; ++r) y[r] = y[r] * q.s3[r];
+    }
+}
+
 // Re-order a finished block from the last layout to layout 0 (E consecutive elements per thread,
 // thread t holding [E*t, E*t+E)) through a single LDS buffer that may still be in use: a barrier
 // first, then write, barrier, read.

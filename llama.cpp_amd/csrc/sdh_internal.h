@@ -149,6 +149,15 @@ int launch_decode_pair(DeviceWeight & g, DeviceWeight & u, int act, const uint16
                        const float * x, float * h, int * nf_g, int * nf_u, bool zero_nonfinite, hipStream_t s);
 int launch_glu(int act, const uint16_t * gelu_tab, const float * g, const float * u, float * y, int64_t n, hipStream_t s);
 
+// Persistent FFN stack (sdh_stack.hip): n_layers gated FFN blocks at T = 1 in one launch.
+struct FfnStack;
+int  stack_create(const sdh_weight * const * gate, const sdh_weight * const * up, const sdh_weight * const * down, int n_layers, FfnStack ** out);
+void stack_free(FfnStack * st);
+int  stack_forward(FfnStack * st, int act, const uint16_t * gelu_tab, const float * x, float * y, bool zero_nf, hipStream_t s);
+int  stack_status(FfnStack * st, int64_t * nonfinite, int64_t * timeouts);
+int  stack_layers(const FfnStack * st);
+int64_t stack_bytes(const FfnStack * st);
+
 int launch_w0_tile(const DeviceWeight & w, int64_t o0, int64_t o1, int64_t i0, int64_t i1,
                    float * out_dev, hipStream_t s);
 

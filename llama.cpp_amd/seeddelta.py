@@ -33,6 +33,7 @@ ABI_SYMBOLS = [
     "sdh_init", "sdh_abi_version", "sdh_last_error", "sdh_device_synchronize", "sdh_library_stream",
     "sdh_weight_create", "sdh_weight_destroy", "sdh_weight_op_kind", "sdh_weight_payload_bytes",
     "sdh_forward", "sdh_forward_noalloc", "sdh_noalloc_scratch_bytes", "sdh_nonfinite_count", "sdh_w0_tile", "sdh_ffn_forward", "sdh_ffn_gate_up", "sdh_ffn_last_fused", "sdh_glu",
+    "sdh_ffn_stack_create", "sdh_ffn_stack_destroy", "sdh_ffn_stack_forward", "sdh_ffn_stack_status", "sdh_ffn_stack_payload_bytes",
     "sdh_profile_enable", "sdh_profile_read", "sdh_profile_span_begin", "sdh_profile_span_end",
     "sdh_dense_create", "sdh_dense_destroy", "sdh_dense_bytes",
     "sdh_scan_create", "sdh_scan_destroy", "sdh_scan_reseed", "sdh_scan_tensor", "sdh_scan_skip", "sdh_scan_fetch", "sdh_scan_fetch_packed", "sdh_scan_memo_clear", "sdh_imatrix_scale",
@@ -126,6 +127,13 @@ def load_library(path: str = LIB_PATH):
                                     C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
     lib.sdh_ffn_gate_up.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64,
                                     C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+    lib.sdh_ffn_stack_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]
+    lib.sdh_ffn_stack_destroy.argtypes = [C.c_void_p]
+    lib.sdh_ffn_stack_destroy.restype = None
+    lib.sdh_ffn_stack_forward.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.sdh_ffn_stack_status.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.sdh_ffn_stack_payload_bytes.argtypes = [C.c_void_p]
+    lib.sdh_ffn_stack_payload_bytes.restype = C.c_int64
     lib.sdh_glu.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.sdh_nonfinite_count.argtypes = [C.c_void_p]
     lib.sdh_nonfinite_count.restype = C.c_int64
@@ -308,6 +316,44 @@ def ffn_forward_device(gate: SeedDeltaWeight, up: SeedDeltaWeight, down: SeedDel
     rc = load_library().sdh_ffn_forward(gate._h, up._h, down._h, act, x_ptr, ldx, T, y_ptr, ldy,
                                         flags & ~FWD_HOST_IO, C.c_void_p(stream) if stream else None)
     _check(rc, "sdh_ffn_forward")
+
+
+class FfnStack:
+    """n gated FFN blocks evaluated by one persistent launch at T = 1 (sdh_ffn_stack_*). `layers` is a list of
+    (gate, up, down) SeedDeltaWeight triples, kept alive by this object. Raises SeedDeltaError with status -4
+    (SDH_ERR_UNSUPPORTED) in the text when the layers do not have the shape the kernel is built for."""
+
+    def __init__(self, layers):
+        lib = load_library()
+        self.layers = [tuple(t) for t in layers]
+        n = len(self.layers)
+        arrs = [(C.c_void_p * n)(*[t[k]._h for t in self.layers]) for k in range(3)]
+        h = C.c_void_p()
+        _check(lib.sdh_ffn_stack_create(arrs[0], arrs[1], arrs[2], n, C.byref(h)), "sdh_ffn_stack_create")
+        self._h = h
+        self.n_layers = n
+        self.payload_bytes = lib.sdh_ffn_stack_payload_bytes(h)
+
+    def forward_device(self, act: int, x_ptr: int, y_ptr: int, flags: int = 0, stream: int = 0):
+        _check(load_library().sdh_ffn_stack_forward(self._h, act, x_ptr, y_ptr, flags, C.c_void_p(stream) if stream else None),
+               "sdh_ffn_stack_forward")
+
+    def status(self):
+        """-> (non-finite node outputs of the last call, hand-off timeouts so far); waits for the last call."""
+        nf, to = C.c_int64(0), C.c_int64(0)
+        _check(load_library().sdh_ffn_stack_status(self._h, C.byref(nf), C.byref(to)), "sdh_ffn_stack_status")
+        return nf.value, to.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().sdh_ffn_stack_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def ffn_last_fused() -> bool:
