@@ -56,6 +56,9 @@ def parse_args():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-scan", action="store_true", help="skip the scan (candidates/s) leg")
     ap.add_argument("--no-ffn", action="store_true", help="skip the gated-FFN-block leg")
+    ap.add_argument("--no-stack", action="store_true", help="skip the persistent FFN-stack leg")
+    ap.add_argument("--stack-layers", type=int, default=32)
+    ap.add_argument("--stack-reps", type=int, default=40)
     ap.add_argument("--no-prefill", action="store_true", help="skip the prefill (T=512) leg")
     ap.add_argument("--prefill-reps", type=int, default=20)
     ap.add_argument("--ffn-layers", type=int, default=16, help="distinct synthetic Mistral-7B layers rotated in the FFN-block leg")
@@ -294,6 +297,83 @@ def run_ffn(args, dev):
     # the event span can only be shorter than the host clock by the enqueue lead; a large gap means mis-timing
     out["timing_consistent"] = bool(us_block <= out["us_per_layer_host_clock"] * 1.02 and us_block >= 0.80 * out["us_per_layer_host_clock"])
     return out
+
+
+def run_ffn_stack(args, dev):
+    """FFN stack leg: 32 distinct synthetic Mistral-7B layers (gate, up 4096->14336, down
+    14336->4096, COO K=128 + base, SiLU), x_{l+1} = FFN_l(x_l), evaluated by ONE persistent launch per token
+    (sdh_ffn_stack_forward). 32 layers x 17.46 MB = 559 MB of payload per token: more than twice the 256 MB
+    Infinity Cache, so every layer streams from HBM on every call. Launched and timed on one explicit stream."""
+    import torch
+    from llama_cpp_amd import seeddelta
+    from llama_cpp_amd.payload import make_payload
+    NL = max(1, args.stack_layers)
+    n_embd, n_ff, K = 4096, 14336, 128
+    layers, alg = [], 0
+    # A chain of random layers has no norm between its blocks (a model has one), so each layer's down row_scale is
+    # rescaled by one scalar that brings |x_{l+1}|_rms back to 1: activations stay O(1) through all layers (a chain
+    # that overflows would measure the non-finite counter's atomics, one that decays would measure zeros).
+    import numpy as _np
+    xh = _np.random.default_rng(77).standard_normal((1, n_embd)).astype(_np.float32)
+    x0 = xh.copy()
+    for i in range(NL):
+        pg = make_payload(n_embd, n_ff, scheme="coo", K=K, base=True, seed=9000 + 3 * i)
+        pu = make_payload(n_embd, n_ff, scheme="coo", K=K, base=True, seed=9001 + 3 * i)
+        pd = make_payload(n_ff, n_embd, scheme="coo", K=K, base=True, seed=9002 + 3 * i)
+        wg, wu = seeddelta.SeedDeltaWeight(pg), seeddelta.SeedDeltaWeight(pu)
+        h = seeddelta.ffn_gate_up_host(wg, wu, xh, seeddelta.ACT_SILU)
+        wd0 = seeddelta.SeedDeltaWeight(pd)
+        y0 = wd0.forward_host(h)
+        wd0.close()
+        c = 1.0 / max(float(_np.sqrt(_np.mean(y0.astype(_np.float64) ** 2))), 1e-20)
+        pd.row_scale = (pd.row_scale.astype(_np.float32) * _np.float32(c)).astype(_np.float16)
+        wd = seeddelta.SeedDeltaWeight(pd)
+        xh = wd.forward_host(h)
+        alg = sum(p.algorithmic_bytes(1) for p in (pg, pu, pd))
+        layers.append((wg, wu, wd))
+        del pg, pu, pd
+    stack = seeddelta.FfnStack(layers)
+    x = torch.from_numpy(x0).to(dev)
+    y = torch.empty((1, n_embd), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    st = torch.cuda.Stream(device=dev)
+    sp = st.cuda_stream
+
+    def call():
+        stack.forward_device(seeddelta.ACT_SILU, x.data_ptr(), y.data_ptr(), 0, sp)
+
+    reps = max(4, args.stack_reps)
+    ev_ms, host_ms = timed_on_stream(call, reps, st, seeddelta, warm=3)
+    nf, timeouts = stack.status()
+    y_rms = float(torch.sqrt(torch.mean(y.double() ** 2)).item())
+    us_layer = ev_ms * 1e3 / (reps * NL)
+    # the same layers one sdh_ffn_forward per layer (two launches per layer), for the speed-up
+    a, b = x.clone(), torch.empty_like(x)
+
+    def per_layer():
+        for wg, wu, wd in layers:
+            seeddelta.ffn_forward_device(wg, wu, wd, seeddelta.ACT_SILU, a.data_ptr(), n_embd, 1, b.data_ptr(), n_embd, 0, sp)
+
+    ev2, _ = timed_on_stream(per_layer, max(2, reps // 4), st, seeddelta, warm=1)
+    us_layer_launches = ev2 * 1e3 / (max(2, reps // 4) * NL)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_ffn_stack_mistral_coo_k128.json")
+    if os.path.exists(tpath):
+        with open(tpath) as fh:
+            traffic = json.load(fh).get("hbm_bytes_per_layer")
+    stack.close()
+    for t in layers:
+        for w in t:
+            w.close()
+    return {"metric": "FFN stack decode, layers/s (Mistral-7B layers, COO K=128 + base, SiLU, T=1, one persistent launch per token)",
+            "value": 1e6 / us_layer, "unit": "layers/s", "us_per_layer": us_layer,
+            "us_per_layer_host_clock": host_ms * 1e3 / (reps * NL), "us_per_token_%d_layers" % NL: us_layer * NL,
+            "us_per_layer_two_launches_per_layer": us_layer_launches, "speedup_vs_launches": us_layer_launches / us_layer,
+            "layers": NL, "calls_timed": reps, "algorithmic_bytes_per_layer": alg, "nonfinite": nf, "handoff_timeouts": timeouts, "output_rms": y_rms,
+            "timing": "HIP events recorded by the library on the explicit launch stream / (calls x layers); host clock beside it",
+            "roofline": {"bound": "hbm", "achieved": alg / us_layer / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / us_layer / 1e3 / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "ffn_stack_kernel (one launch walks all layers)"}}
 
 
 PREFILL_WORKLOADS = ("cfg4_mistral_gate_coo_k128", "cfg4_mistral_gate_block16_k128",
@@ -567,6 +647,11 @@ def main():
         ffn = run_ffn(args, dev)
         torch.cuda.empty_cache()
 
+    stack = None
+    if not args.no_stack and rank == 0 and world == 1:
+        stack = run_ffn_stack(args, dev)
+        torch.cuda.empty_cache()
+
     prefill = None
     if not args.no_prefill and rank == 0 and world == 1:
         prefill = run_prefill(args, dev)
@@ -595,6 +680,8 @@ def main():
             line["pcie_inclusive"] = host_io
         if ffn is not None:
             line["ffn_block"] = ffn
+        if stack is not None:
+            line["ffn_stack"] = stack
         if prefill is not None:
             line["prefill"] = prefill
         if scan is not None:

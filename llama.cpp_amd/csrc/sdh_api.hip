@@ -817,6 +817,12 @@ int sdh_ffn_stack_status(sdh_ffn_stack * h, int64_t * nonfinite, int64_t * timeo
     return stack_status(reinterpret_cast<FfnStack *>(h), nonfinite, timeouts);
 }
 
+// diagnostic builds only (-DSDH_STK_STAMPS fills the buffer): not declared in the public header
+int sdh_ffn_stack_debug_stamps(sdh_ffn_stack * h, unsigned long long * out) {
+    if (!h || !out) return SDH_ERR_INVALID;
+    return stack_stamps(reinterpret_cast<FfnStack *>(h), out);
+}
+
 int64_t sdh_ffn_stack_payload_bytes(const sdh_ffn_stack * h) {
     if (!h) { set_error("null argument"); return SDH_ERR_INVALID; }
     return stack_bytes(reinterpret_cast<const FfnStack *>(h));

@@ -38,6 +38,10 @@ __device__ unsigned long long * sdh_diag_buf;
 #define SDH_DIAG_VAL(k, v) do { } while (0)
 #endif
 
+#ifndef SDH_CORE_STAMP
+#define SDH_CORE_STAMP(k) do { } while (0)
+#endif
+
 namespace sdh {
 
 template <int LOG_E_, int TB_ = 8>
@@ -157,6 +161,107 @@ __device__ __forceinline__ void base_fwht(float (&y)[Ly::E], float * lds0, float
     }
 }
 
+// ---- FWHT with the lane bits done across lanes (no LDS transposes for them) ------------------------------------
+// In layout 0 the index bits are [0, LOG_E) = register, [LOG_E, LOG_E + 6) = lane, the rest = wave. A butterfly
+// stage on a lane bit k pairs lane with lane ^ (1 << k): the lane whose bit is clear takes own + partner, the one
+// whose bit is set takes partner - own = partner + (-own): ONE add per element after a cross-lane move and a sign
+// flip, the same IEEE additions as the butterfly (u + v, u - v), so the result stays bit-identical and the STAGE
+// ORDER (bit 0 first) is kept. Moves: DPP quad_perm for xor 1 / 2, two DPP mirrors for xor 4 / 8 (row_half_mirror is
+// xor 7 within 8 lanes, row_mirror xor 15 within 16: composed with the xor 3 / xor 7 permutation they give xor 4 /
+// xor 8), ds_swizzle for xor 16, ds_bpermute for xor 32. Only the wave bits need LDS: one transpose from layout 0
+// straight to the last layout, whose register bits [N - LOG_E, N) cover them. One barrier per transform instead of
+// six, 2 E LDS accesses per thread instead of 6 E, none of them bank-conflicted. Measured: DESIGN.md §3.
+template <int K>
+__device__ __forceinline__ float base_lane_xor(float v) {
+    const int i = __float_as_int(v);
+    if constexpr (K == 0) return __int_as_float(__builtin_amdgcn_update_dpp(i, i, 0xB1, 0xF, 0xF, false));          // quad_perm [1,0,3,2]
+    else if constexpr (K == 1) return __int_as_float(__builtin_amdgcn_update_dpp(i, i, 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
+#ifdef SDH_BASE_XOR48_DPP
+    else if constexpr (K == 2) {
+        const int t = __builtin_amdgcn_update_dpp(i, i, 0x141, 0xF, 0xF, false);                                    // row_half_mirror: xor 7
+        return __int_as_float(__builtin_amdgcn_update_dpp(t, t, 0x1B, 0xF, 0xF, false));                            // quad_perm [3,2,1,0]: xor 3
+    } else if constexpr (K == 3) {
+        const int t = __builtin_amdgcn_update_dpp(i, i, 0x140, 0xF, 0xF, false);                                    // row_mirror: xor 15
+        return __int_as_float(__builtin_amdgcn_update_dpp(t, t, 0x141, 0xF, 0xF, false));                           // row_half_mirror: xor 7
+    }
+#else
+    // xor 4 / 8 / 16 through the LDS crossbar (ds_swizzle, bit mode: and 0x1F, xor mask << 10): the transform is
+    // VALU-issue bound (two waves per SIMD), two DPP moves per element cost more than one DS instruction
+    else if constexpr (K == 2) return __int_as_float(__builtin_amdgcn_ds_swizzle(i, 0x101F));
+    else if constexpr (K == 3) return __int_as_float(__builtin_amdgcn_ds_swizzle(i, 0x201F));
+#endif
+    else if constexpr (K == 4) return __int_as_float(__builtin_amdgcn_ds_swizzle(i, 0x401F));
+    else return __shfl_xor(v, 32, 64);
+}
+
+// One stage on lane bit K: y = partner + sgn * y with sgn = +1 (bit clear) / -1 (bit set): partner - y is the fused
+// multiply-add partner + (-1 * y), exact product, ONE rounding — the butterfly's own addition. Two elements per
+// v_pk_fma_f32.
+template <class Ly, int K>
+__device__ __forceinline__ void base_lane_stage(float (&y)[Ly::E], int lane) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const float sg = ((lane >> K) & 1) ? -1.0f : 1.0f;
+    const f32x2 sgn = {sg, sg};
+    float partner[Ly::E];
+#pragma unroll
+    for (int r = 0; r < Ly::E; ++r) partner[r] = base_lane_xor<K>(y[r]);
+#pragma unroll
+    for (int r = 0; r < Ly::E; r += 2) {
+        const f32x2 a = {y[r], y[r + 1]};
+        const f32x2 p = {partner[r], partner[r + 1]};
+        const f32x2 o = __builtin_elementwise_fma(a, sgn, p);
+        y[r] = o.x; y[r + 1] = o.y;
+    }
+}
+
+// Block in layout 0 -> transformed block in layout J-1. `buf`: L floats that no thread is still reading (or
+// PRE_BARRIER: a barrier separates their last readers from the write).
+template <class Ly, bool PRE_BARRIER>
+__device__ __forceinline__ void base_fwht_x(float (&y)[Ly::E], float * buf, int tid) {
+#pragma clang fp contract(off)
+    constexpr int E = Ly::E, LOG_E = Ly::LOG_E, N = Ly::N, JL = Ly::J - 1;
+    static_assert(Ly::TB >= 6 && Ly::TB - 6 <= LOG_E && N > LOG_E, "wave bits must fit the last layout's register bits");
+    base_stages<Ly, 0>(y);                                   // bits [0, LOG_E)
+    const int lane = tid & 63;
+    base_lane_stage<Ly, 0>(y, lane);                         // bits LOG_E .. LOG_E + 5
+    base_lane_stage<Ly, 1>(y, lane);
+    base_lane_stage<Ly, 2>(y, lane);
+    base_lane_stage<Ly, 3>(y, lane);
+    base_lane_stage<Ly, 4>(y, lane);
+    base_lane_stage<Ly, 5>(y, lane);
+    if constexpr (PRE_BARRIER) __syncthreads();
+    base_lds_write<Ly, 0>(buf, y, tid);
+    __syncthreads();
+    base_lds_read<Ly, JL>(y, buf, tid);
+    if constexpr (Ly::TB > 6) {                              // wave bits [LOG_E + 6, N) = register bits of the last layout
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int bit = LOG_E + 6; bit < N; ++bit) {
+            const int rb = 1 << (bit - (N - LOG_E));
+            if (rb == 1) {
+#pragma unroll
+                for (int r = 0; r < E; r += 2) {
+                    const f32x2 uu = {y[r], y[r]};
+                    const f32x2 ww = {y[r + 1], -y[r + 1]};
+                    const f32x2 o = uu + ww;
+                    y[r] = o.x; y[r + 1] = o.y;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < E; r += 2) {
+                    if ((r & rb) == 0) {
+                        const f32x2 a = {y[r], y[r + 1]};
+                        const f32x2 b = {y[r | rb], y[(r | rb) + 1]};
+                        const f32x2 pp = a + b, mm = a - b;
+                        y[r] = pp.x; y[r + 1] = pp.y;
+                        y[r | rb] = mm.x; y[(r | rb) + 1] = mm.y;
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <bool P32>
 __device__ __forceinline__ float base_param_f(const uint8_t * p, int i) {
     if constexpr (P32) return reinterpret_cast<const float *>(p)[i];
@@ -225,7 +330,11 @@ __device__ __forceinline__ void base_transform(const float * __restrict__ xt, in
     }
     SDH_STAMP(2);
     // ---- H ----------------------------------------------------------------------------------------
+#ifdef SDH_BASE_FWHT_LDS
     base_fwht<Ly, 0, ONE_BUF>(y, lds0, lds1, tid);        // y now in layout JL
+#else
+    base_fwht_x<Ly, ONE_BUF>(y, lds1, tid);               // lds1: not the buffer the P1 gather reads (ONE_BUF: barrier first)
+#endif
     SDH_STAMP(3);
     if (!has_d2 && !has_p2) {                                // depth 1 (:537-544)
         if (has_d3) {
@@ -239,10 +348,14 @@ __device__ __forceinline__ void base_transform(const float * __restrict__ xt, in
         for (int r = 0; r < E; ++r) y[r] = y[r] * s2[r];
     }
     // ---- back to layout 0, through the optional second permutation ------------------------------
+#ifdef SDH_BASE_FWHT_LDS
     // The first FWHT's last transpose used lds0 when J is odd, lds1 when J is even; the other
     // buffer's readers are already behind a barrier, so it takes the way back. The second FWHT
     // then starts on the buffer that is not being read here (PAR = J & 1).
     float * back = (Ly::J & 1) ? lds1 : lds0;
+#else
+    float * back = lds0;                                     // its last readers (P1 gather) are behind the FWHT's barrier
+#endif
     if constexpr (ONE_BUF) __syncthreads();
     base_lds_write<Ly, JL>(back, y, tid);
     __syncthreads();
@@ -253,7 +366,11 @@ __device__ __forceinline__ void base_transform(const float * __restrict__ xt, in
         base_lds_read<Ly, 0>(y, back, tid);
     }
     SDH_STAMP(4);
+#ifdef SDH_BASE_FWHT_LDS
     base_fwht<Ly, (Ly::J & 1), ONE_BUF>(y, lds0, lds1, tid);
+#else
+    base_fwht_x<Ly, ONE_BUF>(y, lds1, tid);
+#endif
     SDH_STAMP(5);
     if (has_d3) {
 #pragma unroll
@@ -287,12 +404,15 @@ __device__ __forceinline__ void base_prm_load(BasePrm<Ly> & q, const BasePackDes
 }
 
 // y: the block's input in layout 0 (thread tid holds elements [E*tid, E*tid + E), zero past the end of x).
-// On return y[r] holds output element idx(J-1, tid, r). lds: L floats (one buffer).
-template <class Ly>
+// On return y[r] holds output element idx(J-1, tid, r). lds: L floats (ONE_BUF) or 2 L floats: with two buffers
+// the transposes alternate between them and need one barrier each instead of two.
+template <class Ly, bool ONE_BUF>
 __device__ __forceinline__ void base_transform_core(float (&y)[Ly::E], const BasePrm<Ly> & q, const BasePackDesc & pd,
                                                     float * lds, int tid) {
 #pragma clang fp contract(off)
-    constexpr int E = Ly::E, JL = Ly::J - 1;
+    constexpr int E = Ly::E, L = Ly::L, JL = Ly::J - 1;
+    float * lds0 = lds;
+    float * lds1 = ONE_BUF ? lds : lds + L;
     const bool has_p1 = pd.off_p1 >= 0, has_d2 = pd.off_d2 >= 0, has_d1 = pd.off_d1 >= 0,
                has_d3 = pd.off_d3 >= 0, has_p2 = pd.off_p2 >= 0;
     if (has_d1) {
@@ -300,12 +420,18 @@ __device__ __forceinline__ void base_transform_core(float (&y)[Ly::E], const Bas
         for (int r = 0; r < E; ++r) y[r] = y[r] * q.s1[r];
     }
     if (has_p1) {
-        base_lds_write<Ly, 0>(lds, y, tid);
+        base_lds_write<Ly, 0>(lds0, y, tid);
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < E; ++r) y[r] = lds[Ly::phys(q.g1[r])];
+        for (int r = 0; r < E; ++r) y[r] = lds0[Ly::phys(q.g1[r])];
     }
-    base_fwht<Ly, 0, true>(y, lds, lds, tid);
+    SDH_CORE_STAMP(4);
+#ifdef SDH_BASE_FWHT_LDS
+    base_fwht<Ly, 0, ONE_BUF>(y, lds0, lds1, tid);
+#else
+    base_fwht_x<Ly, ONE_BUF>(y, lds1, tid);
+#endif
+    SDH_CORE_STAMP(5);
     if (!has_d2 && !has_p2) {                                // depth 1 (:537-544)
         if (has_d3) {
 #pragma unroll
@@ -317,16 +443,26 @@ __device__ __forceinline__ void base_transform_core(float (&y)[Ly::E], const Bas
 #pragma unroll
         for (int r = 0; r < E; ++r) y[r] = y[r] * q.s2[r];
     }
-    __syncthreads();
-    base_lds_write<Ly, JL>(lds, y, tid);
+#ifdef SDH_BASE_FWHT_LDS
+    float * back = (Ly::J & 1) ? lds1 : lds0;                // as base_transform: the buffer whose readers are behind a barrier
+#else
+    float * back = lds0;
+#endif
+    if constexpr (ONE_BUF) __syncthreads();
+    base_lds_write<Ly, JL>(back, y, tid);
     __syncthreads();
     if (has_p2) {
 #pragma unroll
-        for (int r = 0; r < E; ++r) y[r] = lds[Ly::phys(q.g2[r])];
+        for (int r = 0; r < E; ++r) y[r] = back[Ly::phys(q.g2[r])];
     } else {
-        base_lds_read<Ly, 0>(y, lds, tid);
+        base_lds_read<Ly, 0>(y, back, tid);
     }
-    base_fwht<Ly, (Ly::J & 1), true>(y, lds, lds, tid);
+    SDH_CORE_STAMP(6);
+#ifdef SDH_BASE_FWHT_LDS
+    base_fwht<Ly, (Ly::J & 1), ONE_BUF>(y, lds0, lds1, tid);
+#else
+    base_fwht_x<Ly, ONE_BUF>(y, lds1, tid);
+#endif
     if (has_d3) {
 #pragma unroll
         for (int r = 0; r < E; ++r) y[r] = y[r] * q.s3[r];

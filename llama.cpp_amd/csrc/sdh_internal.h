@@ -155,6 +155,7 @@ int  stack_create(const sdh_weight * const * gate, const sdh_weight * const * up
 void stack_free(FfnStack * st);
 int  stack_forward(FfnStack * st, int act, const uint16_t * gelu_tab, const float * x, float * y, bool zero_nf, hipStream_t s);
 int  stack_status(FfnStack * st, int64_t * nonfinite, int64_t * timeouts);
+int  stack_stamps(FfnStack * st, unsigned long long * out);
 int  stack_layers(const FfnStack * st);
 int64_t stack_bytes(const FfnStack * st);
 

@@ -16,10 +16,11 @@
 //   0 .. 3B-1      base workgroups: block b of gate, of up, of down. Per layer: request the block's parameters, wait
 //                  for the input vector (x_l, or chunk b of h_l) as granules, run D3 H D2 H P1 D1 (sdh_base_dev.h,
 //                  bit-identical to the stand-alone transform), publish L granules.
-//   3B .. grid-1   row workgroups. Waves 0..nw_gu-1 own gate/up row groups: stage x_l in LDS (granule sweep), form
-//                  the two residual sums per row from payload already in registers, pick up the two base terms,
-//                  write h[o] = act(g)*u as a granule, THEN request the next layer's payload. The remaining waves own
-//                  down rows: gather their h entries directly as granules, add the B base terms, publish x_{l+1}.
+//   next n_dwg     down-row workgroups: stage h_l whole in LDS (coalesced granule sweep), form their rows' sums, add the B
+//                  base terms, publish x_{l+1} (or store y), THEN request the next layer's payload.
+//   the rest       gate/up-row workgroups: stage x_l in LDS (granule sweep), form the two residual sums per row from
+//                  payload already in registers, pick up the two base terms, write h[o] = act(g)*u as a granule,
+//                  THEN request the next layer's payload.
 // A wave never has the next phase's payload loads outstanding while it polls for something it needs now: loads
 // retire in order, so a poll issued behind a fresh HBM request would wait for it.
 //
@@ -33,10 +34,21 @@
 // the grid always drains. Tags are unique per (call, layer); tag 0 is never used. Not capturable into a HIP graph
 // (a replay would repeat its tags): the host entry point declines under capture.
 #include "sdh_internal.h"
+#ifdef SDH_STK_STAMPS
+static __shared__ unsigned long long stk_stamp_lds[512];
+static __shared__ int stk_stamp_l;
+#define SDH_CORE_STAMP(k)                                                                                      \
+    do {                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        if (threadIdx.x == 0 && stk_stamp_l >= 0) stk_stamp_lds[stk_stamp_l * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+    } while (0)
+#endif
 #include "sdh_base_dev.h"
 #include "sdh_delta_dev.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace sdh {
@@ -45,6 +57,7 @@ constexpr int STK_WAVES   = 8;          // 512-thread workgroups
 constexpr int STK_MAXP_GU = 3;          // gate/up row groups per wave and layer (register-resident payload)
 constexpr int STK_MAXP_D  = 3;          // down row groups per wave and layer
 constexpr int STK_MAXX    = 16;         // x granules staged per thread
+constexpr int STK_MAXH    = 32;         // h granules staged per thread of a down workgroup (n_ff <= 16384)
 constexpr int STK_MAXB    = 4;          // base blocks per output of the wide (down) tensor
 constexpr unsigned long long STK_SPIN_TICKS = 50000;     // 100 MHz ticks = 500 us
 
@@ -72,9 +85,29 @@ struct StackArgs {
     int zero_nf;
     int * nf;                                       // [n_layers][3] non-finite counters
     unsigned * ctr;                                 // [0] census arrivals, [1] census failures, [2] timeouts
-    int nw_gu;                                      // gate/up waves per row workgroup
+    int n_dwg;                                      // workgroups that own down rows (the rest of the row workgroups own gate/up rows)
     int census;
+    unsigned long long * stamps;                    // diagnostic build (-DSDH_STK_STAMPS): [7 samples][n_layers][8] real-time ticks
 };
+
+#ifdef SDH_STK_STAMPS
+// Stamps go to LDS while the kernel runs and to memory when the sampled workgroup leaves: a global store per stamp
+// sits in the wave's vmcnt queue and every later wait for a load then also waits for that store (~1 us each).
+#define STK_STAMP(sample, l, k)                                                                              \
+    do {                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        if ((sample) >= 0 && threadIdx.x == 0 && (l) < 64) stk_stamp_lds[(l) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+    } while (0)
+#define STK_STAMP_FLUSH(sample)                                                                              \
+    do {                                                                                                     \
+        if ((sample) >= 0 && threadIdx.x == 0)                                                               \
+            for (int i_ = 0; i_ < a.n_layers * 8 && i_ < 512; ++i_) a.stamps[(sample) * a.n_layers * 8 + i_] = stk_stamp_lds[i_]; \
+    } while (0)
+#else
+#define STK_STAMP(sample, l, k) do { } while (0)
+#define STK_STAMP_FLUSH(sample) do { } while (0)
+#endif
 
 __device__ __forceinline__ unsigned long long stk_gload(const unsigned long long * base, int i) {
     return __hip_atomic_load(reinterpret_cast<const unsigned long long *>(reinterpret_cast<const char *>(base) + (size_t) ((unsigned) i * 8u)),
@@ -85,19 +118,28 @@ __device__ __forceinline__ void stk_gstore(unsigned long long * base, int i, flo
                        ((unsigned long long) tag << 32) | (unsigned long long) __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Wait for N granules (indices gi, only those with used[i]). First one granule alone (keeps the polling traffic of
-// a few hundred waiting workgroups small), then all N issued back to back, branch-free, tags checked afterwards.
-// Returns false on timeout; unused slots give 0.
+// Waiting is gated per WORKGROUP. While a hand-off is not there yet, ONE lane of the workgroup watches ONE of the
+// granules it needs (stk_gate, a load every ~0.3 us) and the other waves sit in s_barrier, which costs no memory
+// traffic. Agent-scope granule loads are served by the fabric, not by L1/L2 hits: with every lane of ~250 workgroups
+// spinning on its own granules the pollers alone moved several TB/s and a layer's hand-offs took 2-5 us each
+// (profiles/r02_b_stack_stamps_before.txt). After the gate, every lane loads all its N granules back to back,
+// branch-free, and checks the tags; stragglers are re-polled at a slow cadence. Returns false on timeout; unused
+// slots give 0.
+__device__ __forceinline__ void stk_gate(const unsigned long long * vg, int i, unsigned tag, bool watch) {
+    if (threadIdx.x == 0 && watch) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while ((unsigned) (stk_gload(vg, i) >> 32) != tag) {
+            if (__builtin_amdgcn_s_memrealtime() - t0 >= STK_SPIN_TICKS) break;
+            __builtin_amdgcn_s_sleep(10);
+        }
+    }
+    __syncthreads();
+}
+
 template <int N>
 __device__ __forceinline__ bool stk_poll(const unsigned long long * vg, const int (&gi)[N], const bool (&used)[N], unsigned tag,
                                          float (&vals)[N]) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    if (used[0]) {
-        while ((unsigned) (stk_gload(vg, gi[0]) >> 32) != tag) {
-            if (__builtin_amdgcn_s_memrealtime() - t0 >= STK_SPIN_TICKS) break;
-            __builtin_amdgcn_s_sleep(2);
-        }
-    }
     bool ok = false;
     do {
         unsigned long long g[N];
@@ -110,9 +152,19 @@ __device__ __forceinline__ bool stk_poll(const unsigned long long * vg, const in
             vals[i] = used[i] ? __uint_as_float((unsigned) g[i]) : 0.0f;
         }
         if (ok) break;
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(6);
     } while (__builtin_amdgcn_s_memrealtime() - t0 < STK_SPIN_TICKS);
     return ok;
+}
+
+// The workgroup's wait for a hand-off (every wave of the workgroup calls it): gate, then load. Loading first and
+// gating only when something is missing measured 22.6 against 17.8 us per layer: the first attempt of ~250
+// workgroups is itself the polling storm the gate avoids.
+template <int N>
+__device__ __forceinline__ bool stk_wait(const unsigned long long * vg, const int (&gi)[N], const bool (&used)[N], unsigned tag,
+                                         float (&vals)[N]) {
+    stk_gate(vg, gi[0], tag, used[0]);
+    return stk_poll<N>(vg, gi, used, tag, vals);
 }
 
 // ---- one row group's payload in registers -------------------------------------------------------------
@@ -189,50 +241,6 @@ __device__ __forceinline__ float stk_row_dot_lds(const RowRegs<BLOCK, STEPS> & r
     return acc;
 }
 
-// granule indices of the activations a lane needs for one row group (down rows read h as granules)
-template <bool BLOCK, int STEPS>
-__device__ __forceinline__ void stk_row_gather_idx(const RowRegs<BLOCK, STEPS> & r, const StackShape & s, bool row_ok, int l,
-                                                   int * gi, bool * used) {
-#pragma unroll
-    for (int u = 0; u < STEPS; ++u) {
-        const int e = (u * s.G + l) * 8;
-        const bool ok = row_ok & (e < s.Ktot);
-        if constexpr (BLOCK) {
-            const int e0 = ok ? e : 0;
-            const int raw = (r.blk[u] << s.block_shift) + (e0 & (s.block - 1));
-            const bool okb = ok & ((unsigned) r.blk[u] < (unsigned) s.n_blk_in) & (raw < s.n_in);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { used[u * 8 + j] = okb; gi[u * 8 + j] = okb ? raw + j : 0; }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int i = idx_to_i32<uint16_t>(r.ii[u].get(j));
-                const bool okj = ok & ((unsigned) i < (unsigned) s.n_in);
-                used[u * 8 + j] = okj;
-                gi[u * 8 + j] = okj ? i : 0;
-            }
-        }
-    }
-}
-
-template <bool BLOCK, int STEPS>
-__device__ __forceinline__ float stk_row_dot_vals(const RowRegs<BLOCK, STEPS> & r, const float * xv, const bool * used) {
-    float acc = 0.0f;
-#pragma unroll
-    for (int u = 0; u < STEPS; ++u) {
-        if constexpr (BLOCK) {
-            const float4 xa = make_float4(xv[u * 8 + 0], xv[u * 8 + 1], xv[u * 8 + 2], xv[u * 8 + 3]);
-            const float4 xb = make_float4(xv[u * 8 + 4], xv[u * 8 + 5], xv[u * 8 + 6], xv[u * 8 + 7]);
-            acc = add_if(acc, used[u * 8], dot8<uint16_t>(r.vv[u], xa, xb));
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                acc = add_if(acc, used[u * 8 + j], __fmul_rn(val_to_f32<uint16_t>(r.vv[u].get(j)), xv[u * 8 + j]));
-        }
-    }
-    return acc;
-}
-
 // scale (only if != 1, :645), count / optionally zero non-finite outputs (:363-392): finish_output's operations
 __device__ __forceinline__ float stk_finish(float y, float scale, int * nf, int zero_nf) {
     float out = (scale != 1.0f) ? (y * scale) : y;
@@ -249,7 +257,10 @@ void ffn_stack_kernel(const StackArgs a) {
     using Ly = BaseLay<LOG_E, LOG_T>;
     constexpr int L = Ly::L;
     constexpr int E = Ly::E;
-    extern __shared__ __align__(16) float lds[];        // max(L, n_embd) floats
+    extern __shared__ __align__(16) float lds[];        // max(2 L, n_embd, n_ff) floats (the base transform alternates between two buffers)
+#ifdef SDH_STK_STAMPS
+    if (threadIdx.x == 0) { for (int i_ = 0; i_ < 512; ++i_) stk_stamp_lds[i_] = 0; stk_stamp_l = -1; }
+#endif
 
     if (a.census) {                                     // residency self-test (as decode_fused_kernel)
         if (threadIdx.x == 0) {
@@ -288,8 +299,14 @@ void ffn_stack_kernel(const StackArgs a) {
             used[r] = i < n_src;
             gi[r] = used[r] ? i : 0;
         }
+        const int smp = b == 0 ? which : -1;           // stamps: block 0 of gate, up, down
+        (void) smp;
         for (int l = 0; l < a.n_layers; ++l) {
             __syncthreads();                            // the previous layer's last LDS reads are done
+#ifdef SDH_STK_STAMPS
+            if (threadIdx.x == 0) stk_stamp_l = (smp >= 0 && l < 64) ? l : -1;
+#endif
+            STK_STAMP(smp, l, 0);
             const unsigned tag = a.tag0 + (unsigned) l;
             BasePackDesc pd = a.pd[which];
             pd.pack = a.layers[l].pack[which];
@@ -300,33 +317,40 @@ void ffn_stack_kernel(const StackArgs a) {
 #pragma unroll
                 for (int r = 0; r < E; ++r) y[r] = used[r] ? a.x[gi[r]] : 0.0f;
             } else {
-                if (!stk_poll<E>(src, gi, used, tag, y)) {
+                if (!stk_poll<E>(src, gi, used, tag, y)) {     // 3B workgroups: they poll directly
                     atomicAdd(&a.ctr[2], 1u);
 #pragma unroll
                     for (int r = 0; r < E; ++r) y[r] = qnan;
                 }
             }
-            base_transform_core<Ly>(y, q, pd, lds, tid);
+            STK_STAMP(smp, l, 1);
+            base_transform_core<Ly, false>(y, q, pd, lds, tid);
+            STK_STAMP(smp, l, 2);
 #pragma unroll
             for (int r = 0; r < E; ++r) stk_gstore(out, Ly::idx(Ly::J - 1, tid, r), y[r], tag);
+            STK_STAMP(smp, l, 3);
         }
+        STK_STAMP_FLUSH(smp);
         return;
     }
 
     // ---- row roles --------------------------------------------------------------------------------------------
-    const int rw = bid - n_base_wg;                     // row workgroup index
-    const int n_rw = (int) gridDim.x - n_base_wg;
+    // A workgroup owns EITHER gate/up rows OR down rows: a CU then never has its own payload prefetch in its memory
+    // queue while one of its waves waits for a hand-off (the price of a hand-off sits in the consumer CU's queue:
+    // with both kinds of rows on every CU a layer took 17.4 us, the prefetch of one kind delaying the polls of the other).
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     float * const xs = lds;
+    const bool is_down_wg = bid < n_base_wg + a.n_dwg;
 
-    if (wave < a.nw_gu) {
+    if (!is_down_wg) {
         // ---- gate | up rows ---------------------------------------------------------------------------------
         const StackShape & s = a.gu;
         const int G = s.G, l_in = lane & (G - 1), rpp = 64 / G;
-        const int slots = n_rw * a.nw_gu, slot = rw * a.nw_gu + wave;
+        const int n_rw = (int) gridDim.x - n_base_wg - a.n_dwg, rw = bid - n_base_wg - a.n_dwg;
+        const int slots = n_rw * STK_WAVES, slot = rw * STK_WAVES + wave;
         const int n_groups = (s.n_out + rpp - 1) / rpp;
-        const int tg = threadIdx.x, nt = a.nw_gu * 64;  // staging threads: the gate/up waves
+        const int tg = threadIdx.x, nt = STK_WAVES * 64; // staging threads: the whole workgroup
         int xi[STK_MAXX];
         bool xu[STK_MAXX];
 #pragma unroll
@@ -360,15 +384,18 @@ void ffn_stack_kernel(const StackArgs a) {
             }
         };
         load_layer(0);
+        const int smp = rw == 0 ? 5 : (rw == n_rw - 1 ? 6 : -1);
+        (void) smp;
         for (int l = 0; l < a.n_layers; ++l) {
             const unsigned tag = a.tag0 + (unsigned) l;
+            STK_STAMP(smp, l, 0);
             // stage x_l (every gate/up wave of the workgroup takes part)
             if (l == 0) {
 #pragma unroll
                 for (int k = 0; k < STK_MAXX; ++k) if (xu[k]) xs[xi[k]] = a.x[xi[k]];
             } else {
-                float xv[STK_MAXX];
-                if (!stk_poll<STK_MAXX>(a.XG, xi, xu, tag, xv)) {
+                float xv[STK_MAXX] = {};
+                if (!stk_wait<STK_MAXX>(a.XG, xi, xu, tag, xv)) {
                     atomicAdd(&a.ctr[2], 1u);
 #pragma unroll
                     for (int k = 0; k < STK_MAXX; ++k) xv[k] = qnan;
@@ -377,16 +404,18 @@ void ffn_stack_kernel(const StackArgs a) {
                 for (int k = 0; k < STK_MAXX; ++k) if (xu[k]) xs[xi[k]] = xv[k];
             }
             __syncthreads();
+            STK_STAMP(smp, l, 1);
             float accg[STK_MAXP_GU], accu[STK_MAXP_GU];
 #pragma unroll
             for (int p = 0; p < STK_MAXP_GU; ++p) {
                 accg[p] = group_reduce(stk_row_dot_lds<BLOCK, STEPS_GU>(rg[p], s, xs, rok[p], l_in), G);
                 accu[p] = group_reduce(stk_row_dot_lds<BLOCK, STEPS_GU>(ru[p], s, xs, rok[p], l_in), G);
             }
+            STK_STAMP(smp, l, 2);
             // base terms of this wave's rows: granule o of the gate block array, granule B*L + o of the up one
             int vi[2 * STK_MAXP_GU];
             bool vu[2 * STK_MAXP_GU];
-            float vv[2 * STK_MAXP_GU];
+            float vv[2 * STK_MAXP_GU] = {};
 #pragma unroll
             for (int p = 0; p < STK_MAXP_GU; ++p) {
                 const bool leader = rok[p] && l_in == 0;
@@ -394,7 +423,8 @@ void ffn_stack_kernel(const StackArgs a) {
                 vi[2 * p] = leader ? orow[p] : 0;
                 vi[2 * p + 1] = leader ? B * L + orow[p] : 0;
             }
-            const bool ok = stk_poll<2 * STK_MAXP_GU>(a.VGU, vi, vu, tag, vv);
+            const bool ok = stk_wait<2 * STK_MAXP_GU>(a.VGU, vi, vu, tag, vv);
+            STK_STAMP(smp, l, 3);
             if (!ok) atomicAdd(&a.ctr[2], 1u);
 #pragma unroll
             for (int p = 0; p < STK_MAXP_GU; ++p) {
@@ -406,17 +436,19 @@ void ffn_stack_kernel(const StackArgs a) {
                     stk_gstore(a.HG, orow[p], glu_value(a.act, yg, yu, a.gelu_tab), tag);
                 }
             }
+            STK_STAMP(smp, l, 4);
             if (l + 1 < a.n_layers) load_layer(l + 1);  // the HBM stream of the next layer runs under the down phase
+            STK_STAMP(smp, l, 5);
         }
+        STK_STAMP_FLUSH(smp);
         return;
     }
 
     // ---- down rows ----------------------------------------------------------------------------------------------
     {
         const StackShape & s = a.d;
-        const int nw_d = STK_WAVES - a.nw_gu, wd = wave - a.nw_gu;
         const int G = s.G, l_in = lane & (G - 1), rpp = 64 / G;
-        const int slots = n_rw * nw_d, slot = rw * nw_d + wd;
+        const int slots = a.n_dwg * STK_WAVES, slot = (bid - n_base_wg) * STK_WAVES + wave;
         const int n_groups = (s.n_out + rpp - 1) / rpp;
         int orow[STK_MAXP_D];
         bool rok[STK_MAXP_D], act_pass[STK_MAXP_D];
@@ -438,30 +470,44 @@ void ffn_stack_kernel(const StackArgs a) {
             }
         };
         load_layer(0);
-        constexpr int NG = STK_MAXP_D * STEPS_D * 8;
+        // h_l is staged whole in LDS by a coalesced granule sweep (n_ff / 512 granules per thread, 512 contiguous bytes
+        // per wave instruction). Gathering each row's entries straight from the granule array cost 3.2 us per layer:
+        // 24 scattered 8-byte loads per lane are 64 address-coalescer cycles per wave instruction, 5 us per CU
+        // (tools/gpu/gpu_stack_ablate.sh, profiles/r02_c_stack_ablation.txt).
+        int hi[STK_MAXH];
+        bool hu[STK_MAXH];
+#pragma unroll
+        for (int k = 0; k < STK_MAXH; ++k) {
+            const int i = (int) threadIdx.x + k * STK_WAVES * 64;
+            hu[k] = i < a.n_ff;
+            hi[k] = hu[k] ? i : 0;
+        }
+        const int smp = bid == n_base_wg ? 3 : (bid == n_base_wg + a.n_dwg - 1 ? 4 : -1);
+        (void) smp;
         for (int l = 0; l < a.n_layers; ++l) {
             const unsigned tag = a.tag0 + (unsigned) l;
-            __syncthreads();                            // pairs with the gate/up waves' staging barrier of this layer
-            int gi[NG];
-            bool gu[NG];
-            float hv[NG];
+            STK_STAMP(smp, l, 0);
+            {
+                float hv[STK_MAXH] = {};
+                if (!stk_wait<STK_MAXH>(a.HG, hi, hu, tag, hv)) {
+                    atomicAdd(&a.ctr[2], 1u);
 #pragma unroll
-            for (int p = 0; p < STK_MAXP_D; ++p)
-                stk_row_gather_idx<BLOCK, STEPS_D>(rd[p], s, rok[p], l_in, gi + p * STEPS_D * 8, gu + p * STEPS_D * 8);
-            bool ok = stk_poll<NG>(a.HG, gi, gu, tag, hv);
-            if (!ok) {
-                atomicAdd(&a.ctr[2], 1u);
+                    for (int k = 0; k < STK_MAXH; ++k) hv[k] = qnan;
+                }
 #pragma unroll
-                for (int i = 0; i < NG; ++i) hv[i] = qnan;
+                for (int k = 0; k < STK_MAXH; ++k) if (hu[k]) xs[hi[k]] = hv[k];
             }
+            __syncthreads();
+            STK_STAMP(smp, l, 1);
             float acc[STK_MAXP_D];
 #pragma unroll
             for (int p = 0; p < STK_MAXP_D; ++p)
-                acc[p] = group_reduce(stk_row_dot_vals<BLOCK, STEPS_D>(rd[p], hv + p * STEPS_D * 8, gu + p * STEPS_D * 8), G);
+                acc[p] = group_reduce(stk_row_dot_lds<BLOCK, STEPS_D>(rd[p], s, xs, rok[p], l_in), G);
+            STK_STAMP(smp, l, 2);
             // base terms: sum_b v_b[o], from 0.0f in block order
             int vi[STK_MAXP_D * STK_MAXB];
             bool vu[STK_MAXP_D * STK_MAXB];
-            float vv[STK_MAXP_D * STK_MAXB];
+            float vv[STK_MAXP_D * STK_MAXB] = {};
 #pragma unroll
             for (int p = 0; p < STK_MAXP_D; ++p) {
                 const bool leader = rok[p] && l_in == 0;
@@ -471,7 +517,8 @@ void ffn_stack_kernel(const StackArgs a) {
                     vi[p * STK_MAXB + bb] = (leader && bb < B) ? bb * L + orow[p] : 0;
                 }
             }
-            const bool okv = stk_poll<STK_MAXP_D * STK_MAXB>(a.VD, vi, vu, tag, vv);
+            const bool okv = stk_wait<STK_MAXP_D * STK_MAXB>(a.VD, vi, vu, tag, vv);
+            STK_STAMP(smp, l, 3);
             if (!okv) atomicAdd(&a.ctr[2], 1u);
             const bool last = l + 1 == a.n_layers;
 #pragma unroll
@@ -487,8 +534,11 @@ void ffn_stack_kernel(const StackArgs a) {
                     else stk_gstore(a.XG, orow[p], yo, tag + 1u);
                 }
             }
+            STK_STAMP(smp, l, 4);
             if (!last) load_layer(l + 1);
+            STK_STAMP(smp, l, 5);
         }
+        STK_STAMP_FLUSH(smp);
     }
 }
 
@@ -500,12 +550,13 @@ struct FfnStack {
     unsigned long long * XG = nullptr, * HG = nullptr, * VGU = nullptr, * VD = nullptr;
     int * nf = nullptr;
     unsigned * ctr = nullptr;
+    unsigned long long * stamps = nullptr;
     unsigned tag = 0;                   // last tag handed out
     int n_embd = 0, n_ff = 0, L = 0, B = 0;
     StackShape gu{}, d{};
     bool block = false;
     int steps_gu = 0, steps_d = 0;
-    int nw_gu = 0;
+    int n_dwg = 0;
     unsigned grid = 0;
     size_t lds = 0;
     bool census_ok = false;
@@ -516,9 +567,10 @@ typedef void (*stack_kernel_t)(const StackArgs);
 
 template <bool BLOCK, int LOG_E, int LOG_T>
 static stack_kernel_t pick_steps(int sgu, int sd) {
-    // down rows of two steps per lane (K > 512) would hold 48 granules per lane and spill: not instantiated
     if (sgu == 1 && sd == 1) return ffn_stack_kernel<BLOCK, 1, 1, LOG_E, LOG_T>;
     if (sgu == 2 && sd == 1) return ffn_stack_kernel<BLOCK, 2, 1, LOG_E, LOG_T>;
+    if (sgu == 1 && sd == 2) return ffn_stack_kernel<BLOCK, 1, 2, LOG_E, LOG_T>;
+    if (sgu == 2 && sd == 2) return ffn_stack_kernel<BLOCK, 2, 2, LOG_E, LOG_T>;
     return nullptr;
 }
 static stack_kernel_t pick_kernel(const FfnStack & st) {
@@ -551,7 +603,7 @@ static StackShape shape_of(const DeviceWeight & w, int G) {
 void stack_free(FfnStack * st) {
     if (!st) return;
     (void) hipFree(st->dev_layers); (void) hipFree(st->XG); (void) hipFree(st->HG); (void) hipFree(st->VGU); (void) hipFree(st->VD);
-    (void) hipFree(st->nf); (void) hipFree(st->ctr);
+    (void) hipFree(st->nf); (void) hipFree(st->ctr); (void) hipFree(st->stamps);
     delete st;
 }
 
@@ -607,15 +659,14 @@ int stack_create(const sdh_weight * const * gate, const sdh_weight * const * up,
     const int n_rw = (int) st->grid - 3 * st->B;
     if (n_rw < 8) STK_DECLINE("too few CUs");
     const int groups_gu = (st->n_ff + 64 / st->gu.G - 1) / (64 / st->gu.G), groups_d = (st->n_embd + 64 / st->d.G - 1) / (64 / st->d.G);
-    int best = 0;
-    for (int nw = 1; nw < STK_WAVES; ++nw) {             // nw gate/up waves, 8 - nw down waves per workgroup
-        const int pgu = (groups_gu + n_rw * nw - 1) / (n_rw * nw), pd = (groups_d + n_rw * (STK_WAVES - nw) - 1) / (n_rw * (STK_WAVES - nw));
-        if (pgu <= STK_MAXP_GU && pd <= STK_MAXP_D) best = nw;      // the most gate/up waves that still leave room for down
-    }
-    if (!best) STK_DECLINE("rows do not fit the register-resident passes");
-    st->nw_gu = best;
-    if ((st->n_embd + best * 64 - 1) / (best * 64) > STK_MAXX) STK_DECLINE("n_embd too large for the staging pass");
-    st->lds = (size_t) std::max(st->L, st->n_embd) * sizeof(float);
+    // the fewest down workgroups whose waves hold their row groups in MAXP_D passes; the rest own gate/up rows
+    const int n_dwg = (groups_d + STK_WAVES * STK_MAXP_D - 1) / (STK_WAVES * STK_MAXP_D);      // more (64, 86) measured the same
+    const int n_guwg = n_rw - n_dwg;
+    if (n_guwg < 1 || (groups_gu + n_guwg * STK_WAVES - 1) / (n_guwg * STK_WAVES) > STK_MAXP_GU) STK_DECLINE("rows do not fit the register-resident passes");
+    st->n_dwg = n_dwg;
+    if ((st->n_embd + STK_WAVES * 64 - 1) / (STK_WAVES * 64) > STK_MAXX) STK_DECLINE("n_embd too large for the staging pass");
+    st->lds = (size_t) std::max(std::max(2 * st->L, st->n_embd), st->n_ff) * sizeof(float);
+    if (st->n_ff > STK_MAXH * STK_WAVES * 64) STK_DECLINE("n_ff too large for the staging pass");
     if (st->lds > 64 * 1024) STK_DECLINE("activation vector too large for LDS");
 #undef STK_DECLINE
 
@@ -630,6 +681,7 @@ int stack_create(const sdh_weight * const * gate, const sdh_weight * const * up,
     if ((rc = dmalloc((void **) &st->XG, (size_t) st->n_embd * 8)) || (rc = dmalloc((void **) &st->HG, (size_t) st->n_ff * 8)) ||
         (rc = dmalloc((void **) &st->VGU, 2 * BL * 8)) || (rc = dmalloc((void **) &st->VD, BL * 8)) ||
         (rc = dmalloc((void **) &st->nf, (size_t) n_layers * 3 * sizeof(int))) || (rc = dmalloc((void **) &st->ctr, 16)) ||
+        (rc = dmalloc((void **) &st->stamps, (size_t) 7 * n_layers * 8 * sizeof(unsigned long long))) ||
         (rc = dmalloc((void **) &st->dev_layers, (size_t) n_layers * sizeof(StackLayer)))) { stack_free(st); return rc; }
     std::vector<StackLayer> hl((size_t) n_layers);
     for (int l = 0; l < n_layers; ++l)
@@ -659,7 +711,7 @@ int stack_forward(FfnStack * st, int act, const uint16_t * gelu_tab, const float
     a.gu = st->gu; a.d = st->d;
     for (int t = 0; t < 3; ++t) a.pd[t] = st->w[t][0]->pack;
     a.act = act; a.gelu_tab = gelu_tab; a.zero_nf = zero_nf ? 1 : 0;
-    a.nf = st->nf; a.ctr = st->ctr; a.nw_gu = st->nw_gu;
+    a.nf = st->nf; a.ctr = st->ctr; a.n_dwg = st->n_dwg; a.stamps = st->stamps;
     if (!st->census_ok) {
         int occ = 0;
         SDH_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, STK_WAVES * 64, st->lds));
@@ -696,6 +748,12 @@ int stack_status(FfnStack * st, int64_t * nonfinite, int64_t * timeouts) {
     for (int v : nf) n += v;
     if (nonfinite) *nonfinite = n;
     if (timeouts) *timeouts = ctr[2];
+    return SDH_OK;
+}
+
+int stack_stamps(FfnStack * st, unsigned long long * out) {      // diagnostic: 7 x n_layers x 8 ticks of the last call
+    SDH_HIP_CHECK(hipStreamSynchronize(st->last_stream));
+    SDH_HIP_CHECK(hipMemcpy(out, st->stamps, (size_t) 7 * st->n_layers * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return SDH_OK;
 }
 
