@@ -121,6 +121,33 @@ def ref_lib():
     return _ref
 
 
+REF_NATIVE_SO = os.path.join(HERE, "_ref", "libsdref_native.so")   # same library, ggml-cpu built -march=native (stock GGML_NATIVE)
+_ref_native = None
+
+
+def ref_native_available() -> bool:
+    return os.path.exists(REF_NATIVE_SO)
+
+
+def ref_native_lib():
+    global _ref_native
+    if _ref_native is None:
+        _ref_native = C.CDLL(REF_NATIVE_SO)
+        _bind_ffn(_ref_native)
+    return _ref_native
+
+
+def glu_native(act: int, g: np.ndarray, u: np.ndarray) -> np.ndarray:
+    """act(g) * u by the reference's CPU backend built as a stock build builds it (SIMD bodies of vec.cpp / vec.h)."""
+    g = np.ascontiguousarray(g, dtype=np.float32)
+    u = np.ascontiguousarray(u, dtype=np.float32)
+    y = np.empty_like(g)
+    rc = ref_native_lib().sdref_glu(act, g.size, g.ctypes.data, u.ctypes.data, y.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"sdref_glu (native) failed: {rc}")
+    return y
+
+
 def _bind_ffn(lib):
     lib.sdref_glu.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.sdref_glu.restype = C.c_int

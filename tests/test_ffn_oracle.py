@@ -47,6 +47,27 @@ def test_glu_silu_within_tolerance_of_reference():
     assert np.all(np.abs(a[fin] - b[fin]) <= SILU_REL * np.abs(b[fin]) + 1e-37)
 
 
+def test_glu_against_the_stock_native_simd_build():
+    """A stock reference build compiles ggml-cpu with -march=native (GGML_NATIVE), which selects the SIMD bodies of
+    ggml_vec_swiglu_f32 (ggml_v_silu / ggml_v_expf, a polynomial expf) instead of the scalar ggml_silu_f32 the plain
+    -O3 pin runs. oracle/_ref/libsdref_native.so is that build of the same files. Stated tolerance of the oracle
+    (and hence of the HIP path, which evaluates x / (1 + expf(-x)) like the scalar body) against it: SILU_REL
+    relative per element; the GELU table form has no SIMD variant and stays bit-exact."""
+    if not O.ref_native_available():
+        pytest.skip("oracle/_ref/libsdref_native.so not built (needs /root/reference; build container only)")
+    rng = np.random.default_rng(9)
+    g = (6.0 * rng.standard_normal(100003)).astype(np.float32)          # odd length: SIMD body + scalar tail
+    u = rng.standard_normal(100003).astype(np.float32)
+    g[:8] = [0.0, -0.0, 88.0, -88.0, 20.0, -20.0, 1e-30, -1e-30]
+    a, b = O.glu(O.ACT_SILU, g, u), O.glu_native(O.ACT_SILU, g, u)
+    fin = np.isfinite(b)
+    assert np.array_equal(np.isfinite(a), fin)
+    rel = np.abs(a[fin] - b[fin]) / np.maximum(np.abs(b[fin]), 1e-37)
+    assert rel.max() <= SILU_REL, rel.max()
+    a, b = O.glu(O.ACT_GELU, g, u), O.glu_native(O.ACT_GELU, g, u)
+    assert np.array_equal(bits(a), bits(b))
+
+
 @pytest.mark.parametrize("name", ffn_golden_names())
 def test_ffn_oracle_vs_reference_graph_fixture(name):
     gate, up, down, x, act, h_ref, y_ref = load_ffn_golden(name)
