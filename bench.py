@@ -187,12 +187,21 @@ def run_scan(args, rank, world, dev):
     payload = None
     if rank == 0 and args.scan_payload_sample > 0 and mine:
         full = scan_variants(metrics_only=False)
-        sample = mine[:: max(1, len(mine) // args.scan_payload_sample)][: args.scan_payload_sample]
-        ev.run_many(sample[:2], threads=args.scan_threads, params_of=lambda c: full[c.variant])
+        # whole K schedules (every K of a sampled (layer, tensor, variant)): the unit the builder works in
+        groups = {}
+        for c in mine:
+            groups.setdefault((c.variant, c.layer, c.kind), []).append(c)
+        keys = sorted(groups)
+        n_groups = max(1, args.scan_payload_sample // max(1, len(SCAN_K["ffn_gate"])))
+        keys = keys[:: max(1, len(keys) // n_groups)][:n_groups]
+        sample = [c for k in keys for c in groups[k]]
+        ev.run_many(groups[keys[0]], threads=args.scan_threads, params_of=lambda c: full[c.variant])
         t1 = time.perf_counter()
         ev.run_many(sample, threads=args.scan_threads, params_of=lambda c: full[c.variant])
         payload = {"value": len(sample) / (time.perf_counter() - t1), "unit": "candidates/s", "candidates": len(sample),
-                   "note": "every output row selected and kept on the device (payload emission), rank 0 only"}
+                   "schedules": len(keys),
+                   "note": "every output row selected and kept on the device (payload emission), whole K schedules of "
+                           "sampled (layer, tensor, variant) groups, rank 0 only"}
     ev.close()
     assert len(allr) == len(cands)
     # algorithmic bytes per candidate: the quantised tensor read once + idx/val/row_scale emitted

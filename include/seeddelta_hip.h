@@ -347,6 +347,24 @@ void sdh_scan_memo_clear(void);
  * eval row sample, then the eval-x row sample and Gaussian activations). Blocks until done. */
 int  sdh_scan_tensor(sdh_scan * s, const sdh_dense * W, const sdh_dense * Wg, const sdh_dense * Wu,
                      const sdh_dense * Wd, const sdh_scan_params * p, sdh_scan_result * out);
+/* A K schedule of one tensor from one fit and one selection. The builder fits the base once per tensor
+ * (tools/seeddelta-build/sd_build.cpp:444-451) and then runs one trial per K of the schedule (:843-913), each
+ * of which dequantises, forms the residual and sorts again; here the rows are selected and sorted once at the
+ * largest budget — descending score, ties by ascending index (sd_eval.cpp:53-77), so the top-K of every
+ * smaller K is a prefix of each stored row — and the row scales and metric passes of all n_k budgets are
+ * queued behind that one selection, with one copy and one synchronisation for the whole schedule.
+ * outs[j] equals, bit for bit, what sdh_scan_tensor with p->K = Ks[j] returns from the same generator state
+ * (p->K itself is ignored); the generator advances once, as for one candidate: every K of a layer-scan grid is
+ * a builder run of its own with the same seed, so all of them see the same draws. gpu_ms is an equal share of
+ * the schedule's device time. 1 <= n_k <= SDH_SCAN_MAX_K. With delta_norm_clamp_down acting (ffn_down, COO)
+ * the stored values depend on K: SDH_ERR_UNSUPPORTED for n_k > 1 — evaluate those budgets one by one. */
+#define SDH_SCAN_MAX_K 16
+int  sdh_scan_tensor_kgrid(sdh_scan * s, const sdh_dense * W, const sdh_dense * Wg, const sdh_dense * Wu,
+                           const sdh_dense * Wd, const sdh_scan_params * p, const int64_t * Ks, int n_k,
+                           sdh_scan_result * outs);
+/* Choose the member j of the last schedule that sdh_scan_fetch / sdh_scan_fetch_packed return (after
+ * sdh_scan_tensor_kgrid: the last one; after sdh_scan_tensor there is only member 0). */
+int  sdh_scan_pick(sdh_scan * s, int j);
 /* Advance the RNG as sdh_scan_tensor would for a tensor of these dims, without touching the GPU:
  * lets a rank that owns (layer, ffn_up) reproduce the stream position after ffn_gate (sharding). */
 int  sdh_scan_skip(sdh_scan * s, int64_t n_in, int64_t n_out, const sdh_scan_params * p);

@@ -395,9 +395,15 @@ __device__ __forceinline__ void bitonic_desc(int n, CMP swap_if_needed) {
     }
 }
 
+// A K schedule evaluated from ONE selection (the builder fits once per tensor and runs a trial per K,
+// sd_build.cpp:444-451, :843-913): rows are selected and sorted at the largest K; descending order with
+// ties by ascending index makes the top-K of every smaller K a prefix of that row. k[j] counts idx entries
+// (COO: residuals; block: kept blocks). Row scales and metric results are laid out [j][slot].
+struct KGrid { int n; int k[SDH_SCAN_MAX_K]; };
+
 template <int DT>
 __global__ __launch_bounds__(256)
-void scan_select_coo_kernel(DenseView W, BaseView base, int has_base, int K, int Kpad, int want_rs,
+void scan_select_coo_kernel(DenseView W, BaseView base, int has_base, int K /* the largest of kg */, int Kpad, int want_rs, KGrid kg,
                             const int * __restrict__ rows_sel /* null: every row; else outputs are compact */,
                             const float * __restrict__ ws,
                             int * __restrict__ idx_out, float * __restrict__ val_out, float * __restrict__ rs_out) {
@@ -512,22 +518,28 @@ void scan_select_coo_kernel(DenseView W, BaseView base, int has_base, int K, int
         }
     }
 
-    double dot2 = 0.0, nn2 = 0.0;
     for (int rr = tid; rr < K; rr += 256) {
         const int i = (int) (0xffffffffu - (uint32_t) sbuf[rr]);
         idx_out[orow * K + rr] = i;
         val_out[orow * K + rr] = r[i];
-        if (want_rs) {
-            const double wi = (double) dense_at<DT>(W, row, i), di = (double) r[i];
-            const double s1 = ws ? (double) ws[i] : 1.0;
-            if (has_base) { dot2 += wi * di * s1 * s1; nn2 += (2.0 * wi * di - di * di) * s1 * s1; }
-            else          { dot2 += wi * wi * s1 * s1; nn2 += wi * wi * s1 * s1; }
-        }
     }
     if (want_rs) {
-        const double d_all = block_sum(dot, dsc) + block_sum(dot2, dsc);
-        const double n_all = block_sum(nn, dsc) + block_sum(nn2, dsc);
-        if (tid == 0) rs_out[orow] = n_all > 1e-30 ? (float) (d_all / n_all) : 1.0f;
+        // the least-squares scale of every K of the schedule: each thread adds its entries rr = tid, tid + 256, ...
+        // below K_j, the order a selection at K_j alone would use
+        const double d_row = block_sum(dot, dsc), n_row = block_sum(nn, dsc);
+        for (int j = 0; j < kg.n; ++j) {
+            double dot2 = 0.0, nn2 = 0.0;
+            for (int rr = tid; rr < kg.k[j]; rr += 256) {
+                const int i = (int) (0xffffffffu - (uint32_t) sbuf[rr]);
+                const double wi = (double) dense_at<DT>(W, row, i), di = (double) r[i];
+                const double s1 = ws ? (double) ws[i] : 1.0;
+                if (has_base) { dot2 += wi * di * s1 * s1; nn2 += (2.0 * wi * di - di * di) * s1 * s1; }
+                else          { dot2 += wi * wi * s1 * s1; nn2 += wi * wi * s1 * s1; }
+            }
+            const double d_all = d_row + block_sum(dot2, dsc);
+            const double n_all = n_row + block_sum(nn2, dsc);
+            if (tid == 0) rs_out[(size_t) j * gridDim.x + orow] = n_all > 1e-30 ? (float) (d_all / n_all) : 1.0f;
+        }
     }
 }
 
@@ -535,8 +547,8 @@ void scan_select_coo_kernel(DenseView W, BaseView base, int has_base, int K, int
 // LDS: r[n_in] f32 | energy[NBpad] f64 | bid[NBpad] i32 | misc
 template <int DT>
 __global__ __launch_bounds__(256)
-void scan_select_block_kernel(DenseView W, BaseView base, int has_base, int block, int keep, int n_blocks, int NBpad,
-                              int want_rs, const int * __restrict__ rows_sel, const float * __restrict__ ws,
+void scan_select_block_kernel(DenseView W, BaseView base, int has_base, int block, int keep /* the largest of kg */, int n_blocks, int NBpad,
+                              int want_rs, KGrid kg, const int * __restrict__ rows_sel, const float * __restrict__ ws,
                               int * __restrict__ idx_out, float * __restrict__ val_out, float * __restrict__ rs_out) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int n_in = (int) W.n_in;
@@ -572,28 +584,31 @@ void scan_select_block_kernel(DenseView W, BaseView base, int has_base, int bloc
         if (desc ? !a_first : a_first) { en[a] = eb; en[b] = ea; bid[a] = ib; bid[b] = ia; }
     });
 
-    double dot2 = 0.0, nn2 = 0.0;
     for (int e = tid; e < keep * block; e += 256) {
         const int bi = e / block, t = e - bi * block;
         const int blk = bid[bi];
         const int i = blk * block + t;
         if (t == 0) idx_out[orow * keep + bi] = blk;
-        float v = 0.0f;
-        if (i < n_in) {
-            v = r[i];
-            if (want_rs) {
-                const double wi = (double) dense_at<DT>(W, row, i), di = (double) v;
-                const double s1 = ws ? (double) ws[i] : 1.0;
-                if (has_base) { dot2 += wi * di * s1 * s1; nn2 += (2.0 * wi * di - di * di) * s1 * s1; }
-                else          { dot2 += wi * wi * s1 * s1; nn2 += wi * wi * s1 * s1; }
-            }
-        }
-        val_out[((size_t) orow * keep + bi) * block + t] = v;
+        val_out[((size_t) orow * keep + bi) * block + t] = i < n_in ? r[i] : 0.0f;
     }
     if (want_rs) {
-        const double d_all = block_sum(dot, dsc) + block_sum(dot2, dsc);
-        const double n_all = block_sum(nn, dsc) + block_sum(nn2, dsc);
-        if (tid == 0) rs_out[orow] = n_all > 1e-30 ? (float) (d_all / n_all) : 1.0f;
+        const double d_row = block_sum(dot, dsc), n_row = block_sum(nn, dsc);
+        for (int j = 0; j < kg.n; ++j) {                      // per K of the schedule, in a lone selection's order
+            double dot2 = 0.0, nn2 = 0.0;
+            for (int e = tid; e < kg.k[j] * block; e += 256) {
+                const int bi = e / block, t = e - bi * block;
+                const int i = bid[bi] * block + t;
+                if (i < n_in) {
+                    const double wi = (double) dense_at<DT>(W, row, i), di = (double) r[i];
+                    const double s1 = ws ? (double) ws[i] : 1.0;
+                    if (has_base) { dot2 += wi * di * s1 * s1; nn2 += (2.0 * wi * di - di * di) * s1 * s1; }
+                    else          { dot2 += wi * wi * s1 * s1; nn2 += wi * wi * s1 * s1; }
+                }
+            }
+            const double d_all = d_row + block_sum(dot2, dsc);
+            const double n_all = n_row + block_sum(nn2, dsc);
+            if (tid == 0) rs_out[(size_t) j * gridDim.x + orow] = n_all > 1e-30 ? (float) (d_all / n_all) : 1.0f;
+        }
     }
 }
 
@@ -634,14 +649,18 @@ __global__ void scan_scale_vals_kernel(float * __restrict__ val, int64_t n, doub
 // ---- kernel: weight-space metric triples (w_norm2, hat_norm2, dot) per sampled row -------------------
 template <int DT>
 __global__ __launch_bounds__(256)
-void scan_evalw_kernel(DenseView W, BaseView base, int has_base, int scheme, int K, int block,
-                       const int * __restrict__ idx, const float * __restrict__ val, const float * __restrict__ rs,
-                       const float * __restrict__ ws, const int * __restrict__ rows, int compact /* payload indexed by sample, not by row */,
-                       double * __restrict__ out /* [n_rows][3] */) {
+void scan_evalw_kernel(DenseView W, BaseView base, int has_base, int scheme, KGrid kg, int ld /* idx entries per payload row */, int block,
+                       const int * __restrict__ idx, const float * __restrict__ val, const float * __restrict__ rs /* [kg.n][rs_stride] */,
+                       int64_t rs_stride, const float * __restrict__ ws, const int * __restrict__ rows,
+                       int compact /* payload indexed by sample, not by row */,
+                       double * __restrict__ out /* [kg.n][n_rows][3] */) {
     __shared__ double dsc[4];
     const int64_t row = rows[blockIdx.x];
     const int64_t pr = compact ? (int64_t) blockIdx.x : row;       // payload slot of this row
     const int n_in = (int) W.n_in;
+    const int K = kg.k[blockIdx.y];                                // this K of the schedule: a prefix of the row
+    if (rs) rs += (size_t) blockIdx.y * (size_t) rs_stride;
+    out += (size_t) blockIdx.y * gridDim.x * 3;
     const double scale = rs ? (double) rs[pr] : 1.0;
     double wn = 0.0, hn = 0.0, dt = 0.0;
     for (int i = threadIdx.x; i < n_in; i += 256) {
@@ -660,16 +679,16 @@ void scan_evalw_kernel(DenseView W, BaseView base, int has_base, int scheme, int
         float dv;
         if (scheme == 1) {
             const int bi = e / block, t = e - bi * block;
-            const int blk = idx[pr * K + bi];
+            const int blk = idx[pr * ld + bi];
             if (blk < 0) continue;
             i = (int64_t) blk * block + t;
             if (i >= n_in) continue;
-            dv = val[((size_t) pr * K + bi) * block + t];
+            dv = val[((size_t) pr * ld + bi) * block + t];
         } else {
-            const int ii = idx[pr * K + e];
+            const int ii = idx[pr * ld + e];
             if (ii < 0 || ii >= n_in) continue;
             i = ii;
-            dv = val[pr * K + e];
+            dv = val[pr * ld + e];
         }
         const double s1 = ws ? (double) ws[i] : 1.0;
         if (has_base) {
@@ -708,13 +727,16 @@ void scan_dense_dot_kernel(DenseView W, const int * __restrict__ rows, int n_row
 // v = base transforms [n_x][B][L] (fp32, exact); tall picks v[b][p], wide sums blocks in fp32 from 0.0f
 // in block order (sd_eval.cpp:1119-1134)
 __global__ __launch_bounds__(256)
-void scan_delta_dot_kernel(int n_in, int scheme, int K, int block, const int * __restrict__ idx,
-                           const float * __restrict__ val, const float * __restrict__ rs,
+void scan_delta_dot_kernel(int n_in, int scheme, KGrid kg, int ld /* idx entries per payload row */, int block, const int * __restrict__ idx,
+                           const float * __restrict__ val, const float * __restrict__ rs /* [kg.n][rs_stride] */, int64_t rs_stride,
                            const float * __restrict__ v, int L, int B, int tall,
                            const int * __restrict__ rows, int n_rows, int compact, const float * __restrict__ xs,
-                           double * __restrict__ out /* [n_x][n_rows] */) {
+                           double * __restrict__ out /* [kg.n][n_x][n_rows] */) {
     __shared__ double dsc[4];
     const int ci = blockIdx.x, xi = blockIdx.y;
+    const int K = kg.k[blockIdx.z];                                // this K of the schedule: a prefix of the row
+    if (rs) rs += (size_t) blockIdx.z * (size_t) rs_stride;
+    out += (size_t) blockIdx.z * gridDim.y * (size_t) n_rows;
     const int64_t row = rows[ci];
     const int64_t pr = compact ? (int64_t) ci : row;
     const float * x = xs + (size_t) xi * n_in;
@@ -723,15 +745,15 @@ void scan_delta_dot_kernel(int n_in, int scheme, int K, int block, const int * _
     for (int e = threadIdx.x; e < n_ent; e += 256) {
         if (scheme == 1) {
             const int bi = e / block, t = e - bi * block;
-            const int blk = idx[pr * K + bi];
+            const int blk = idx[pr * ld + bi];
             if (blk < 0) continue;
             const int64_t i = (int64_t) blk * block + t;
             if (i >= n_in) continue;
-            acc += (double) val[((size_t) pr * K + bi) * block + t] * (double) x[i];
+            acc += (double) val[((size_t) pr * ld + bi) * block + t] * (double) x[i];
         } else {
-            const int ii = idx[pr * K + e];
+            const int ii = idx[pr * ld + e];
             if (ii < 0 || ii >= n_in) continue;
-            acc += (double) val[pr * K + e] * (double) x[ii];
+            acc += (double) val[pr * ld + e] * (double) x[ii];
         }
     }
     acc = block_sum(acc, dsc);
@@ -764,17 +786,17 @@ __global__ void scan_gather_kernel(DenseView W, const int * __restrict__ rows, i
 // ---- kernels: the builder's packing step (tools/seeddelta-build/sd_build.cpp:1104-1236) -----------------
 // indices: int32 staging -> I16, anything outside [-32768, 32767] becomes -1 (:1132, :1162)
 __global__ __launch_bounds__(256)
-void scan_pack_i16_kernel(const int * __restrict__ in, int16_t * __restrict__ out, int64_t n) {
+void scan_pack_i16_kernel(const int * __restrict__ in, int16_t * __restrict__ out, int64_t n, int64_t w /* entries per row */, int64_t ld /* row stride of in */) {
     const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
-    if (i < n) { const int v = in[i]; out[i] = (v < -32768 || v > 32767) ? (int16_t) -1 : (int16_t) v; }
+    if (i < n) { const int v = in[(i / w) * ld + i % w]; out[i] = (v < -32768 || v > 32767) ? (int16_t) -1 : (int16_t) v; }
 }
 // values: fp32 -> F16 as ggml_fp32_to_fp16_row does it (ggml/src/ggml.c:457-462): round to nearest even,
 // overflow to infinity, subnormals kept, every NaN -> sign | 0x7E00
 __global__ __launch_bounds__(256)
-void scan_pack_f16_kernel(const float * __restrict__ in, uint16_t * __restrict__ out, int64_t n) {
+void scan_pack_f16_kernel(const float * __restrict__ in, uint16_t * __restrict__ out, int64_t n, int64_t per_row /* entries per row */, int64_t ld /* row stride of in */) {
     const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const float f = in[i];
+    const float f = in[(i / per_row) * ld + i % per_row];
     const uint32_t w = __float_as_uint(f);
     const uint16_t h = __half_as_ushort(__float2half_rn(f));
     out[i] = ((w & 0x7FFFFFFFu) > 0x7F800000u) ? (uint16_t) (((w >> 16) & 0x8000u) | 0x7E00u) : h;
@@ -814,7 +836,10 @@ struct DevBuf {
 struct Scan {
     std::mt19937 rng;
     // last candidate
-    int64_t n_in = 0, n_out = 0, K = 0, block = 0, L = 0, B = 0;
+    int64_t n_in = 0, n_out = 0, K = 0, block = 0, L = 0, B = 0;     // K: idx entries per row of the candidate sdh_scan_fetch returns
+    int64_t ld = 0;                     // idx entries per row as stored (the largest K of the last schedule)
+    int     kg_n = 1, pick = 0;         // K schedule of the last call and the member sdh_scan_fetch* returns
+    int64_t kg_ksel[SDH_SCAN_MAX_K] = {0};
     int scheme = 0; bool has_base = false, has_rs = false;
     bool emitted = false;               // the last candidate selected every row (sdh_scan_fetch can return the payload)
     const void * fit_of = nullptr;      // the dense handle the current fit belongs to
@@ -1250,23 +1275,36 @@ static int sdh_scan_skip_impl(sdh_scan * h, int64_t n_in, int64_t n_out, const s
     return SDH_OK;
 }
 
-static int sdh_scan_tensor_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, const sdh_dense * Wu,
-                    const sdh_dense * Wd, const sdh_scan_params * pp, sdh_scan_result * out) {
-    if (!h || !Wh || !pp || !out) { set_error("sdh_scan_tensor: null argument"); return SDH_ERR_INVALID; }
+// One tensor, a schedule of nK budgets (Ks; nK = 1 is sdh_scan_tensor): one fit, one selection at the largest K,
+// the metric passes of every K queued behind it, one copy, one synchronisation. outs[j] is what a lone
+// sdh_scan_tensor with K = Ks[j] returns from the same generator state; the generator advances once.
+static int scan_grid_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, const sdh_dense * Wu,
+                    const sdh_dense * Wd, const sdh_scan_params * pp, const int64_t * Ks, int nK, sdh_scan_result * outs) {
+    if (!h || !Wh || !pp || !outs || !Ks) { set_error("sdh_scan_tensor: null argument"); return SDH_ERR_INVALID; }
+    if (nK < 1 || nK > SDH_SCAN_MAX_K) { set_error("scan: a K schedule holds 1..%d budgets, got %d", SDH_SCAN_MAX_K, nK); return SDH_ERR_INVALID; }
     Scan & s = *(Scan *) h;
     const sdh_scan_params & p = *pp;
     hipStream_t st = s.stream;
     const DenseView W = ((const DeviceDense *) Wh)->v;
     const int64_t n_in = W.n_in, n_out = W.n_out;
     const bool tall = n_out >= n_in;
-    std::memset(out, 0, sizeof(*out));
+    std::memset(outs, 0, sizeof(*outs) * (size_t) nK);
     if (p.scheme != 0 && p.scheme != 1) { set_error("scan: scheme must be 0 (coo) or 1 (block)"); return SDH_ERR_INVALID; }
     if (p.scheme == 1 && p.block <= 0) { set_error("scan: block must be > 0"); return SDH_ERR_INVALID; }
 
-    int64_t K_eff, keep;
-    clamp_budget(p, n_in, &K_eff, &keep);
-    const int64_t Ksel = p.scheme == 1 ? keep : K_eff;       // entries of idx per row
-    out->K_eff = K_eff; out->n_blocks = keep;
+    int64_t K_eff = 0, keep = 0;                             // of the largest budget: what is selected and stored
+    int64_t K_eff_j[SDH_SCAN_MAX_K], keep_j[SDH_SCAN_MAX_K];
+    KGrid kg{};
+    kg.n = nK;
+    for (int j = 0; j < nK; ++j) {
+        sdh_scan_params pj = p;
+        pj.K = Ks[j];
+        clamp_budget(pj, n_in, &K_eff_j[j], &keep_j[j]);
+        K_eff = std::max(K_eff, K_eff_j[j]); keep = std::max(keep, keep_j[j]);
+        kg.k[j] = (int) (p.scheme == 1 ? keep_j[j] : K_eff_j[j]);
+        outs[j].K_eff = K_eff_j[j]; outs[j].n_blocks = keep_j[j];
+    }
+    const int64_t Ksel = p.scheme == 1 ? keep : K_eff;       // entries of idx per stored row
     int rc;
     SDH_HIP_CHECK(hipEventRecord(s.ev0, st));
     const float * ws_dev = nullptr;
@@ -1367,8 +1405,9 @@ static int sdh_scan_tensor_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_de
         bv.h2 = s.h2.p; bv.inv = s.inv.p; bv.L = (int) L; bv.B = (int) B; bv.tall = tall ? 1 : 0; bv.log2L = 0; while ((1 << bv.log2L) < bv.L) ++bv.log2L;
         s.fit_of = (const void *) Wh;
     }
-    out->L = L; out->B = B;
-    s.n_in = n_in; s.n_out = n_out; s.K = Ksel; s.block = p.scheme == 1 ? p.block : 1; s.scheme = p.scheme;
+    for (int j = 0; j < nK; ++j) { outs[j].L = L; outs[j].B = B; s.kg_ksel[j] = kg.k[j]; }
+    s.kg_n = nK; s.pick = nK - 1; s.ld = Ksel;
+    s.n_in = n_in; s.n_out = n_out; s.K = s.kg_ksel[s.pick]; s.block = p.scheme == 1 ? p.block : 1; s.scheme = p.scheme;
     s.L = L; s.B = B; s.has_base = p.write_base != 0; s.has_rs = p.write_row_scale != 0;
     if (!p.write_base) s.fit_of = nullptr;
 
@@ -1376,6 +1415,10 @@ static int sdh_scan_tensor_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_de
     // select(rows_dev, n_sel): rows_dev == null selects every output row into [n_out] slots (the payload);
     // otherwise only the listed rows, into compact slots [n_sel] in list order (metrics_only)
     const bool clamp_applies = p.delta_norm_clamp_down > 0.0 && p.kind == 2 && p.scheme == 0;   // ffn_down, d_val non-empty
+    if (clamp_applies && nK > 1) {
+        set_error("scan: delta_norm_clamp_down rescales the residual values of each K: evaluate such budgets one by one");
+        return SDH_ERR_UNSUPPORTED;
+    }
     const bool metrics_only = p.metrics_only != 0 && !clamp_applies;
     const int compact = metrics_only ? 1 : 0;
     const size_t r_bytes = ((size_t) n_in * 4 + 15) & ~(size_t) 15;
@@ -1393,7 +1436,7 @@ static int sdh_scan_tensor_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_de
     auto select = [&](const int * rows_dev, int64_t n_sel) -> int {
         int rc2;
         if ((rc2 = s.idx.ensure((size_t) n_sel * (size_t) Ksel)) || (rc2 = s.val.ensure((size_t) n_sel * (size_t) K_eff)) ||
-            (rc2 = s.rs.ensure((size_t) n_sel))) return rc2;
+            (rc2 = s.rs.ensure((size_t) n_sel * (size_t) nK))) return rc2;
         if (n_sel <= 0) return SDH_OK;
         if (p.scheme == 0) {
             int Kpad = 2;
@@ -1404,7 +1447,7 @@ static int sdh_scan_tensor_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_de
                 return SDH_ERR_UNSUPPORTED;
             }
             SDH_LAUNCH_DT(W, scan_select_coo_kernel, dim3((unsigned) n_sel), dim3(256), lds, st, W, bv, p.write_base ? 1 : 0,
-                          (int) K_eff, Kpad, p.write_row_scale ? 1 : 0, rows_dev, ws_dev, s.idx.p, s.val.p, s.rs.p);
+                          (int) K_eff, Kpad, p.write_row_scale ? 1 : 0, kg, rows_dev, ws_dev, s.idx.p, s.val.p, s.rs.p);
         } else {
             const int64_t n_blocks = (n_in + p.block - 1) / p.block;
             int NBpad = 2;
@@ -1415,7 +1458,7 @@ static int sdh_scan_tensor_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_de
                 return SDH_ERR_UNSUPPORTED;
             }
             SDH_LAUNCH_DT(W, scan_select_block_kernel, dim3((unsigned) n_sel), dim3(256), lds, st, W, bv, p.write_base ? 1 : 0,
-                          (int) p.block, (int) keep, (int) n_blocks, NBpad, p.write_row_scale ? 1 : 0, rows_dev, ws_dev, s.idx.p, s.val.p, s.rs.p);
+                          (int) p.block, (int) keep, (int) n_blocks, NBpad, p.write_row_scale ? 1 : 0, kg, rows_dev, ws_dev, s.idx.p, s.val.p, s.rs.p);
         }
         SDH_HIP_CHECK(hipGetLastError());
         return SDH_OK;
@@ -1423,7 +1466,8 @@ static int sdh_scan_tensor_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_de
     s.emitted = !metrics_only;
     ph.reset(); ph.reset(new PhaseTimer(s.t_phase[1]));
     if (!metrics_only && (rc = select(nullptr, n_out))) return rc;
-    out->delta_clamp_scale = 1.0;
+    sdh_scan_result * out = outs;                            // the clamp acts on a lone budget only
+    for (int j = 0; j < nK; ++j) outs[j].delta_clamp_scale = 1.0;
     if (clamp_applies && K_eff > 0) {
         if ((rc = s.dbl.ensure((size_t) n_out * 2))) return rc;
         SDH_LAUNCH_DT(W, scan_row_sumsq_dense_kernel, dim3((unsigned) n_out), dim3(256), 0, st, W, s.dbl.p);
@@ -1447,10 +1491,10 @@ static int sdh_scan_tensor_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_de
     }
 
     // ---- cost model (sd_cost.cpp:7-40) --------------------------------------------------------------
-    {
-        double * c = out->cost;
+    for (int j = 0; j < nK; ++j) {
+        double * c = outs[j].cost;
         c[2] = 2.0 * (double) n_in * (double) n_out;
-        c[4] = 2.0 * (double) K_eff * (double) n_out;
+        c[4] = 2.0 * (double) K_eff_j[j] * (double) n_out;
         c[5] = p.write_row_scale ? (double) n_out : 0.0;
         if (p.write_base && L > 0 && B > 0) {
             c[0] = (double) L; c[1] = (double) B;
@@ -1471,7 +1515,7 @@ static int sdh_scan_tensor_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_de
         int kind = 0;                         // 0 weight space, 1 activation space, 2 proxy
         const float * ws_dev = nullptr;       // kind 0: imatrix scale on the device, or null
         const float * x_scale_host = nullptr; // kind 1: imatrix scale on the host, or null
-        double * o5 = nullptr;
+        int which = 0;                        // result field: 0 em, 1 em_w, 2 em_x, 3 em_x_w
         std::shared_ptr<const std::vector<int>> rows;
         std::shared_ptr<const Normals> normals;
         std::vector<float> scaled;            // kind 1 with x_scale_host
@@ -1480,18 +1524,19 @@ static int sdh_scan_tensor_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_de
     };
     ph.reset(); ph.reset(new PhaseTimer(s.t_phase[2]));
     std::vector<Pass> passes;
-    out->has_w = ws_dev ? 1 : 0;
+    for (int j = 0; j < nK; ++j) outs[j].has_w = ws_dev ? 1 : 0;
+    auto o5_of = [](sdh_scan_result & r, int which) { return which == 0 ? r.em : which == 1 ? r.em_w : which == 2 ? r.em_x : r.em_x_w; };
     if (p.eval_cols > 0) {
         for (int k = 0; k < (ws_dev ? 2 : 1); ++k) {
-            Pass ps; ps.kind = 0; ps.ws_dev = k ? ws_dev : nullptr; ps.o5 = k ? out->em_w : out->em;
+            Pass ps; ps.kind = 0; ps.ws_dev = k ? ws_dev : nullptr; ps.which = k ? 1 : 0;
             ps.rows = draw_rows(s.rng, n_out, p.eval_cols);
             passes.push_back(std::move(ps));
         }
     }
     if (p.eval_cols > 0 && p.eval_x > 0) {
-        out->has_x = 1;
+        for (int j = 0; j < nK; ++j) outs[j].has_x = 1;
         for (int k = 0; k < (ws_dev ? 2 : 1); ++k) {
-            Pass ps; ps.kind = 1; ps.x_scale_host = k ? p.w_scale : nullptr; ps.o5 = k ? out->em_x_w : out->em_x;
+            Pass ps; ps.kind = 1; ps.x_scale_host = k ? p.w_scale : nullptr; ps.which = k ? 3 : 2;
             ps.rows = draw_rows(s.rng, n_out, p.eval_cols);
             ps.nx = (int) p.eval_x;
             ps.normals = draw_normals(s.rng, (int64_t) ps.nx * n_in);
@@ -1532,13 +1577,13 @@ static int sdh_scan_tensor_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_de
             ps.nr = (int) ps.rows->size();
             ps.row0 = total_rows; total_rows += ps.nr;
             ps.out0 = total_dbl;
-            if (ps.kind == 0) total_dbl += (size_t) ps.nr * 3;
-            else if (ps.kind == 1) { total_dbl += (size_t) ps.nr * ps.nx * 2; ++n_xpass; }
+            if (ps.kind == 0) total_dbl += (size_t) ps.nr * 3 * nK;                          // [nK][nr][3]
+            else if (ps.kind == 1) { total_dbl += (size_t) ps.nr * ps.nx * (1 + nK); ++n_xpass; }   // truth, hat [nK]
             else {
                 const uint64_t id_g = ((const DeviceDense *) Wg)->serial, id_u = ((const DeviceDense *) Wu)->serial, id_d = ((const DeviceDense *) Wd)->serial;
                 have_truth = pt.g == id_g && pt.u == id_u && pt.d == id_d && pt.seed == (int64_t) p.proxy_seed && pt.cap == proxy_cap &&
                              pt.nx == ps.nx && pt.gu.size() == (size_t) ps.nr * ps.nx * 2 && pt.wd.size() == proxy_outs->size() * (size_t) ps.nr;
-                total_dbl += (size_t) ps.nr * ps.nx * (have_truth ? 1 : 3);      // hat [, gate truth, up truth]
+                total_dbl += (size_t) ps.nr * ps.nx * (nK + (have_truth ? 0 : 2));   // hat [nK] [, gate truth, up truth]
             }
         }
         if ((rc = s.dbl.ensure(total_dbl))) return rc;
@@ -1548,6 +1593,7 @@ static int sdh_scan_tensor_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_de
         if ((rc = s.rows.put(all_rows, st))) return rc;
         if (metrics_only && (rc = select(s.rows.p, total_rows))) return rc;
         const float * rs_all = p.write_row_scale ? s.rs.p : nullptr;
+        const int64_t rs_stride = metrics_only ? total_rows : n_out;      // slots of the selection launch
         const size_t v_per = (size_t) p.eval_x * (size_t) B * (size_t) L;
         if (p.write_base && n_xpass && (rc = s.v.ensure(n_xpass * v_per))) return rc;
         size_t xi_pass = 0;
@@ -1560,8 +1606,8 @@ static int sdh_scan_tensor_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_de
             const int *   rows_p = s.rows.p + ps.row0;
             double * o = s.dbl.p + ps.out0;
             if (ps.kind == 0) {
-                SDH_LAUNCH_DT(W, scan_evalw_kernel, dim3((unsigned) ps.nr), dim3(256), 0, st, W, bv, p.write_base ? 1 : 0, p.scheme,
-                              (int) Ksel, (int) s.block, idx_p, val_p, rs_p, ps.ws_dev, rows_p, compact, o);
+                SDH_LAUNCH_DT(W, scan_evalw_kernel, dim3((unsigned) ps.nr, (unsigned) nK), dim3(256), 0, st, W, bv, p.write_base ? 1 : 0, p.scheme,
+                              kg, (int) Ksel, (int) s.block, idx_p, val_p, rs_p, rs_stride, ps.ws_dev, rows_p, compact, o);
             } else if (ps.kind == 1) {
                 const float * xs_dev = nullptr;            // unscaled draws: the copy shared by all handles
                 if (ps.x_scale_host) {
@@ -1579,8 +1625,8 @@ static int sdh_scan_tensor_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_de
                 }
                 ++xi_pass;
                 SDH_LAUNCH_DT(W, scan_dense_dot_kernel, dim3((unsigned) ps.nr, (unsigned) ps.nx), dim3(256), 0, st, W, rows_p, ps.nr, xs_dev, o);
-                hipLaunchKernelGGL(scan_delta_dot_kernel, dim3((unsigned) ps.nr, (unsigned) ps.nx), dim3(256), 0, st, (int) n_in, p.scheme,
-                                   (int) Ksel, (int) s.block, idx_p, val_p, rs_p, vdev, (int) L, (int) B, tall ? 1 : 0,
+                hipLaunchKernelGGL(scan_delta_dot_kernel, dim3((unsigned) ps.nr, (unsigned) ps.nx, (unsigned) nK), dim3(256), 0, st, (int) n_in, p.scheme,
+                                   kg, (int) Ksel, (int) s.block, idx_p, val_p, rs_p, rs_stride, vdev, (int) L, (int) B, tall ? 1 : 0,
                                    rows_p, ps.nr, compact, xs_dev, o + (size_t) ps.nr * ps.nx);
             } else {
                 const DenseView G = view_or_null(Wg), U = view_or_null(Wu), D = view_or_null(Wd);
@@ -1588,15 +1634,16 @@ static int sdh_scan_tensor_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_de
                 if (!xs_dev) { set_error("scan: upload of the proxy inputs failed"); return SDH_ERR_HIP; }
                 const int nh = ps.nr;
                 no = (int) proxy_outs->size();
-                hipLaunchKernelGGL(scan_delta_dot_kernel, dim3((unsigned) nh, (unsigned) ps.nx), dim3(256), 0, st, (int) n_in, 0, (int) Ksel, 1,
-                                   idx_p, val_p, (const float *) nullptr, (const float *) nullptr, 0, 0, 1, rows_p, nh, compact, xs_dev, o);
+                hipLaunchKernelGGL(scan_delta_dot_kernel, dim3((unsigned) nh, (unsigned) ps.nx, (unsigned) nK), dim3(256), 0, st, (int) n_in, 0, kg, (int) Ksel, 1,
+                                   idx_p, val_p, (const float *) nullptr, (int64_t) 0, (const float *) nullptr, 0, 0, 1, rows_p, nh, compact, xs_dev, o);
+                double * truth = o + (size_t) nh * ps.nx * nK;
                 if (!have_truth) {
                     // true gate / up pre-activations of the sampled hidden units and W_down[out rows][hidden cols]:
                     // functions of the three dense tensors and the proxy seed only, kept for the next K
                     if ((rc = s.cols.put(*proxy_outs, st)) || (rc = s.gat.ensure((size_t) no * nh))) return rc;
                     if (s.h_flt.size() < (size_t) no * nh) s.h_flt.resize((size_t) no * nh);
-                    SDH_LAUNCH_DT(G, scan_dense_dot_kernel, dim3((unsigned) nh, (unsigned) ps.nx), dim3(256), 0, st, G, rows_p, nh, xs_dev, o + (size_t) nh * ps.nx);
-                    SDH_LAUNCH_DT(U, scan_dense_dot_kernel, dim3((unsigned) nh, (unsigned) ps.nx), dim3(256), 0, st, U, rows_p, nh, xs_dev, o + (size_t) nh * ps.nx * 2);
+                    SDH_LAUNCH_DT(G, scan_dense_dot_kernel, dim3((unsigned) nh, (unsigned) ps.nx), dim3(256), 0, st, G, rows_p, nh, xs_dev, truth);
+                    SDH_LAUNCH_DT(U, scan_dense_dot_kernel, dim3((unsigned) nh, (unsigned) ps.nx), dim3(256), 0, st, U, rows_p, nh, xs_dev, truth + (size_t) nh * ps.nx);
                     SDH_LAUNCH_DT(D, scan_gather_kernel, dim3((unsigned) ((no * nh + 255) / 256)), dim3(256), 0, st, D, s.cols.p, no, rows_p, nh, s.gat.p);
                     pt.seed = -1;                          // invalid until the copies below have landed
                     SDH_HIP_CHECK(hipMemcpyAsync(s.h_flt.data(), s.gat.p, (size_t) no * nh * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -1616,24 +1663,30 @@ static int sdh_scan_tensor_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_de
             const int nr = ps.nr, nx = ps.nx;
             if (ps.kind == 0) {
                 std::vector<double> rel((size_t) nr), cs((size_t) nr), nrm((size_t) nr);
-                for (int i = 0; i < nr; ++i) triple_metrics(r[(size_t) i * 3], r[(size_t) i * 3 + 1], r[(size_t) i * 3 + 2], &rel[(size_t) i], &cs[(size_t) i], &nrm[(size_t) i]);
-                summarise(rel, cs, nrm, ps.o5);
-            } else if (ps.kind == 1) {
-                const double * yt = r, * yh = r + (size_t) nr * nx;
-                std::vector<double> rel((size_t) nx), cs((size_t) nx), nrm((size_t) nx);
-                for (int xi = 0; xi < nx; ++xi) {
-                    double n1 = 0.0, n2 = 0.0, dot = 0.0;
-                    for (int ci = 0; ci < nr; ++ci) {
-                        const double a = yt[(size_t) xi * nr + ci], b = yh[(size_t) xi * nr + ci];
-                        n1 += a * a; n2 += b * b; dot += a * b;
-                    }
-                    triple_metrics(n1, n2, dot, &rel[(size_t) xi], &cs[(size_t) xi], &nrm[(size_t) xi]);
+                for (int j = 0; j < nK; ++j) {
+                    const double * rj = r + (size_t) j * nr * 3;
+                    for (int i = 0; i < nr; ++i) triple_metrics(rj[(size_t) i * 3], rj[(size_t) i * 3 + 1], rj[(size_t) i * 3 + 2], &rel[(size_t) i], &cs[(size_t) i], &nrm[(size_t) i]);
+                    summarise(rel, cs, nrm, o5_of(outs[j], ps.which));
                 }
-                summarise(rel, cs, nrm, ps.o5);
+            } else if (ps.kind == 1) {
+                const double * yt = r;
+                std::vector<double> rel((size_t) nx), cs((size_t) nx), nrm((size_t) nx);
+                for (int j = 0; j < nK; ++j) {
+                    const double * yh = r + (size_t) nr * nx * (size_t) (1 + j);
+                    for (int xi = 0; xi < nx; ++xi) {
+                        double n1 = 0.0, n2 = 0.0, dot = 0.0;
+                        for (int ci = 0; ci < nr; ++ci) {
+                            const double a = yt[(size_t) xi * nr + ci], b = yh[(size_t) xi * nr + ci];
+                            n1 += a * a; n2 += b * b; dot += a * b;
+                        }
+                        triple_metrics(n1, n2, dot, &rel[(size_t) xi], &cs[(size_t) xi], &nrm[(size_t) xi]);
+                    }
+                    summarise(rel, cs, nrm, o5_of(outs[j], ps.which));
+                }
             } else {
                 const int nh = nr;
                 if (!have_truth) {
-                    pt.gu.assign(r + (size_t) nh * nx, r + (size_t) nh * nx * 3);
+                    pt.gu.assign(r + (size_t) nh * nx * nK, r + (size_t) nh * nx * (nK + 2));
                     pt.wd.assign(s.h_flt.data(), s.h_flt.data() + (size_t) no * nh);
                     pt.g = ((const DeviceDense *) Wg)->serial; pt.u = ((const DeviceDense *) Wu)->serial; pt.d = ((const DeviceDense *) Wd)->serial;
                     pt.seed = (int64_t) p.proxy_seed; pt.cap = proxy_cap; pt.nx = nx;
@@ -1641,7 +1694,9 @@ static int sdh_scan_tensor_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_de
                 no = (int) proxy_outs->size();
                 const std::vector<double> & gu = pt.gu;
                 const std::vector<float> & wd = pt.wd;
-                const double * hat = r;
+                for (int j = 0; j < nK; ++j) {
+                sdh_scan_result * out = &outs[j];
+                const double * hat = r + (size_t) j * nh * nx;
                 std::vector<double> cs_all, l2_all, lnr_all;
                 auto silu = [](double v) { return v / (1.0 + std::exp(-v)); };
                 std::vector<double> at((size_t) nh), ah((size_t) nh);
@@ -1679,6 +1734,7 @@ static int sdh_scan_tensor_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_de
                 out->proxy[4] = mean(lnr_all); out->proxy[5] = percentile(lnr_all, 0.95);
                 out->proxy[6] = (double) nx;   out->proxy[7] = (double) no;
                 out->proxy_available = 1;
+                }
             }
         }
     }
@@ -1690,7 +1746,16 @@ static int sdh_scan_tensor_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_de
     }
     float ms = 0.0f;
     SDH_HIP_CHECK(hipEventElapsedTime(&ms, s.ev0, s.ev1));
-    out->gpu_ms = (double) ms;
+    for (int j = 0; j < nK; ++j) outs[j].gpu_ms = (double) ms / (double) nK;      // an equal share of the schedule's device time
+    return SDH_OK;
+}
+
+static int sdh_scan_pick_impl(sdh_scan * h, int j) {
+    if (!h) { set_error("sdh_scan_pick: null handle"); return SDH_ERR_INVALID; }
+    Scan & s = *(Scan *) h;
+    if (s.n_out <= 0 || j < 0 || j >= s.kg_n) { set_error("sdh_scan_pick: member %d of a schedule of %d", j, s.n_out > 0 ? s.kg_n : 0); return SDH_ERR_INVALID; }
+    s.pick = j;
+    s.K = s.kg_ksel[j];
     return SDH_OK;
 }
 
@@ -1705,11 +1770,13 @@ static int sdh_scan_fetch_impl(sdh_scan * h, int32_t * idx, float * val, float *
         set_error("sdh_scan_fetch: the candidate was evaluated with metrics_only, no payload was kept");
         return SDH_ERR_INVALID;
     }
-    if (idx) SDH_HIP_CHECK(hipMemcpyAsync(idx, s.idx.p, n_idx * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    if (val) SDH_HIP_CHECK(hipMemcpyAsync(val, s.val.p, n_idx * (size_t) s.block * sizeof(float), hipMemcpyDeviceToHost, st));
+    // the picked K is a prefix of every stored row (rows are s.ld entries apart)
+    const size_t w_idx = (size_t) s.K * sizeof(int32_t), w_val = (size_t) s.K * (size_t) s.block * sizeof(float);
+    if (idx && n_idx) SDH_HIP_CHECK(hipMemcpy2DAsync(idx, w_idx, s.idx.p, (size_t) s.ld * sizeof(int32_t), w_idx, (size_t) s.n_out, hipMemcpyDeviceToHost, st));
+    if (val && n_idx) SDH_HIP_CHECK(hipMemcpy2DAsync(val, w_val, s.val.p, (size_t) s.ld * (size_t) s.block * sizeof(float), w_val, (size_t) s.n_out, hipMemcpyDeviceToHost, st));
     if (row_scale) {
         if (!s.has_rs) { set_error("sdh_scan_fetch: candidate had no row scale"); return SDH_ERR_INVALID; }
-        SDH_HIP_CHECK(hipMemcpyAsync(row_scale, s.rs.p, (size_t) s.n_out * sizeof(float), hipMemcpyDeviceToHost, st));
+        SDH_HIP_CHECK(hipMemcpyAsync(row_scale, s.rs.p + (size_t) s.pick * (size_t) s.n_out, (size_t) s.n_out * sizeof(float), hipMemcpyDeviceToHost, st));
     }
     SDH_HIP_CHECK(hipStreamSynchronize(st));
     if (d2 || h2 || perm1 || perm1_inv) {
@@ -1744,19 +1811,19 @@ static int sdh_scan_fetch_packed_impl(sdh_scan * h, int idx_type, void * idx, in
     if ((rc = s.packed.ensure(total ? total : 1))) return rc;
     auto grid = [](size_t n) { return dim3((unsigned) ((n + 255) / 256)); };
     if (idx && idx_type == SDH_TYPE_I16 && n_idx)
-        hipLaunchKernelGGL(scan_pack_i16_kernel, grid(n_idx), dim3(256), 0, st, s.idx.p, (int16_t *) (s.packed.p + o_idx), (int64_t) n_idx);
+        hipLaunchKernelGGL(scan_pack_i16_kernel, grid(n_idx), dim3(256), 0, st, s.idx.p, (int16_t *) (s.packed.p + o_idx), (int64_t) n_idx, s.K, s.ld);
     if (val && val_type == SDH_TYPE_F16 && n_val)
-        hipLaunchKernelGGL(scan_pack_f16_kernel, grid(n_val), dim3(256), 0, st, s.val.p, s.packed.p + o_val, (int64_t) n_val);
+        hipLaunchKernelGGL(scan_pack_f16_kernel, grid(n_val), dim3(256), 0, st, s.val.p, s.packed.p + o_val, (int64_t) n_val, s.K * s.block, s.ld * s.block);
     if (row_scale_f16)                                                   // row_scale is always F16 (:1188-1191)
-        hipLaunchKernelGGL(scan_pack_f16_kernel, grid(n_rs), dim3(256), 0, st, s.rs.p, s.packed.p + o_rs, (int64_t) n_rs);
+        hipLaunchKernelGGL(scan_pack_f16_kernel, grid(n_rs), dim3(256), 0, st, s.rs.p + (size_t) s.pick * n_rs, s.packed.p + o_rs, (int64_t) n_rs, (int64_t) n_rs, (int64_t) n_rs);
     SDH_HIP_CHECK(hipGetLastError());
     if (idx) {
         if (idx_type == SDH_TYPE_I16) SDH_HIP_CHECK(hipMemcpyAsync(idx, s.packed.p + o_idx, n_idx * 2, hipMemcpyDeviceToHost, st));
-        else                          SDH_HIP_CHECK(hipMemcpyAsync(idx, s.idx.p, n_idx * 4, hipMemcpyDeviceToHost, st));
+        else if (n_idx)               SDH_HIP_CHECK(hipMemcpy2DAsync(idx, (size_t) s.K * 4, s.idx.p, (size_t) s.ld * 4, (size_t) s.K * 4, (size_t) s.n_out, hipMemcpyDeviceToHost, st));
     }
     if (val) {
         if (val_type == SDH_TYPE_F16) SDH_HIP_CHECK(hipMemcpyAsync(val, s.packed.p + o_val, n_val * 2, hipMemcpyDeviceToHost, st));
-        else                          SDH_HIP_CHECK(hipMemcpyAsync(val, s.val.p, n_val * 4, hipMemcpyDeviceToHost, st));
+        else if (n_val)               SDH_HIP_CHECK(hipMemcpy2DAsync(val, (size_t) s.K * s.block * 4, s.val.p, (size_t) s.ld * s.block * 4, (size_t) s.K * s.block * 4, (size_t) s.n_out, hipMemcpyDeviceToHost, st));
     }
     if (row_scale_f16) SDH_HIP_CHECK(hipMemcpyAsync(row_scale_f16, s.packed.p + o_rs, n_rs * 2, hipMemcpyDeviceToHost, st));
     SDH_HIP_CHECK(hipStreamSynchronize(st));
@@ -1789,7 +1856,18 @@ int sdh_scan_skip(sdh_scan * h, int64_t n_in, int64_t n_out, const sdh_scan_para
 
 int sdh_scan_tensor(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, const sdh_dense * Wu,
                     const sdh_dense * Wd, const sdh_scan_params * pp, sdh_scan_result * out) {
-    SDH_NO_THROW(sdh_scan_tensor_impl(h, Wh, Wg, Wu, Wd, pp, out));
+    if (!pp) { set_error("sdh_scan_tensor: null argument"); return SDH_ERR_INVALID; }
+    const int64_t K = pp->K;
+    SDH_NO_THROW(scan_grid_impl(h, Wh, Wg, Wu, Wd, pp, &K, 1, out));
+}
+
+int sdh_scan_tensor_kgrid(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * Wg, const sdh_dense * Wu,
+                          const sdh_dense * Wd, const sdh_scan_params * pp, const int64_t * Ks, int n_k, sdh_scan_result * outs) {
+    SDH_NO_THROW(scan_grid_impl(h, Wh, Wg, Wu, Wd, pp, Ks, n_k, outs));
+}
+
+int sdh_scan_pick(sdh_scan * h, int j) {
+    SDH_NO_THROW(sdh_scan_pick_impl(h, j));
 }
 
 int sdh_scan_fetch(sdh_scan * h, int32_t * idx, float * val, float * row_scale,

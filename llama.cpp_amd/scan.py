@@ -103,9 +103,12 @@ class ScanParams:
         p.metrics_only = int(self.metrics_only)
         p.delta_norm_clamp_down = float(self.delta_norm_clamp_down)
         if self.w_scale is not None:
-            self._ws = np.ascontiguousarray(self.w_scale, dtype=np.float32)   # kept alive for the call
-            p.w_scale = self._ws.ctypes.data
+            p._ws = np.ascontiguousarray(self.w_scale, dtype=np.float32)      # kept alive by the struct that points at it
+            p.w_scale = p._ws.ctypes.data
         return p
+
+
+MAX_KGRID = 16       # SDH_SCAN_MAX_K of include/seeddelta_hip.h
 
 
 class ScanSession:
@@ -117,6 +120,7 @@ class ScanSession:
         sd._check(lib.sdh_scan_create(C.c_uint32(seed & 0xFFFFFFFF), C.byref(h)), "sdh_scan_create")
         self._h = h
         self._last = None
+        self._grid = None
 
     def close(self):
         if getattr(self, "_h", None):
@@ -138,12 +142,41 @@ class ScanSession:
         g, u, d = (x._h if x is not None else None for x in (ffn or (None, None, None)))
         sd._check(lib.sdh_scan_tensor(self._h, W._h, g, u, d, C.byref(p), C.byref(r)), "sdh_scan_tensor")
         self._last = (W.n_in, W.n_out, params, int(r.K_eff), int(r.n_blocks), int(r.L), int(r.B))
+        self._grid = None
+        return self._result(r)
+
+    @staticmethod
+    def _result(r) -> dict:
         return {"K_eff": int(r.K_eff), "n_blocks": int(r.n_blocks), "L": int(r.L), "B": int(r.B),
                 "has_x": bool(r.has_x), "has_w": bool(r.has_w), "proxy_available": bool(r.proxy_available),
                 "em": np.array(r.em[:]), "em_x": np.array(r.em_x[:]), "em_w": np.array(r.em_w[:]),
                 "em_x_w": np.array(r.em_x_w[:]), "cost": np.array(r.cost[:]),
                 "proxy": np.array(r.proxy[:]), "gpu_ms": float(r.gpu_ms),
                 "delta_clamp_scale": float(r.delta_clamp_scale)}
+
+    def tensor_kgrid(self, W: DenseWeight, params: ScanParams, Ks: Sequence[int], kind: str = "ffn_gate", layer: int = 0,
+                     ffn: Optional[Tuple[DenseWeight, DenseWeight, DenseWeight]] = None) -> List[dict]:
+        """A K schedule of one tensor from ONE fit and ONE selection (the builder fits once per tensor and runs a
+        trial per K, sd_build.cpp:444-451, :843-913): result j is what tensor() with K = Ks[j] returns from the
+        same generator state; the generator advances once. pick(j) chooses the member fetch*() returns
+        (default: the last). params.K is ignored. At most MAX_KGRID budgets per call."""
+        lib = sd.load_library()
+        p = params.c_struct(kind, layer)
+        n = len(Ks)
+        rs = (sd.SdhScanResult * n)()
+        ks = (C.c_int64 * n)(*[int(k) for k in Ks])
+        g, u, d = (x._h if x is not None else None for x in (ffn or (None, None, None)))
+        sd._check(lib.sdh_scan_tensor_kgrid(self._h, W._h, g, u, d, C.byref(p), ks, n, rs), "sdh_scan_tensor_kgrid")
+        self._grid = [(W.n_in, W.n_out, params, int(r.K_eff), int(r.n_blocks), int(r.L), int(r.B)) for r in rs]
+        self._last = self._grid[-1]
+        return [self._result(r) for r in rs]
+
+    def pick(self, j: int):
+        """Choose which K of the last tensor_kgrid() the fetch calls return."""
+        if not self._grid:
+            raise ValueError("pick: the last call was not a K schedule")
+        sd._check(sd.load_library().sdh_scan_pick(self._h, int(j)), "sdh_scan_pick")
+        self._last = self._grid[j]
 
     def reseed(self, seed: int):
         """A new builder run on this handle (fresh mt19937), keeping device buffers and the last fit."""
@@ -584,25 +617,45 @@ class Evaluator:
         finally:
             s.close()
 
-    def run_group(self, group: Sequence[Candidate], params: Optional[ScanParams] = None) -> List[dict]:
-        """All K of one (layer, tensor) on one handle. Every K is its own builder run (fresh RNG), but with
-        the same seed the base fit of the tensor comes out the same each time, so it is computed for the
-        first K and reused (its draws replayed) for the others."""
+    def _position(self, s: "ScanSession", c: Candidate, p: ScanParams):
+        """Fresh builder run on the handle, generator moved past the layer's earlier tensors."""
+        s.reseed(p.seed)
+        for t in self.tensors:
+            if t == c.kind:
+                break
+            n_in, n_out = self.dims_of(c.layer, t) if self.dims_of is not None else \
+                (self.dense(c.layer, t).n_in, self.dense(c.layer, t).n_out)
+            s.skip(n_in, n_out, p, t, c.layer)
+
+    def run_group(self, group: Sequence[Candidate], params: Optional[ScanParams] = None, kgrid: bool = True,
+                  session: Optional["ScanSession"] = None) -> List[dict]:
+        """All K of one (layer, tensor) on one handle. Every K is its own builder run (fresh RNG) with the same
+        seed, so all of them see the same draws and the same base fit: the whole schedule goes to the device as
+        ONE call — one fit, one selection at the largest K, every K's metric passes behind it
+        (ScanSession.tensor_kgrid; sd_build.cpp:444-451, :843-913). kgrid=False evaluates the budgets one by one
+        (fit reused, its draws replayed): the form the clamp needs (--delta-norm-clamp-down rescales the stored
+        values per K) and the one the parity tests compare against. `session`: evaluate on this handle and leave
+        the schedule's payload on it (build_run fetches from it)."""
+        base = params or self.params
+        s = session or self._session(base.seed)
+        c0 = group[0]
+        assert all((c.layer, c.kind) == (c0.layer, c0.kind) for c in group)
+        need_proxy = base.scheme == "coo" and not base.base and base.eval_x > 0 and c0.kind != "ffn_down"
+        ffn = tuple(self.dense(c0.layer, k) for k in KINDS) if need_proxy else None
+        clamp = base.delta_norm_clamp_down > 0.0 and c0.kind == "ffn_down" and base.scheme == "coo"
         out = []
-        s = self._session((params or self.params).seed)
+        if kgrid and not clamp:
+            for i in range(0, len(group), MAX_KGRID):
+                part = group[i:i + MAX_KGRID]
+                p = ScanParams(**{**base.__dict__, "K": part[0].K})
+                p.base_mode = 2 if (i > 0 and p.base) else 0
+                self._position(s, c0, p)
+                out += s.tensor_kgrid(self.dense(c0.layer, c0.kind), p, [c.K for c in part], c0.kind, c0.layer, ffn)
+            return out
         for n, c in enumerate(group):
-            assert (c.layer, c.kind) == (group[0].layer, group[0].kind)
-            p = ScanParams(**{**(params or self.params).__dict__, "K": c.K})
+            p = ScanParams(**{**base.__dict__, "K": c.K})
             p.base_mode = 2 if (n > 0 and p.base) else 0            # never across groups: the handle is reused
-            s.reseed(p.seed)
-            for t in self.tensors:
-                if t == c.kind:
-                    break
-                n_in, n_out = self.dims_of(c.layer, t) if self.dims_of is not None else \
-                    (self.dense(c.layer, t).n_in, self.dense(c.layer, t).n_out)
-                s.skip(n_in, n_out, p, t, c.layer)
-            need_proxy = p.scheme == "coo" and not p.base and p.eval_x > 0 and c.kind != "ffn_down"
-            ffn = tuple(self.dense(c.layer, k) for k in KINDS) if need_proxy else None
+            self._position(s, c, p)
             out.append(s.tensor(self.dense(c.layer, c.kind), p, c.kind, c.layer, ffn))
         return out
 

@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "sdh_ffn_stack_create", "sdh_ffn_stack_destroy", "sdh_ffn_stack_forward", "sdh_ffn_stack_status", "sdh_ffn_stack_payload_bytes",
     "sdh_profile_enable", "sdh_profile_read", "sdh_profile_span_begin", "sdh_profile_span_end",
     "sdh_dense_create", "sdh_dense_destroy", "sdh_dense_bytes",
-    "sdh_scan_create", "sdh_scan_destroy", "sdh_scan_reseed", "sdh_scan_tensor", "sdh_scan_skip", "sdh_scan_fetch", "sdh_scan_fetch_packed", "sdh_scan_memo_clear", "sdh_imatrix_scale",
+    "sdh_scan_create", "sdh_scan_destroy", "sdh_scan_reseed", "sdh_scan_tensor", "sdh_scan_tensor_kgrid", "sdh_scan_pick", "sdh_scan_skip", "sdh_scan_fetch", "sdh_scan_fetch_packed", "sdh_scan_memo_clear", "sdh_imatrix_scale",
 ]
 
 
@@ -155,6 +155,9 @@ def load_library(path: str = LIB_PATH):
     lib.sdh_scan_tensor.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.POINTER(SdhScanParams), C.POINTER(SdhScanResult)]
     lib.sdh_scan_skip.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(SdhScanParams)]
+    lib.sdh_scan_tensor_kgrid.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.POINTER(SdhScanParams), C.POINTER(C.c_int64), C.c_int, C.POINTER(SdhScanResult)]
+    lib.sdh_scan_pick.argtypes = [C.c_void_p, C.c_int]
     lib.sdh_scan_fetch.argtypes = [C.c_void_p] + [C.c_void_p] * 7
     lib.sdh_scan_fetch_packed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.POINTER(C.c_int)]
