@@ -63,7 +63,7 @@ def parse_args():
     ap.add_argument("--prefill-reps", type=int, default=20)
     ap.add_argument("--ffn-layers", type=int, default=16, help="distinct synthetic Mistral-7B layers rotated in the FFN-block leg")
     ap.add_argument("--scan-layers", type=int, default=32, help="synthetic Mistral-7B layers in the scan job")
-    ap.add_argument("--scan-payload-sample", type=int, default=48,
+    ap.add_argument("--scan-payload-sample", type=int, default=144,
                     help="candidates re-run with every output row selected (payload emission), reported beside the scan rate")
     ap.add_argument("--scan-threads", type=int, default=16, help="host threads preparing candidates per rank")
     ap.add_argument("--host-io", action="store_true",
@@ -204,17 +204,37 @@ def run_scan(args, rank, world, dev):
                            "sampled (layer, tensor, variant) groups, rank 0 only"}
     ev.close()
     assert len(allr) == len(cands)
-    # algorithmic bytes per candidate: the quantised tensor read once + idx/val/row_scale emitted
-    q8 = MISTRAL["n_embd"] * MISTRAL["n_ff"] // 32 * 34
-    alg = sum(q8 + scan_dims(c.layer, c.kind)[1] * (8 * c.K + 4) for c in cands)
+    # bytes actually read: HBM traffic per candidate from the committed counter passes (tools/gpu/gpu_scan_pmc.sh:
+    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this sweep at 8 layers, FETCH_SIZE doubled as the guide prescribes)
+    traffic = None
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_scan_traffic.json")
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath))
+    per_c = traffic["sweep"]["hbm_bytes_per_candidate"] if traffic else None
+    # algorithmic bytes of the unit measured (a report entry from the rows the metric passes sample, SURVEY 8d per-unit
+    # figure restricted to what this path reads): per K schedule the fit's sampled row blocks once + the sampled rows
+    # of the selection and of each pass; per candidate that is the schedule's bytes over its K count
+    q8_row = lambda n_in: n_in // 32 * 34                                                    # noqa: E731
+    def alg_bytes(c):
+        n_in, n_out = scan_dims(c.layer, c.kind)
+        L = 1 << (min(n_in, n_out) - 1).bit_length()
+        fit = (min(2048, L) * -(-max(n_in, n_out) // L) * q8_row(min(n_in, L))) if c.variant else 0
+        rows = 64 * (2 + 2) * q8_row(n_in)                      # selection (2 passes' rows) + eval_w + eval_x dense rows
+        return (fit + rows) / len(SCAN_K[c.kind])
+    alg = sum(alg_bytes(c) for c in cands)
     out = {"metric": "scan candidates/s", "value": len(cands) / elapsed, "unit": "candidates/s", "n_gpus": world,
            "scaling": "strong", "candidates": len(cands), "seconds": elapsed,
            "roofline": {"bound": "hbm", "achieved": alg / elapsed / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
-                        "frac": alg / elapsed / 1e9 / (HBM_PEAK_GBS * world), "traffic": None,
-                        "note": "whole-pipeline, work-equivalent rate: bytes are those of the reference algorithm per candidate "
-                                "(SURVEY 8d: the quantised tensor read once + emitted payload); the metrics-only path reads only "
-                                "the sampled rows and the fit samples, and the pipeline is bound by host sample drawing "
-                                "(libstdc++ mt19937 / normal_distribution, bit-identical streams), not by the weight stream"},
+                        "frac": alg / elapsed / 1e9 / (HBM_PEAK_GBS * world),
+                        "traffic": per_c * len(cands) if per_c else None,
+                        "traffic_rate_gbs": per_c * len(cands) / elapsed / 1e9 if per_c else None,
+                        "traffic_source": "profiles/r02_scan_traffic.json" if per_c else None,
+                        "note": "achieved = bytes this path has to read (fit sample blocks once per K schedule + the rows "
+                                "the metric passes sample) / sweep time; traffic = measured HBM bytes per candidate "
+                                "(counter passes over the same sweep at 8 layers) x candidates. The sweep is bound by the "
+                                "fit kernel's per-sample arithmetic (fp64 sums in sample order, ~0.77 ms per fit on 64 "
+                                "CUs) and by launch latency, not by the weight stream; measured traffic exceeds the "
+                                "algorithmic bytes because the 4 workgroups of a fit job each re-read the job's rows"},
            "with_payload_emission": payload,
            "config": {"workload": f"cfg5: {args.scan_layers} synthetic Mistral-7B layers x gate/up/down x "
                                   f"K {SCAN_K} x {{coo no-base + proxy, coo base + row_scale}}, eval_cols=64 eval_x=32, Q8_0; "
@@ -449,8 +469,10 @@ def run_prefill(args, dev):
 
 
 def scan_cpu_baseline(budget_s):
-    """The oracle's restatement of one base+row_scale candidate (fit, run_trial loop on all host
-    threads, evals) on one gate tensor: kind 'port' (sd_build.cpp's run_trial cannot be compiled here)."""
+    """The oracle's restatement of the builder on one gate tensor, in the unit the GPU's payload-emission figure
+    uses: K schedules of a tensor — the base fitted once (sd_build.cpp:444-451), then per K a trial that selects
+    EVERY output row (the reference has no other form) and takes the weight- and activation-space metrics
+    (:843-913). kind 'port': sd_build.cpp's run_trial cannot be compiled here."""
     import scan_py as S
     W = scan_model(0, "ffn_gate")
     cores = min(16, os.cpu_count() or 1)
@@ -458,17 +480,22 @@ def scan_cpu_baseline(budget_s):
     while True:
         o = S.Engine("oracle", 1234)
         fit = o.fit_base(W, 2048, 4)
-        idx, val, rs = S.select_rows(W, fit, 0, 128, 32, True, nth=cores)
-        o.eval_w(W, fit, 0, idx, val, 128, 32, rs, 64)
-        o.eval_x(W, fit, 0, idx, val, 128, 32, rs, 64, 32)
-        n += 1
+        for K in SCAN_K["ffn_gate"]:
+            idx, val, rs = S.select_rows(W, fit, 0, K, 32, True, nth=cores)
+            o.eval_w(W, fit, 0, idx, val, K, 32, rs, 64)
+            o.eval_x(W, fit, 0, idx, val, K, 32, rs, 64, 32)
+            n += 1
+            if time.perf_counter() - t0 >= 3 * budget_s:
+                break
         el = time.perf_counter() - t0
-        if el >= budget_s or n >= 50:
+        if el >= budget_s or n >= 60:
             break
     return {"value": n / el, "unit": "candidates/s", "cores": cores, "kind": "port",
-            "sample": f"{n} candidates (ffn_gate 4096->14336 Q8_0, COO K=128, base fit 2048 samples x 4 perms, row_scale, "
-                      f"eval_cols=64, eval_x=32) in {el:.1f}s; base fit and evals single-threaded as in the reference, "
-                      f"row loop on {cores} threads"}
+            "compare_with": "with_payload_emission (every output row selected: the only form the reference has); "
+                            "the metrics-only `value` has no CPU counterpart",
+            "sample": f"{n} candidates = K schedule {SCAN_K['ffn_gate']} of ffn_gate 4096->14336 Q8_0 (COO, base fitted once: "
+                      f"2048 samples x 4 perms, row_scale, eval_cols=64, eval_x=32) in {el:.1f}s; base fit and evals "
+                      f"single-threaded as in the reference, row loop on {cores} threads"}
 
 
 def spawn_ranks(n: int) -> int:

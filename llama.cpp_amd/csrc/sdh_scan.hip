@@ -20,6 +20,7 @@
 // Host side: libstdc++'s std::mt19937 / std::shuffle / std::normal_distribution<float> — the same
 // library routines the reference calls, consumed in the same order.
 #include "sdh_internal.h"
+#include "sdh_rng.h"
 #include <atomic>
 #include <array>
 #include <chrono>
@@ -270,55 +271,59 @@ void scan_fit_lds_q8_kernel(DenseView W, int L, int tall, const FitJob * __restr
     // stage k is being accumulated. L <= 4096 (host check): at most R*256/FT pieces and R*128/FT scales per thread.
     constexpr int MAXP = R * 256 / FT, MAXD = (R * 128 + FT - 1) / FT;
     const int n_piece = R * (L >> 4), n_scale = R * nd;
-    uint4 pq[MAXP];
-    __half pd[MAXD];
-    auto fetch = [&](int s0) {
+    // two register sets: the fetch of stage k+2 is issued at the start of stage k and committed at the end of
+    // stage k+1, so a stage no longer waits out one full memory round trip (one workgroup per CU at this LDS
+    // footprint: nothing else hides it)
+    uint4 pq[2][MAXP];
+    __half pd[2][MAXD];
+    auto fetch = [&](auto set_c, int s0) {
+        constexpr int S = decltype(set_c)::value;
 #pragma unroll
         for (int i = 0; i < MAXP; ++i) {
             const int e = tid + FT * i;
-            pq[i] = make_uint4(0, 0, 0, 0);
+            pq[S][i] = make_uint4(0, 0, 0, 0);
             if (e < n_piece) {
                 const int k = e >> (lg - 4), c = e & ((L >> 4) - 1);
                 if (s0 + k < job.n_rows && c * 16 < span) {
                     const int row = rows_s[s0 + k];
-                    pq[i] = *reinterpret_cast<const uint4 *>(W.q + (int64_t) row * W.n_in + in0 + c * 16);
+                    pq[S][i] = *reinterpret_cast<const uint4 *>(W.q + (int64_t) row * W.n_in + in0 + c * 16);
                 }
             }
         }
 #pragma unroll
         for (int i = 0; i < MAXD; ++i) {
             const int e = tid + FT * i;
-            pd[i] = __float2half(0.0f);
+            pd[S][i] = __float2half(0.0f);
             if (e < n_scale) {
                 const int k = e >> (lg - 5), c = e & (nd - 1);
                 if (s0 + k < job.n_rows && c * 32 < span) {
                     const int row = rows_s[s0 + k];
-                    pd[i] = W.d[(int64_t) row * (W.n_in >> 5) + (in0 >> 5) + c];
+                    pd[S][i] = W.d[(int64_t) row * (W.n_in >> 5) + (in0 >> 5) + c];
                 }
             }
         }
     };
-    auto commit = [&](int buf) {
+    auto commit = [&](auto set_c) {                 // register set S holds a stage of parity S: LDS buffer S
+        constexpr int S = decltype(set_c)::value;
 #pragma unroll
         for (int i = 0; i < MAXP; ++i) {
             const int e = tid + FT * i;
-            if (e < n_piece) *reinterpret_cast<uint4 *>(qs + (size_t) buf * R * L + (size_t) e * 16) = pq[i];
+            if (e < n_piece) *reinterpret_cast<uint4 *>(qs + (size_t) S * R * L + (size_t) e * 16) = pq[S][i];
         }
 #pragma unroll
         for (int i = 0; i < MAXD; ++i) {
             const int e = tid + FT * i;
-            if (e < n_scale) ds[(size_t) buf * R * nd + e] = pd[i];
+            if (e < n_scale) ds[(size_t) S * R * nd + e] = pd[S][i];
         }
     };
 
     double s = 0.0, s2 = 0.0, n = 0.0;
-    fetch(0);
-    commit(0);
-    __syncthreads();
-    int buf = 0;
-    for (int s0 = 0; s0 < job.n_rows; s0 += R) {
-        const bool more = s0 + R < job.n_rows;
-        if (more) fetch(s0 + R);
+    using set0 = std::integral_constant<int, 0>;
+    using set1 = std::integral_constant<int, 1>;
+    // one stage: parity P = (s0 / R) & 1 is its LDS buffer and the register set the stage after next is fetched into
+    auto stage = [&](auto par_c, auto other_c, int s0) {
+        constexpr int buf = decltype(par_c)::value;
+        if (s0 + 2 * R < job.n_rows) fetch(par_c, s0 + 2 * R);
         // the R samples of the stage: all LDS reads first (branch-free, clamped), then the sums in sample order;
         // a sample past the end of the job, like one outside the block, adds +0.0 (exact)
         int srcv[R];
@@ -356,12 +361,100 @@ void scan_fit_lds_q8_kernel(DenseView W, int L, int tall, const FitJob * __restr
                 n  += okv[k] ? 1.0 : 0.0;
             }
         }
-        if (more) commit(buf ^ 1);
+        if (s0 + R < job.n_rows) commit(other_c);                      // the next stage, fetched one stage ago
         __syncthreads();
-        buf ^= 1;
+    };
+    fetch(set0{}, 0);
+    commit(set0{});
+    if (R < job.n_rows) fetch(set1{}, R);
+    __syncthreads();
+    for (int s0 = 0; s0 < job.n_rows; s0 += 2 * R) {
+        stage(set0{}, set1{}, s0);
+        if (s0 + R < job.n_rows) stage(set1{}, set0{}, s0 + R);
     }
     double * o = out + (size_t) blockIdx.y * 3 * L;
     o[u] = s; o[L + u] = s2; o[2 * L + u] = n;
+}
+
+// ---- kernels: the fit's tail on the device (sd_eval.cpp:600-651) -----------------------------------------
+// The host used to fetch the [n_jobs][3][L] sums, pick the best permutation trial per block and upload h2,
+// d2, perm1 and its inverse: one synchronisation in the middle of every candidate. The same arithmetic here:
+//   scan_fit_sse_kernel   grid n_jobs: sse_j = sum_u max(sm2 - sm^2/wg, 0) over bins with wg > 0, the terms
+//                         computed by all threads, added by ONE thread in bin order (the host's order);
+//   scan_fit_pick_kernel  grid B: first trial with the strictly smallest sse (trial order), h2 = (float)(sm/wg),
+//                         d2 = FWHT(h2)/L with the host's butterfly order (independent pairs per stage: the
+//                         values do not depend on which thread forms them), perm1, its inverse, d1 = 1.
+__global__ __launch_bounds__(256)
+void scan_fit_sse_kernel(const double * __restrict__ sums /* [n_jobs][3][L] */, int L, double * __restrict__ sse /* [n_jobs] */) {
+    extern __shared__ __align__(16) unsigned char fit_tail_smem[];
+    double * term = (double *) fit_tail_smem;                           // [L]
+    const double * sm = sums + (size_t) blockIdx.x * 3 * L, * sm2 = sm + L, * wg = sm2 + L;
+    for (int u = threadIdx.x; u < L; u += 256) {
+        double t = 0.0;                                                 // a bin without samples adds +0.0: exact
+        if (wg[u] > 0.0) t = fmax(sm2[u] - (sm[u] * sm[u]) / wg[u], 0.0);
+        term[u] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double acc = 0.0;
+        for (int u = 0; u < L; u += 8) {                                // L is a power of two >= 256
+            double t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = term[u + k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += t[k];
+        }
+        sse[blockIdx.x] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256)
+void scan_fit_pick_kernel(const double * __restrict__ sums, const double * __restrict__ sse, const FitJob * __restrict__ jobs, int n_jobs,
+                          const int * __restrict__ perms, int L,
+                          float * __restrict__ h2_out, float * __restrict__ d2_out, int * __restrict__ perm1_out,
+                          int * __restrict__ inv_out, float * __restrict__ d1_out /* each [B][L] */) {
+    extern __shared__ __align__(16) unsigned char fit_tail_smem[];
+    float * a = (float *) fit_tail_smem;                                // [L]
+    __shared__ int best_s;
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) {
+        double best = INFINITY;
+        int bj = -1;
+        for (int j = 0; j < n_jobs; ++j)                                // jobs are in (block, trial) order
+            if (jobs[j].b == b && sse[j] < best) { best = sse[j]; bj = j; }
+        best_s = bj;
+    }
+    __syncthreads();
+    const int bj = best_s;
+    const size_t o = (size_t) b * L;
+    for (int u = threadIdx.x; u < L; u += 256) { inv_out[o + u] = 0; d1_out[o + u] = 1.0f; }     // D1 = I in the fit (:450)
+    if (bj < 0) {                                                       // block without rows / inputs: stays zero
+        for (int u = threadIdx.x; u < L; u += 256) { h2_out[o + u] = 0.0f; d2_out[o + u] = 0.0f; perm1_out[o + u] = 0; }
+        return;
+    }
+    const double * sm = sums + (size_t) bj * 3 * L, * wg = sm + 2 * (size_t) L;
+    const int * perm = perms + jobs[bj].perm_off;
+    for (int u = threadIdx.x; u < L; u += 256) {
+        const float h = wg[u] > 0.0 ? (float) (sm[u] / wg[u]) : 0.0f;
+        a[u] = h;
+        h2_out[o + u] = h;
+        perm1_out[o + u] = perm[u];
+    }
+    __syncthreads();                                                    // also orders inv_out = 0 before the scatter below
+    for (int i = threadIdx.x; i < L; i += 256) {
+        const int src = perm[i];
+        if (src >= 0 && src < L) inv_out[o + src] = i;
+    }
+    for (int len = 1; len < L; len <<= 1) {
+        for (int t = threadIdx.x; t < (L >> 1); t += 256) {
+            const int i = ((t & ~(len - 1)) << 1) | (t & (len - 1));
+            const float u = a[i], v = a[i + len];
+            a[i] = u + v; a[i + len] = u - v;
+        }
+        __syncthreads();
+    }
+    const float inv_L = 1.0f / (float) L;
+    for (int u = threadIdx.x; u < L; u += 256) d2_out[o + u] = a[u] * inv_L;
 }
 
 // ---- kernel: COO selection ---------------------------------------------------------------------------
@@ -833,6 +926,7 @@ struct DevBuf {
     ~DevBuf() { if (p) (void) hipFree(p); }
 };
 
+struct FitPlan;
 struct Scan {
     std::mt19937 rng;
     // last candidate
@@ -845,7 +939,10 @@ struct Scan {
     const void * fit_of = nullptr;      // the dense handle the current fit belongs to
     DevBuf<int> idx; DevBuf<float> val; DevBuf<float> rs;
     DevBuf<float> h2, d2, d1; DevBuf<int> inv, perm1;
-    std::vector<float> h_h2, h_d2, h_ones; std::vector<int> h_perm1, h_inv;
+    std::vector<float> h_h2, h_d2; std::vector<int> h_perm1, h_inv;   // host copies of the fit, fetched on demand
+    bool host_fit_valid = false;
+    std::shared_ptr<const FitPlan> fit_plan;   // keeps the device copy of the plan alive while the fit kernels may run
+    DevBuf<double> sse;
     // scratch
     DevBuf<uint16_t> packed;            // sdh_scan_fetch_packed: converted idx / val / row_scale
     DevBuf<int> rows, perms, cols; DevBuf<FitJob> jobs; DevBuf<double> dbl, dbl2; DevBuf<float> xs, v, gat, wsd;
@@ -1062,8 +1159,13 @@ static std::shared_ptr<const Normals> draw_normals(std::mt19937 & rng, int64_t n
             g_normal_misses++; g_normal_miss_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); } } mt{t0};
         auto out = std::make_shared<Normals>();
         out->v.resize((size_t) n);
-        std::normal_distribution<float> nd(0.0f, 1.0f);
-        for (int64_t i = 0; i < n; ++i) out->v[(size_t) i] = nd(g);
+        static const bool std_draws = getenv("SDH_SCAN_STD_NORMALS") != nullptr;        // A/B: the library template
+        if (std_draws) {
+            std::normal_distribution<float> nd(0.0f, 1.0f);
+            for (int64_t i = 0; i < n; ++i) out->v[(size_t) i] = nd(g);
+        } else {
+            fast_normals(g, n, out->v.data());
+        }
         return std::shared_ptr<const Normals>(out);
     });
 }
@@ -1071,6 +1173,28 @@ static std::shared_ptr<const Normals> draw_normals(std::mt19937 & rng, int64_t n
 // RNG consumption of the base fit (sd_eval.cpp:557-651), with or without the work
 struct FitPlan {
     std::vector<FitJob> jobs; std::vector<int> rows; std::vector<int> perms;
+    // device copy of the three arrays (jobs | rows | perms in one allocation), made on first use and shared by
+    // every handle: the plan of a tensor kind is the same for every layer of a sweep. Freed with the plan.
+    mutable std::mutex mu;
+    mutable unsigned char * dev = nullptr;
+    mutable const FitJob * jobs_dev = nullptr; mutable const int * rows_dev = nullptr, * perms_dev = nullptr;
+    FitPlan() = default;
+    FitPlan(FitPlan && o) noexcept : jobs(std::move(o.jobs)), rows(std::move(o.rows)), perms(std::move(o.perms)) {}
+    bool device() const {
+        std::lock_guard<std::mutex> lock(mu);
+        if (dev) return true;
+        const size_t nj = (jobs.size() * sizeof(FitJob) + 255) & ~(size_t) 255, nr = (rows.size() * sizeof(int) + 255) & ~(size_t) 255,
+                     np = perms.size() * sizeof(int);
+        unsigned char * p = nullptr;
+        if (hipMalloc((void **) &p, nj + nr + np + 256) != hipSuccess) return false;
+        if (hipMemcpy(p, jobs.data(), jobs.size() * sizeof(FitJob), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(p + nj, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(p + nj + nr, perms.data(), np, hipMemcpyHostToDevice) != hipSuccess) { (void) hipFree(p); return false; }
+        jobs_dev = (const FitJob *) p; rows_dev = (const int *) (p + nj); perms_dev = (const int *) (p + nj + nr);
+        dev = p;
+        return true;
+    }
+    ~FitPlan() { if (dev) (void) hipFree(dev); }
 };
 
 static FitPlan plan_fit_draw(std::mt19937 & rng, int64_t n_in, int64_t n_out, int64_t L, int64_t B, int64_t max_samples, int trials) {
@@ -1217,6 +1341,18 @@ int sdh_imatrix_scale(const float * imatrix, int64_t n_in, float eps, float powe
     return SDH_OK;
 }
 
+// test hook: n normals after `skip` raw draws of mt19937(seed), by fast_normals (out_fast) and by the standard
+// library's normal_distribution (out_std); returns 1 when the two generators end in the same state
+int sdh_test_normals(uint32_t seed, int64_t skip, int64_t n, float * out_fast, float * out_std) {
+    if (n < 0 || skip < 0 || !out_fast || !out_std) return -1;
+    std::mt19937 a(seed), b(seed);
+    a.discard((unsigned long long) skip); b.discard((unsigned long long) skip);
+    fast_normals(a, n, out_fast);
+    std::normal_distribution<float> nd(0.0f, 1.0f);
+    for (int64_t i = 0; i < n; ++i) out_std[i] = nd(b);
+    return a == b ? 1 : 0;
+}
+
 int sdh_scan_create(uint32_t seed, sdh_scan ** out) {
     if (!out) { set_error("sdh_scan_create: null argument"); return SDH_ERR_INVALID; }
     if (!lib().inited) { set_error("sdh_init() has not been called"); return SDH_ERR_NO_DEVICE; }
@@ -1333,7 +1469,8 @@ static int scan_grid_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * 
         const std::shared_ptr<const FitPlan> plp = plan_fit(s.rng, n_in, n_out, L, B, p.base_max_samples, p.base_perm_trials);
         const FitPlan & pl = *plp;
         const int n_jobs = (int) pl.jobs.size();
-        if ((rc = s.jobs.put(pl.jobs, st)) || (rc = s.rows.put(pl.rows, st)) || (rc = s.perms.put(pl.perms, st))) return rc;
+        if (!pl.device()) { set_error("scan: upload of the fit plan failed"); return SDH_ERR_HIP; }
+        s.fit_plan = plp;
         if ((rc = s.dbl.ensure((size_t) n_jobs * 3 * L))) return rc;
         const int threads = 256;
         if (L < threads) { set_error("scan: base block length %lld < 256 not supported on the GPU path", (long long) L); return SDH_ERR_UNSUPPORTED; }
@@ -1351,57 +1488,29 @@ static int scan_grid_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * 
             if (!attr_ok) { set_error("scan: raising the dynamic LDS limit failed"); return SDH_ERR_HIP; }
             if (fit_256)
                 hipLaunchKernelGGL(scan_fit_lds_q8_kernel<256>, dim3((unsigned) (L / 256), (unsigned) n_jobs), dim3(256), fit_lds, st,
-                                   W, (int) L, tall ? 1 : 0, s.jobs.p, s.rows.p, s.perms.p, ws_dev, s.dbl.p);
+                                   W, (int) L, tall ? 1 : 0, pl.jobs_dev, pl.rows_dev, pl.perms_dev, ws_dev, s.dbl.p);
             else
                 hipLaunchKernelGGL(scan_fit_lds_q8_kernel<1024>, dim3((unsigned) (L / 1024), (unsigned) n_jobs), dim3(1024), fit_lds, st,
-                                   W, (int) L, tall ? 1 : 0, s.jobs.p, s.rows.p, s.perms.p, ws_dev, s.dbl.p);
+                                   W, (int) L, tall ? 1 : 0, pl.jobs_dev, pl.rows_dev, pl.perms_dev, ws_dev, s.dbl.p);
         } else {
             SDH_LAUNCH_DT(W, scan_fit_kernel, dim3((unsigned) (L / threads), (unsigned) n_jobs), dim3(threads),
-                          (size_t) L * sizeof(int), st, W, (int) L, tall ? 1 : 0, s.jobs.p, s.rows.p, s.perms.p, ws_dev, s.dbl.p);
+                          (size_t) L * sizeof(int), st, W, (int) L, tall ? 1 : 0, pl.jobs_dev, pl.rows_dev, pl.perms_dev, ws_dev, s.dbl.p);
         }
         SDH_HIP_CHECK(hipGetLastError());
-        const size_t n_sums = (size_t) n_jobs * 3 * L;
-        if (s.h_dbl.size() < n_sums) s.h_dbl.resize(n_sums);
-        const double * sums = s.h_dbl.data();
-        SDH_HIP_CHECK(hipMemcpyAsync(s.h_dbl.data(), s.dbl.p, n_sums * sizeof(double), hipMemcpyDeviceToHost, st));
-        SDH_HIP_CHECK(hipStreamSynchronize(st));
-        s.h_h2.assign((size_t) (L * B), 0.0f); s.h_d2.assign((size_t) (L * B), 0.0f);
-        s.h_perm1.assign((size_t) (L * B), 0);  s.h_inv.assign((size_t) (L * B), 0);
-        std::vector<double> best((size_t) B, INFINITY);
-        std::vector<float> h2((size_t) L);
-        for (int j = 0; j < n_jobs; ++j) {                     // jobs are in (block, trial) order
-            const double * sm = sums + (size_t) j * 3 * L, * sm2 = sm + L, * wg = sm2 + L;
-            double sse = 0.0;
-            for (int64_t u = 0; u < L; ++u) {
-                h2[(size_t) u] = 0.0f;
-                if (wg[u] > 0.0) {
-                    h2[(size_t) u] = (float) (sm[u] / wg[u]);
-                    sse += std::max(sm2[u] - (sm[u] * sm[u]) / wg[u], 0.0);
-                }
-            }
-            const int b = pl.jobs[(size_t) j].b;
-            if (sse < best[(size_t) b]) {
-                best[(size_t) b] = sse;
-                std::copy(h2.begin(), h2.end(), s.h_h2.begin() + (size_t) b * L);
-                std::copy(pl.perms.begin() + pl.jobs[(size_t) j].perm_off, pl.perms.begin() + pl.jobs[(size_t) j].perm_off + L,
-                          s.h_perm1.begin() + (size_t) b * L);
-            }
-        }
-        for (int64_t b = 0; b < B; ++b) {
-            if (best[(size_t) b] == INFINITY) continue;        // block without rows / inputs: stays zero
-            std::vector<float> d2(s.h_h2.begin() + (size_t) b * L, s.h_h2.begin() + (size_t) (b + 1) * L);
-            host_fwht(d2);
-            const float inv_L = 1.0f / (float) L;
-            for (int64_t u = 0; u < L; ++u) s.h_d2[(size_t) (b * L + u)] = d2[(size_t) u] * inv_L;
-            for (int64_t i = 0; i < L; ++i) {
-                const int src = s.h_perm1[(size_t) (b * L + i)];
-                if (src >= 0 && src < (int) L) s.h_inv[(size_t) (b * L + src)] = (int) i;
-            }
-        }
-        if ((rc = s.h2.put(s.h_h2, st)) || (rc = s.inv.put(s.h_inv, st)) || (rc = s.d2.put(s.h_d2, st)) ||
-            (rc = s.perm1.put(s.h_perm1, st))) return rc;
-        s.h_ones.assign((size_t) (L * B), 1.0f);               // D1 = I in the fit (sd_eval.cpp:450)
-        if ((rc = s.d1.put(s.h_ones, st))) return rc;
+        // the tail — best trial per block, h2, d2 = FWHT(h2)/L, perm1 and its inverse — stays on the device: the
+        // candidate runs through to its metric passes without a synchronisation (host copies: fetch_fit_host)
+        const size_t n_fit = (size_t) (L * B);
+        if ((rc = s.sse.ensure((size_t) n_jobs)) || (rc = s.h2.ensure(n_fit)) || (rc = s.d2.ensure(n_fit)) || (rc = s.perm1.ensure(n_fit)) ||
+            (rc = s.inv.ensure(n_fit)) || (rc = s.d1.ensure(n_fit))) return rc;
+        static const bool tail_attr_ok =
+            hipFuncSetAttribute((const void *) scan_fit_sse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8) == hipSuccess &&
+            hipFuncSetAttribute((const void *) scan_fit_pick_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4) == hipSuccess;
+        if (!tail_attr_ok) { set_error("scan: raising the dynamic LDS limit failed"); return SDH_ERR_HIP; }
+        hipLaunchKernelGGL(scan_fit_sse_kernel, dim3((unsigned) n_jobs), dim3(256), (size_t) L * 8, st, s.dbl.p, (int) L, s.sse.p);
+        hipLaunchKernelGGL(scan_fit_pick_kernel, dim3((unsigned) B), dim3(256), (size_t) L * 4, st, s.dbl.p, s.sse.p, pl.jobs_dev, n_jobs,
+                           pl.perms_dev, (int) L, s.h2.p, s.d2.p, s.perm1.p, s.inv.p, s.d1.p);
+        SDH_HIP_CHECK(hipGetLastError());
+        s.host_fit_valid = false;
         bv.h2 = s.h2.p; bv.inv = s.inv.p; bv.L = (int) L; bv.B = (int) B; bv.tall = tall ? 1 : 0; bv.log2L = 0; while ((1 << bv.log2L) < bv.L) ++bv.log2L;
         s.fit_of = (const void *) Wh;
     }
@@ -1759,6 +1868,20 @@ static int sdh_scan_pick_impl(sdh_scan * h, int j) {
     return SDH_OK;
 }
 
+// host copies of the last fit (the builder's staging of base_d2 / base_h2 / base_perm1), made when first asked for
+static int fetch_fit_host(Scan & s) {
+    if (s.host_fit_valid) return SDH_OK;
+    const size_t n = (size_t) (s.L * s.B);
+    s.h_h2.resize(n); s.h_d2.resize(n); s.h_perm1.resize(n); s.h_inv.resize(n);
+    SDH_HIP_CHECK(hipMemcpyAsync(s.h_h2.data(), s.h2.p, n * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+    SDH_HIP_CHECK(hipMemcpyAsync(s.h_d2.data(), s.d2.p, n * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+    SDH_HIP_CHECK(hipMemcpyAsync(s.h_perm1.data(), s.perm1.p, n * sizeof(int), hipMemcpyDeviceToHost, s.stream));
+    SDH_HIP_CHECK(hipMemcpyAsync(s.h_inv.data(), s.inv.p, n * sizeof(int), hipMemcpyDeviceToHost, s.stream));
+    SDH_HIP_CHECK(hipStreamSynchronize(s.stream));
+    s.host_fit_valid = true;
+    return SDH_OK;
+}
+
 static int sdh_scan_fetch_impl(sdh_scan * h, int32_t * idx, float * val, float * row_scale,
                    float * d2, float * h2, int32_t * perm1, int32_t * perm1_inv) {
     if (!h) { set_error("sdh_scan_fetch: null handle"); return SDH_ERR_INVALID; }
@@ -1781,6 +1904,8 @@ static int sdh_scan_fetch_impl(sdh_scan * h, int32_t * idx, float * val, float *
     SDH_HIP_CHECK(hipStreamSynchronize(st));
     if (d2 || h2 || perm1 || perm1_inv) {
         if (!s.has_base) { set_error("sdh_scan_fetch: candidate had no base"); return SDH_ERR_INVALID; }
+        int rc;
+        if ((rc = fetch_fit_host(s))) return rc;
         const size_t n = (size_t) (s.L * s.B);
         if (d2) std::memcpy(d2, s.h_d2.data(), n * sizeof(float));
         if (h2) std::memcpy(h2, s.h_h2.data(), n * sizeof(float));
@@ -1829,6 +1954,7 @@ static int sdh_scan_fetch_packed_impl(sdh_scan * h, int idx_type, void * idx, in
     SDH_HIP_CHECK(hipStreamSynchronize(st));
     if (d2_f16 || perm1) {
         if (!s.has_base) { set_error("sdh_scan_fetch_packed: candidate had no base"); return SDH_ERR_INVALID; }
+        if ((rc = fetch_fit_host(s))) return rc;
         const size_t n = (size_t) (s.L * s.B);
         if (d2_f16) for (size_t i = 0; i < n; ++i) d2_f16[i] = float_to_half(s.h_d2[i]);
         if (perm1) {

@@ -149,3 +149,19 @@ def test_report_document_has_the_builder_fields(script_golden):
         assert m["S_mean"] == 0.8 and m["ffn_proxy_available"] == (e["kind"] != "ffn_down")
     assert json.loads(SC.dumps(doc))["resid"]["K_down"] == 12
     assert SC.report_document(entries, SC.ScanParams(base=True))["base_kind"] == "xor_circulant"
+
+
+@pytest.mark.parametrize("seed,skip,n", [(1234, 0, 1), (1234, 3, 2), (7, 11, 7), (1234, 0, 32 * 4096), (99, 623, 100001), (5, 624, 32 * 14336)])
+def test_fast_normals_equal_the_standard_library(seed, skip, n):
+    """csrc/sdh_rng.h writes out libstdc++'s normal_distribution<float> over mt19937 (what eval_x and the FFN
+    proxy draw, sd_eval.cpp:1084-1087, sd_ffn_proxy.cpp:77-80); the library's test hook draws the same n values
+    both ways: identical bits, identical generator state afterwards. No GPU involved."""
+    import ctypes as C
+    from llama_cpp_amd import seeddelta as sd
+    lib = sd.load_library()
+    lib.sdh_test_normals.argtypes = [C.c_uint32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.sdh_test_normals.restype = C.c_int
+    a, b = np.empty(n, np.float32), np.empty(n, np.float32)
+    assert lib.sdh_test_normals(seed, skip, n, a.ctypes.data, b.ctypes.data) == 1
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert abs(float(a.mean())) < 5.0 / np.sqrt(n) + (1.0 if n < 100 else 0.0) * 3
