@@ -540,7 +540,18 @@ static int sdh_forward_impl(sdh_weight * h, const float * x, int64_t ldx, int64_
 
     // token chunking bounds the base-term workspace of the two-kernel path
     int64_t chunk = n_tokens;
-    const size_t per_tok = has_base ? (size_t) w->B * (size_t) w->L * 4 : 0;
+    size_t per_tok = has_base ? (size_t) w->B * (size_t) w->L * 4 : 0;
+    // the tiled MFMA form of the base term (SDH_FWD_W0_MFMA): tall payloads write Y0 straight into y and need only
+    // the f16 image of x as workspace; wide ones keep the [T][B][L] partial products as well. SDH_W0_MFMA_V1 (A/B):
+    // the first form, one fragment per lane from global memory. Not on the no-alloc entry point (its scratch is 8 MB).
+    static const bool mfma_v1 = getenv("SDH_W0_MFMA_V1") != nullptr;
+    const bool mfma_tiled = has_base && (flags & SDH_FWD_W0_MFMA) && !(flags & SDH_FWD_EXACT_ORDER) && !noalloc && !mfma_v1 &&
+                            w->w0_closed_form && w->L >= 128 && n_tokens > MAX_FUSED_TOKENS;
+    size_t x16_per_tok = 0;
+    if (mfma_tiled) {
+        x16_per_tok = ((size_t) (w->n_in + 63) / 64 * 64 + 64) * 2;
+        if (w->tall) per_tok = 0;
+    }
     if (has_base) {
         const size_t cap = noalloc ? ext_ws_bytes : (size_t) 512 << 20;
         if (noalloc && per_tok > cap) {
@@ -548,7 +559,8 @@ static int sdh_forward_impl(sdh_weight * h, const float * x, int64_t ldx, int64_
                       per_tok, cap);
             return SDH_ERR_TOO_LARGE;
         }
-        if (per_tok * (size_t) chunk > cap) chunk = (int64_t) (cap / per_tok);
+        if ((per_tok + x16_per_tok) * (size_t) chunk > cap) chunk = (int64_t) (cap / (per_tok + x16_per_tok));
+        if (mfma_tiled && chunk < n_tokens) chunk = std::max<int64_t>(256, chunk / 256 * 256);      // whole token tiles
         if (chunk < 1) chunk = 1;
     }
     LibState & ls = lib();
@@ -591,7 +603,15 @@ static int sdh_forward_impl(sdh_weight * h, const float * x, int64_t ldx, int64_
             }
             // rc == 1: not applicable; the opening event is simply re-recorded below
         }
-        if (has_base) {
+        if (mfma_tiled) {
+            const size_t part_bytes = per_tok * (size_t) chunk;                 // wide: [chunk][B][L] partial products
+            int rc = ensure_ws(w, part_bytes + w0_mfma_x16_bytes(*w, chunk));
+            if (rc != SDH_OK) return rc;
+            _Float16 * x16 = (_Float16 *) ((unsigned char *) w->ws + part_bytes);
+            if (w->tall) { rc = launch_w0_mfma_tiled(*w, xc, dldx, tc, x16, a.y, a.ldy, s); a.v = a.y; a.v_ld = a.ldy; }
+            else         { rc = launch_w0_mfma_tiled(*w, xc, dldx, tc, x16, w->ws, (int64_t) w->B * w->L, s); a.v = w->ws; }
+            if (rc != SDH_OK) { if (rc == 1) set_error("w0 mfma: payload does not fit the tile scheme"); return rc == 1 ? SDH_ERR_UNSUPPORTED : rc; }
+        } else if (has_base) {
             int rc = noalloc ? SDH_OK : ensure_ws(w, per_tok * (size_t) chunk);
             if (rc != SDH_OK) return rc;
             float * const ws = noalloc ? ext_ws : w->ws;

@@ -29,7 +29,7 @@ namespace sdh {
 // base term of output (o, t) read from the base kernel's scratch
 __device__ __forceinline__ float base_term(const DeltaParams & p, int o, int64_t t) {
     if (!p.v) return 0.0f;
-    const float * vt = p.v + (size_t) t * p.B * p.L;
+    const float * vt = p.v + (size_t) t * (size_t) p.v_ld;
     if (p.tall) return vt[o];                       // b*L + (o - b*L) == o
     float yh = 0.0f;
     for (int b = 0; b < p.B; ++b) yh += vt[(size_t) b * p.L + o];
@@ -55,7 +55,7 @@ void delta_rows_kernel(const DeltaParams p) {
     const int nbase = p.v ? (p.tall ? 1 : p.B) : 0;
     if (leader) {
         if (p.rs) scale = p.rs[o];
-        const float * vt = p.v + (size_t) t * p.B * p.L;
+        const float * vt = p.v + (size_t) t * (size_t) p.v_ld;
 #pragma unroll
         for (int b = 0; b < 8; ++b) vb[b] = (b < nbase) ? vt[(size_t) b * p.L + o] : 0.0f;
     }
@@ -69,7 +69,7 @@ void delta_rows_kernel(const DeltaParams p) {
             else {
 #pragma unroll
                 for (int b = 0; b < 8; ++b) if (b < nbase) yh += vb[b];
-                for (int b = 8; b < nbase; ++b) yh += p.v[((size_t) t * p.B + b) * p.L + o];
+                for (int b = 8; b < nbase; ++b) yh += p.v[(size_t) t * (size_t) p.v_ld + (size_t) b * p.L + o];
             }
         }
         store_output(p, o, t, yh + acc, scale);
@@ -200,6 +200,7 @@ DeltaParams make_delta_params(const DeviceWeight & w, const DeltaLaunch & a) {
     p.nb = (int) w.nb; p.block = (int) w.block;
     p.Ktot = is_block ? (int) (w.nb * w.block) : (int) w.K;
     p.L = (int) w.L; p.B = a.v_blocks > 0 ? a.v_blocks : (int) w.B; p.tall = w.tall ? 1 : 0;
+    p.v_ld = a.v_ld > 0 ? a.v_ld : (int64_t) p.B * p.L;
     p.G = 1;
     p.zero_nf = a.zero_nonfinite ? 1 : 0;
     p.x_vec_ok = (((uintptr_t) a.x % 16) == 0 && (a.ldx % 4) == 0) ? 1 : 0;

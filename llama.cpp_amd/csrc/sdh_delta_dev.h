@@ -21,7 +21,8 @@ struct DeltaParams {
     const float * rs;
     const float * x;
     float *       y;
-    const float * v;        // base scratch [T][B][L] or null
+    const float * v;        // base term [T][v_ld] (token t, block b, position p at t*v_ld + b*L + p) or null
+    int64_t v_ld;           // B*L for the base kernels' scratch; ldy when the base term already sits in y (in place)
     int *         nf;       // non-finite counter
     int64_t ldx, ldy;
     int n_in, n_out;

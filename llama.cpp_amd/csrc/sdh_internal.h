@@ -130,12 +130,17 @@ struct DeltaLaunch {
     bool zero_nonfinite;
     bool exact_order;
     int  v_blocks = 0;      // 0: v is [T][B][L] (FWHT form); 1: v is [T][L], base blocks already summed (MFMA form, wide)
+    int64_t v_ld = 0;       // 0: tokens are v_blocks*L (or B*L) apart; else the stride (the MFMA form, tall: the base term
+                            // is written straight into y and the residual kernel updates y in place, v == y, v_ld == ldy)
 };
 int launch_delta(const DeviceWeight & w, const DeltaLaunch & a, hipStream_t s);
 
 // Prefill: base term as W0 tiles regenerated in registers and contracted on MFMA (sdh_w0mfma.hip).
 // Returns SDH_OK if launched, 1 if the payload has no closed-form W0 (caller uses the FWHT form).
 int launch_w0_mfma(const DeviceWeight & w, const float * x, int64_t ldx, int64_t T, float * v_out, hipStream_t s);
+size_t w0_mfma_x16_bytes(const DeviceWeight & w, int64_t T);
+int launch_w0_mfma_tiled(const DeviceWeight & w, const float * x, int64_t ldx, int64_t T, _Float16 * x16_ws,
+                         float * out, int64_t ldo, hipStream_t s);
 
 // Prefill: token-tiled SpMM (sdh_spmm.hip). Returns SDH_OK if launched, 1 if the shape does not fit.
 int launch_delta_spmm(const DeviceWeight & w, const DeltaLaunch & a, hipStream_t s);

@@ -45,7 +45,7 @@ void delta_spmm_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
         const IDX_T * irow = reinterpret_cast<const IDX_T *>(p.idx) + (size_t) o * (BLOCK ? p.nb : p.Ktot);
         float y = 0.0f;
         if (p.v) {                                      // base term: tall picks, wide sums blocks in order
-            const float * vt = p.v + (size_t) tok * p.B * p.L;
+            const float * vt = p.v + (size_t) tok * (size_t) p.v_ld;
             if (p.tall) y = vt[o];
             else for (int b = 0; b < p.B; ++b) y += vt[(size_t) b * p.L + o];
         }
@@ -139,7 +139,7 @@ void delta_spmm4_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int64_t tok = t0 + ((tq + u < nt) ? tq + u : 0);
-                const float * vt = p.v + (size_t) tok * p.B * p.L;
+                const float * vt = p.v + (size_t) tok * (size_t) p.v_ld;
                 if (p.tall) y[u] = vt[o];
                 else for (int b = 0; b < p.B; ++b) y[u] += vt[(size_t) b * p.L + o];
             }

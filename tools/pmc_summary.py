@@ -15,7 +15,7 @@ def main():
         with open(path) as fh:
             for row in csv.DictReader(fh):
                 name = row["Kernel_Name"].split("(")[0].replace("void ", "")
-                if "sdh::" not in name:
+                if "sdh::" not in name and "3sdh" not in name:          # demangled or mangled
                     continue
                 acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
                 acc[name]["_dur_ns"].append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
