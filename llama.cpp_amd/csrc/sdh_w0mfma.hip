@@ -173,18 +173,26 @@ void w0_mfma_tile_kernel(const _Float16 * __restrict__ x16, int64_t ld16, int64_
     // the gathers of a slab depend on its inv entries: those are loaded one slab earlier still (fetch_idx for slab
     // s+3 at the top of slab s, right after the gathers of slab s+2 have used the previous ones), so that no wave
     // sits out a dependent load chain before its MFMAs
+    // One vector load (lane j & 7 reads entry j; unconditional: a slab's 64 columns lie inside the block's L table
+    // entries even where they are past q_len — those columns are blanked through d1q — and a slab index past the end
+    // is clamped). Not scalar loads: eight conditional one-word s_loads cost a round trip each (~1600 cycles per slab),
+    // and any scalar load in flight turns every LDS wait of the wave into lgkmcnt(0).
+    int ivl = 0;
     auto fetch_idx = [&](int s) {
-        const int q0 = s * MT_K + wave * 8;                       // this wave's 8 columns of the slab
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ivq[j] = (s < n_slab && q0 + j < q_len) ? (unsigned) inv[pb + q0 + j] << 2 : 0u;   // wave-uniform
+        const int q0 = min(s, n_slab - 1) * MT_K + wave * 8;      // this wave's 8 columns of the slab
+        ivl = inv[pb + q0 + (lane & 7)];
     };
     auto fetch = [&](auto set_c, int s) {
         constexpr int S = decltype(set_c)::value;
         const int q0 = s * MT_K + wave * 8;
+        float dl = 1.0f;
+        if constexpr (SCALED) dl = d1[pb + q0 + (lane & 7)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ivq[j] = (unsigned) __builtin_amdgcn_readlane(ivl, j) << 2;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             // a zero d1 blanks a column past the end of the block's inputs
-            d1q[S][j] = q0 + j < q_len ? (SCALED ? d1[pb + q0 + j] : 1.0f) : 0.0f;
+            d1q[S][j] = q0 + j < q_len ? (SCALED ? __shfl(dl, j, 64) : 1.0f) : 0.0f;
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) gq[S][rr][j] = *reinterpret_cast<const float *>(Gb + (rowoff[rr] ^ ivq[j]));
         }
