@@ -144,12 +144,15 @@ void delta_spmm4_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
                 else for (int b = 0; b < p.B; ++b) y[u] += vt[(size_t) b * p.L + o];
             }
         }
+        // two tokens per instruction: v_pk_mul_f32 / v_pk_add_f32 round each component as the scalar forms do
+        // (contraction is off), so the sums keep the CPU op's bits at half the multiply and add instructions
+        typedef float float2v __attribute__((ext_vector_type(2)));
+        float2v y01 = {y[0], y[1]}, y23 = {y[2], y[3]};
         auto mac = [&](float v, const float4 x) {
-            float pr;
-            pr = v * x.x; y[0] = y[0] + pr;
-            pr = v * x.y; y[1] = y[1] + pr;
-            pr = v * x.z; y[2] = y[2] + pr;
-            pr = v * x.w; y[3] = y[3] + pr;
+            const float2v vv = {v, v}, x01 = {x.x, x.y}, x23 = {x.z, x.w};
+            const float2v p01 = vv * x01, p23 = vv * x23;
+            y01 = y01 + p01;
+            y23 = y23 + p23;
         };
         if constexpr (BLOCK) {
             for (int bi = 0; bi < p.nb; ++bi) {
@@ -172,11 +175,16 @@ void delta_spmm4_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
                 }
             }
         } else {
+            // the next 8 entries are requested before the current 8 are used: with one workgroup per CU (the tile fills
+            // the LDS) only four waves per SIMD stand behind a step's L2 round trip
+            Vec8<IDX_T> ii_n;
+            Vec8<VAL_T> vv_n;
+            ii_n.load(irow);
+            vv_n.load(vrow);
             for (int e = 0; e < p.Ktot; e += 8) {
-                Vec8<IDX_T> ii;
-                Vec8<VAL_T> vv;
-                ii.load(irow + e);
-                vv.load(vrow + e);
+                const Vec8<IDX_T> ii = ii_n;
+                const Vec8<VAL_T> vv = vv_n;
+                if (e + 8 < p.Ktot) { ii_n.load(irow + e + 8); vv_n.load(vrow + e + 8); }
                 int ix[8];
                 bool all_ok = true;
 #pragma unroll
@@ -194,6 +202,7 @@ void delta_spmm4_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
             }
         }
         const float scale = p.rs ? p.rs[o] : 1.0f;
+        y[0] = y01[0]; y[1] = y01[1]; y[2] = y23[0]; y[3] = y23[1];
 #pragma unroll
         for (int u = 0; u < 4; ++u) if (tq + u < nt) store_output(p, o, t0 + tq + u, y[u], scale);
     }
