@@ -18,6 +18,21 @@
 
 namespace sdh {
 
+// Row of input i in the LDS tile. COO: i. Block scheme: one spare row after every block, i + i / block — the rows a
+// wave works on start their blocks at in0 * TT * 4 bytes, and with block * TT * 4 a multiple of the 256-byte bank
+// cycle (block 16 or 32, TT 8) every lane of a pass hit the same banks (rocprof: 87 % of the LDS cycles of a
+// Mistral gate block16 ubatch were bank conflicts, 8-way). With the spare row the start bank follows blk mod 8,
+// as scattered as the COO gathers are.
+template <bool BLOCK>
+__device__ __forceinline__ int tile_row(const DeltaParams & p, int i) {
+    if constexpr (!BLOCK) return i;
+    return i + (p.block_shift >= 0 ? (i >> p.block_shift) : (i / p.block));
+}
+template <bool BLOCK>
+static size_t spmm_tile_rows(const DeltaParams & p) {
+    return BLOCK ? (size_t) p.n_in + (size_t) ((p.n_in + p.block - 1) / p.block) : (size_t) p.n_in;
+}
+
 template <typename IDX_T, typename VAL_T, bool BLOCK, bool VEC, int TT>
 __global__ __launch_bounds__(1024)
 void delta_spmm_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
@@ -28,11 +43,11 @@ void delta_spmm_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
     const int nt = (int) ((T - t0 < TT) ? (T - t0) : TT);
     for (int t = 0; t < nt; ++t) {
         const float * xt = p.x + (t0 + t) * p.ldx;
-        for (int i = tid; i < p.n_in; i += 1024) xs[i * TT + t] = xt[i];
+        for (int i = tid; i < p.n_in; i += 1024) xs[tile_row<BLOCK>(p, i) * TT + t] = xt[i];
     }
     if (nt < TT) {                                      // ragged last tile: idle lanes read zeros
         for (int i = tid; i < p.n_in; i += 1024)
-            for (int t = nt; t < TT; ++t) xs[i * TT + t] = 0.0f;
+            for (int t = nt; t < TT; ++t) xs[tile_row<BLOCK>(p, i) * TT + t] = 0.0f;
     }
     __syncthreads();
 
@@ -56,7 +71,7 @@ void delta_spmm_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
                 if (blk < 0 || in0 >= p.n_in) continue;             // uniform over the TT lanes of the row
                 const int len = (int) ((in0 + p.block < p.n_in) ? p.block : (p.n_in - in0));
                 const VAL_T * vb = vrow + (size_t) bi * p.block;
-                const float * xb = xs + (size_t) in0 * TT + t;
+                const float * xb = xs + (size_t) (in0 + blk) * TT + t;      // tile_row(in0 + j) = in0 + blk + j inside the block
                 if constexpr (VEC) {
                     for (int j = 0; j < p.block; j += 8) {
                         Vec8<VAL_T> vv;
@@ -120,11 +135,11 @@ void delta_spmm4_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
     const int nt = (int) ((T - t0 < TT) ? (T - t0) : TT);
     for (int t = 0; t < nt; ++t) {
         const float * xt = p.x + (t0 + t) * p.ldx;
-        for (int i = tid; i < p.n_in; i += 1024) xs[i * TT + t] = xt[i];
+        for (int i = tid; i < p.n_in; i += 1024) xs[tile_row<BLOCK>(p, i) * TT + t] = xt[i];
     }
     if (nt < TT) {
         for (int i = tid; i < p.n_in; i += 1024)
-            for (int t = nt; t < TT; ++t) xs[i * TT + t] = 0.0f;
+            for (int t = nt; t < TT; ++t) xs[tile_row<BLOCK>(p, i) * TT + t] = 0.0f;
     }
     __syncthreads();
 
@@ -161,7 +176,7 @@ void delta_spmm4_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
                 if (blk < 0 || in0 >= p.n_in) continue;
                 const int len = (int) ((in0 + p.block < p.n_in) ? p.block : (p.n_in - in0));
                 const VAL_T * vb = vrow + (size_t) bi * p.block;
-                const float4 * xb = xq + (size_t) in0 * LPR;
+                const float4 * xb = xq + (size_t) (in0 + blk) * LPR;        // tile_row(in0 + j) = in0 + blk + j inside the block
                 for (int j = 0; j < p.block; j += 8) {
                     Vec8<VAL_T> vv;
                     vv.load(vb + j);
@@ -210,7 +225,7 @@ void delta_spmm4_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
 
 template <typename IDX_T, typename VAL_T, bool BLOCK, bool VEC, int TT>
 static int launch_tt(const DeltaParams & p, int64_t T, hipStream_t s) {
-    const size_t lds = (size_t) p.n_in * TT * sizeof(float);
+    const size_t lds = spmm_tile_rows<BLOCK>(p) * TT * sizeof(float);
     static const bool one_token = getenv("SDH_SPMM_ONE_TOKEN") != nullptr;      // dev: A/B against the four-token form
     void (*kern)(const DeltaParams, int64_t, int) = delta_spmm_kernel<IDX_T, VAL_T, BLOCK, VEC, TT>;
     int lanes_per_row = TT;
@@ -238,7 +253,7 @@ static int launch_tt(const DeltaParams & p, int64_t T, hipStream_t s) {
 template <typename IDX_T, typename VAL_T, bool BLOCK, bool VEC>
 static int launch_vec(const DeltaParams & p, int64_t T, hipStream_t s) {
     const size_t budget = 152 * 1024;                   // LDS for the tile, leaving headroom
-    const size_t col = (size_t) p.n_in * sizeof(float);
+    const size_t col = spmm_tile_rows<BLOCK>(p) * sizeof(float);
     if (col * 16 <= budget / 2 && T >= 16) return launch_tt<IDX_T, VAL_T, BLOCK, VEC, 16>(p, T, s);   // two workgroups per CU
     if (col * 8 <= budget) return launch_tt<IDX_T, VAL_T, BLOCK, VEC, 8>(p, T, s);
     // narrower tiles re-stream the payload T/TT times: measured on MI355X (T=512, n_in=14336) the COO
