@@ -5,9 +5,10 @@ cfg4 (Mistral-7B gate / down, COO and block16, K=128), cfg2 (Gemma-3 4B gate COO
 Which kernel each shape takes (csrc/sdh_spmm.hip launch_vec, by bytes of one activation column in LDS):
     n_in <= 1216           TT=16 four-token form   (covered at small dims in test_gpu_forward.py)
     n_in <= 4864           TT=8  four-token form   cfg4 gate COO / block16, cfg2 gate COO
-    n_in <= 9728, COO      TT=4  four-token form   the 6912 -> 1152 payload below
-    n_in <= 19456, COO     TT=2  one-token form    cfg4 down COO
-    block, n_in > 4864     per-token row kernels   cfg4 down block16, cfg3
+    n_in <= 9728           TT=4  four-token form   the 6912 -> 1152 payload below
+    n_in <= 19456          TT=2  one-token form    cfg4 down COO, cfg4 down block16
+    block, narrow tile and more than 256 values per row: per-token row kernels   cfg3
+(a block payload's tile holds one spare row per block, n_in + n_in / block rows, so its limits sit that much lower)
 The SpMM kernels accumulate each (row, token) in the CPU op's order with separately rounded multiply and add
 (src/llama-seeddelta.cpp:1088-1175, :1178-1360), so the default path must equal the oracle BIT FOR BIT there;
 the per-token row kernels (and SDH_FWD_NO_SPMM everywhere) keep the fast-path tolerance of
@@ -28,7 +29,7 @@ pytestmark = pytest.mark.gpu
 T = 512
 SPMM_EXACT = {      # workload -> True when the default path at T=512 is a bit-exact SpMM kernel
     "cfg4_mistral_gate_coo_k128": True, "cfg4_mistral_gate_block16_k128": True, "cfg4_mistral_down_coo_k128": True,
-    "cfg4_mistral_down_block16_k128": False, "cfg2_gemma4b_gate_coo_k128": True, "cfg3_mistral_down_block32_k1536": False,
+    "cfg4_mistral_down_block16_k128": True, "cfg2_gemma4b_gate_coo_k128": True, "cfg3_mistral_down_block32_k1536": False,
 }
 _cache = {}
 
