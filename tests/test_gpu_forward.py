@@ -385,12 +385,14 @@ def test_prefill_spmm_dtypes_and_bad_indices(hip):
             assert np.array_equal(bits(w.forward_host(x)), bits(O.forward(p, x, nth=4))), (idx_dtype, val_dtype, scheme)
 
 
-@pytest.mark.parametrize("dims", [(256, 1024), (1024, 256), (1152, 864), (864, 1152)])
+@pytest.mark.parametrize("dims", [(256, 1024), (1024, 256), (1152, 864), (864, 1152), (320, 1000), (1000, 320)])
 @pytest.mark.parametrize("scheme", ["coo", "block"])
-@pytest.mark.parametrize("T", [5, 40, 130])
+@pytest.mark.parametrize("T", [5, 40, 130, 300])
 def test_prefill_w0_mfma_path(hip, dims, scheme, T):
-    """SDH_FWD_W0_MFMA: the base as W0 fragments regenerated in registers (closed form, fp32) and
-    contracted in f16 on MFMA with fp32 accumulation. f16 operands: each product carries up to
+    """SDH_FWD_W0_MFMA: the base as a tiled GEMM (W0 and f16 x tiles in LDS; L >= 128, more than 4 tokens) or, for
+    short base blocks, as W0 fragments regenerated in registers — closed form in fp32, contracted in f16 on MFMA with
+    fp32 accumulation. Shapes with ragged row tiles (n_out % 128), ragged K slabs (n_in % 64), partial last base
+    blocks and ragged token tiles (T % 256), d1/d3 not all ones. f16 operands: each product carries up to
     2 * 2^-11 relative error, so |y - y_ref| <= 1.5e-3 * |rs| * sum_i |W0[o,i] x[i]| + the fast-path
     tolerance of the residual."""
     n_in, n_out = dims
