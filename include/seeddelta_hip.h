@@ -296,7 +296,13 @@ typedef struct sdh_scan_params {
                                        entry is identical (eval_* and the proxy read nothing else, sd_eval.cpp:138,
                                        :1052, sd_ffn_proxy.cpp:60-75) and no payload is kept. This is the layer-scan /
                                        autogate use, where the builder's output GGUF is discarded.              */
-    int32_t reserved0;
+    int32_t kgrid_draws;        /* sdh_scan_tensor_kgrid only: 0 = every K is a builder run of its own with the same seed
+                                       (a layer-scan K grid: all K see the same draws, the generator advances once);
+                                       1 = the K are the trials of ONE builder run's autotune schedule
+                                       (sd_build.cpp:843-913): trial j draws its eval samples after trial j-1's. outs[j]
+                                       then equals sdh_scan_tensor calls in sequence on the handle (base_mode 1 from the
+                                       second on); the generator ends after the last trial and sdh_scan_rewind(j) puts it
+                                       where a builder that stopped after trial j would be.                      */
     double  delta_norm_clamp_down; /* (--delta-norm-clamp-down, default 0 = off) ffn_down, COO only: if the L2 norm
                                        of all residual values exceeds clamp * ||W||_2 they are scaled down to it
                                        before the metrics are taken (sd_build.cpp:29-46, :384-386, :705-720).
@@ -365,6 +371,9 @@ int  sdh_scan_tensor_kgrid(sdh_scan * s, const sdh_dense * W, const sdh_dense * 
 /* Choose the member j of the last schedule that sdh_scan_fetch / sdh_scan_fetch_packed return (after
  * sdh_scan_tensor_kgrid: the last one; after sdh_scan_tensor there is only member 0). */
 int  sdh_scan_pick(sdh_scan * s, int j);
+/* After sdh_scan_tensor_kgrid with kgrid_draws = 1: set the generator to its state after trial j (the autotune loop
+ * breaks at the first trial that passes its gate and draws nothing for the later ones, sd_build.cpp:905-913). */
+int  sdh_scan_rewind(sdh_scan * s, int j);
 /* Advance the RNG as sdh_scan_tensor would for a tensor of these dims, without touching the GPU:
  * lets a rank that owns (layer, ffn_up) reproduce the stream position after ffn_gate (sharding). */
 int  sdh_scan_skip(sdh_scan * s, int64_t n_in, int64_t n_out, const sdh_scan_params * p);

@@ -933,6 +933,8 @@ struct Scan {
     int64_t n_in = 0, n_out = 0, K = 0, block = 0, L = 0, B = 0;     // K: idx entries per row of the candidate sdh_scan_fetch returns
     int64_t ld = 0;                     // idx entries per row as stored (the largest K of the last schedule)
     int     kg_n = 1, pick = 0;         // K schedule of the last call and the member sdh_scan_fetch* returns
+    std::mt19937 rng_after[SDH_SCAN_MAX_K];   // generator after each trial of the last call (sequential draws), else [0] only
+    int     n_after = 0;
     int64_t kg_ksel[SDH_SCAN_MAX_K] = {0};
     int scheme = 0; bool has_base = false, has_rs = false;
     bool emitted = false;               // the last candidate selected every row (sdh_scan_fetch can return the payload)
@@ -1630,14 +1632,22 @@ static int scan_grid_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * 
         std::vector<float> scaled;            // kind 1 with x_scale_host
         int row0 = 0, nr = 0, nx = 0;         // position in the concatenated row list = first compact slot
         size_t out0 = 0;                      // first double of its results in s.dbl
+        int j = -1;                           // -1: one pass serves every K of the schedule (shared draws); else the pass of trial j
+        size_t xs0 = 0;                       // kind 1 with x_scale_host: first float of its scaled inputs in s.xs
+        int nkp = 1;                          // K entries it evaluates: nK or 1
     };
+    // seq: one builder run whose trials follow each other (the autotune loop, sd_build.cpp:843-913): trial j draws its
+    // eval samples after trial j-1's; the generator state after every trial is kept for sdh_scan_rewind
+    const bool seq = p.kgrid_draws == 1 && nK > 1;
     ph.reset(); ph.reset(new PhaseTimer(s.t_phase[2]));
     std::vector<Pass> passes;
     for (int j = 0; j < nK; ++j) outs[j].has_w = ws_dev ? 1 : 0;
     auto o5_of = [](sdh_scan_result & r, int which) { return which == 0 ? r.em : which == 1 ? r.em_w : which == 2 ? r.em_x : r.em_x_w; };
+    for (int jj = 0; jj < (seq ? nK : 1); ++jj) {
     if (p.eval_cols > 0) {
         for (int k = 0; k < (ws_dev ? 2 : 1); ++k) {
             Pass ps; ps.kind = 0; ps.ws_dev = k ? ws_dev : nullptr; ps.which = k ? 1 : 0;
+            ps.j = seq ? jj : -1; ps.nkp = seq ? 1 : nK;
             ps.rows = draw_rows(s.rng, n_out, p.eval_cols);
             passes.push_back(std::move(ps));
         }
@@ -1646,6 +1656,7 @@ static int scan_grid_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * 
         for (int j = 0; j < nK; ++j) outs[j].has_x = 1;
         for (int k = 0; k < (ws_dev ? 2 : 1); ++k) {
             Pass ps; ps.kind = 1; ps.x_scale_host = k ? p.w_scale : nullptr; ps.which = k ? 3 : 2;
+            ps.j = seq ? jj : -1; ps.nkp = seq ? 1 : nK;
             ps.rows = draw_rows(s.rng, n_out, p.eval_cols);
             ps.nx = (int) p.eval_x;
             ps.normals = draw_normals(s.rng, (int64_t) ps.nx * n_in);
@@ -1659,6 +1670,9 @@ static int scan_grid_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * 
             passes.push_back(std::move(ps));
         }
     }
+    s.rng_after[jj] = s.rng;
+    }
+    s.n_after = seq ? nK : 1;
     const bool want_proxy = p.want_proxy && p.scheme == 0 && !p.write_base && p.eval_x > 0 && p.kind != 2 && Wg && Wu && Wd;
     std::shared_ptr<const std::vector<int>> proxy_outs;
     int64_t proxy_cap = 0;
@@ -1666,7 +1680,7 @@ static int scan_grid_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * 
         const DenseView G = view_or_null(Wg), D = view_or_null(Wd);
         proxy_cap = p.eval_cols > 0 ? p.eval_cols : 128;
         std::mt19937 prng((uint32_t) p.proxy_seed);
-        Pass ps; ps.kind = 2;
+        Pass ps; ps.kind = 2; ps.nkp = nK;
         ps.rows = draw_rows(prng, G.n_out, std::min(G.n_out, proxy_cap));          // sampled hidden units
         proxy_outs = draw_rows(prng, D.n_out, std::min(D.n_out, proxy_cap));       // sampled outputs of W_down
         ps.nx = (int) std::min<int64_t>(p.eval_x, 128);
@@ -1679,15 +1693,18 @@ static int scan_grid_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * 
     if (!passes.empty()) {
         // rows of all passes, one upload; results of all passes, one buffer
         int total_rows = 0;
-        size_t total_dbl = 0, n_xpass = 0;
+        size_t total_dbl = 0, n_xpass = 0, total_xs = 0;
         Scan::ProxyTruth & pt = s.proxy_truth;
         bool have_truth = false;
         for (Pass & ps : passes) {
             ps.nr = (int) ps.rows->size();
             ps.row0 = total_rows; total_rows += ps.nr;
             ps.out0 = total_dbl;
-            if (ps.kind == 0) total_dbl += (size_t) ps.nr * 3 * nK;                          // [nK][nr][3]
-            else if (ps.kind == 1) { total_dbl += (size_t) ps.nr * ps.nx * (1 + nK); ++n_xpass; }   // truth, hat [nK]
+            if (ps.kind == 0) total_dbl += (size_t) ps.nr * 3 * ps.nkp;                      // [nkp][nr][3]
+            else if (ps.kind == 1) {                                                          // truth, hat [nkp]
+                total_dbl += (size_t) ps.nr * ps.nx * (1 + ps.nkp); ++n_xpass;
+                if (ps.x_scale_host) { ps.xs0 = total_xs; total_xs += ps.scaled.size(); }
+            }
             else {
                 const uint64_t id_g = ((const DeviceDense *) Wg)->serial, id_u = ((const DeviceDense *) Wu)->serial, id_d = ((const DeviceDense *) Wd)->serial;
                 have_truth = pt.g == id_g && pt.u == id_u && pt.d == id_d && pt.seed == (int64_t) p.proxy_seed && pt.cap == proxy_cap &&
@@ -1705,23 +1722,28 @@ static int scan_grid_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * 
         const int64_t rs_stride = metrics_only ? total_rows : n_out;      // slots of the selection launch
         const size_t v_per = (size_t) p.eval_x * (size_t) B * (size_t) L;
         if (p.write_base && n_xpass && (rc = s.v.ensure(n_xpass * v_per))) return rc;
+        if (total_xs && (rc = s.xs.ensure(total_xs))) return rc;      // every scaled-input pass its own region: the kernels run later
         size_t xi_pass = 0;
         int no = 0;
         for (Pass & ps : passes) {
             // payload slots of this pass: compact -> its own run of slots, else indexed by output row
             const int *   idx_p = s.idx.p + (compact ? (size_t) ps.row0 * (size_t) Ksel : 0);
             const float * val_p = s.val.p + (compact ? (size_t) ps.row0 * (size_t) K_eff : 0);
-            const float * rs_p  = rs_all ? rs_all + (compact ? ps.row0 : 0) : nullptr;
+            // a pass of one trial evaluates that trial's K alone: a one-entry schedule, its row scales at [j][slot]
+            KGrid kgp = kg;
+            if (ps.j >= 0) { kgp.n = 1; kgp.k[0] = kg.k[ps.j]; }
+            const unsigned nkp = (unsigned) ps.nkp;
+            const float * rs_p  = rs_all ? rs_all + (compact ? ps.row0 : 0) + (ps.j >= 0 ? (size_t) ps.j * (size_t) rs_stride : 0) : nullptr;
             const int *   rows_p = s.rows.p + ps.row0;
             double * o = s.dbl.p + ps.out0;
             if (ps.kind == 0) {
-                SDH_LAUNCH_DT(W, scan_evalw_kernel, dim3((unsigned) ps.nr, (unsigned) nK), dim3(256), 0, st, W, bv, p.write_base ? 1 : 0, p.scheme,
-                              kg, (int) Ksel, (int) s.block, idx_p, val_p, rs_p, rs_stride, ps.ws_dev, rows_p, compact, o);
+                SDH_LAUNCH_DT(W, scan_evalw_kernel, dim3((unsigned) ps.nr, nkp), dim3(256), 0, st, W, bv, p.write_base ? 1 : 0, p.scheme,
+                              kgp, (int) Ksel, (int) s.block, idx_p, val_p, rs_p, rs_stride, ps.ws_dev, rows_p, compact, o);
             } else if (ps.kind == 1) {
                 const float * xs_dev = nullptr;            // unscaled draws: the copy shared by all handles
                 if (ps.x_scale_host) {
-                    if ((rc = s.xs.put(ps.scaled, st))) return rc;
-                    xs_dev = s.xs.p;
+                    SDH_HIP_CHECK(hipMemcpyAsync(s.xs.p + ps.xs0, ps.scaled.data(), ps.scaled.size() * sizeof(float), hipMemcpyHostToDevice, st));
+                    xs_dev = s.xs.p + ps.xs0;
                 } else if (!(xs_dev = ps.normals->device())) {
                     set_error("scan: upload of the eval_x inputs failed"); return SDH_ERR_HIP;
                 }
@@ -1734,8 +1756,8 @@ static int scan_grid_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * 
                 }
                 ++xi_pass;
                 SDH_LAUNCH_DT(W, scan_dense_dot_kernel, dim3((unsigned) ps.nr, (unsigned) ps.nx), dim3(256), 0, st, W, rows_p, ps.nr, xs_dev, o);
-                hipLaunchKernelGGL(scan_delta_dot_kernel, dim3((unsigned) ps.nr, (unsigned) ps.nx, (unsigned) nK), dim3(256), 0, st, (int) n_in, p.scheme,
-                                   kg, (int) Ksel, (int) s.block, idx_p, val_p, rs_p, rs_stride, vdev, (int) L, (int) B, tall ? 1 : 0,
+                hipLaunchKernelGGL(scan_delta_dot_kernel, dim3((unsigned) ps.nr, (unsigned) ps.nx, nkp), dim3(256), 0, st, (int) n_in, p.scheme,
+                                   kgp, (int) Ksel, (int) s.block, idx_p, val_p, rs_p, rs_stride, vdev, (int) L, (int) B, tall ? 1 : 0,
                                    rows_p, ps.nr, compact, xs_dev, o + (size_t) ps.nr * ps.nx);
             } else {
                 const DenseView G = view_or_null(Wg), U = view_or_null(Wu), D = view_or_null(Wd);
@@ -1772,16 +1794,18 @@ static int scan_grid_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * 
             const int nr = ps.nr, nx = ps.nx;
             if (ps.kind == 0) {
                 std::vector<double> rel((size_t) nr), cs((size_t) nr), nrm((size_t) nr);
-                for (int j = 0; j < nK; ++j) {
-                    const double * rj = r + (size_t) j * nr * 3;
+                for (int jp = 0; jp < ps.nkp; ++jp) {                // results [jp] belong to trial ps.j, or to K number jp
+                    const int j = ps.j >= 0 ? ps.j : jp;
+                    const double * rj = r + (size_t) jp * nr * 3;
                     for (int i = 0; i < nr; ++i) triple_metrics(rj[(size_t) i * 3], rj[(size_t) i * 3 + 1], rj[(size_t) i * 3 + 2], &rel[(size_t) i], &cs[(size_t) i], &nrm[(size_t) i]);
                     summarise(rel, cs, nrm, o5_of(outs[j], ps.which));
                 }
             } else if (ps.kind == 1) {
                 const double * yt = r;
                 std::vector<double> rel((size_t) nx), cs((size_t) nx), nrm((size_t) nx);
-                for (int j = 0; j < nK; ++j) {
-                    const double * yh = r + (size_t) nr * nx * (size_t) (1 + j);
+                for (int jp = 0; jp < ps.nkp; ++jp) {
+                    const int j = ps.j >= 0 ? ps.j : jp;
+                    const double * yh = r + (size_t) nr * nx * (size_t) (1 + jp);
                     for (int xi = 0; xi < nx; ++xi) {
                         double n1 = 0.0, n2 = 0.0, dot = 0.0;
                         for (int ci = 0; ci < nr; ++ci) {
@@ -1856,6 +1880,14 @@ static int scan_grid_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * 
     float ms = 0.0f;
     SDH_HIP_CHECK(hipEventElapsedTime(&ms, s.ev0, s.ev1));
     for (int j = 0; j < nK; ++j) outs[j].gpu_ms = (double) ms / (double) nK;      // an equal share of the schedule's device time
+    return SDH_OK;
+}
+
+static int sdh_scan_rewind_impl(sdh_scan * h, int j) {
+    if (!h) { set_error("sdh_scan_rewind: null handle"); return SDH_ERR_INVALID; }
+    Scan & s = *(Scan *) h;
+    if (j < 0 || j >= s.n_after) { set_error("sdh_scan_rewind: trial %d of %d", j, s.n_after); return SDH_ERR_INVALID; }
+    s.rng = s.rng_after[j];
     return SDH_OK;
 }
 
@@ -1994,6 +2026,10 @@ int sdh_scan_tensor_kgrid(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * 
 
 int sdh_scan_pick(sdh_scan * h, int j) {
     SDH_NO_THROW(sdh_scan_pick_impl(h, j));
+}
+
+int sdh_scan_rewind(sdh_scan * h, int j) {
+    SDH_NO_THROW(sdh_scan_rewind_impl(h, j));
 }
 
 int sdh_scan_fetch(sdh_scan * h, int32_t * idx, float * val, float * row_scale,

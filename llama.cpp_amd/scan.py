@@ -155,13 +155,18 @@ class ScanSession:
                 "delta_clamp_scale": float(r.delta_clamp_scale)}
 
     def tensor_kgrid(self, W: DenseWeight, params: ScanParams, Ks: Sequence[int], kind: str = "ffn_gate", layer: int = 0,
-                     ffn: Optional[Tuple[DenseWeight, DenseWeight, DenseWeight]] = None) -> List[dict]:
+                     ffn: Optional[Tuple[DenseWeight, DenseWeight, DenseWeight]] = None, sequential: bool = False) -> List[dict]:
         """A K schedule of one tensor from ONE fit and ONE selection (the builder fits once per tensor and runs a
         trial per K, sd_build.cpp:444-451, :843-913): result j is what tensor() with K = Ks[j] returns from the
         same generator state; the generator advances once. pick(j) chooses the member fetch*() returns
-        (default: the last). params.K is ignored. At most MAX_KGRID budgets per call."""
+        (default: the last). params.K is ignored. At most MAX_KGRID budgets per call.
+        sequential=True: the K are the trials of ONE builder run's autotune schedule (sd_build.cpp:843-913) — trial j
+        draws its eval samples after trial j-1's, so result j is what tensor() calls in sequence on this handle return
+        (base_mode 1 from the second on); rewind(j) then puts the generator where a builder that stopped after trial
+        j would be."""
         lib = sd.load_library()
         p = params.c_struct(kind, layer)
+        p.kgrid_draws = 1 if sequential else 0
         n = len(Ks)
         rs = (sd.SdhScanResult * n)()
         ks = (C.c_int64 * n)(*[int(k) for k in Ks])
@@ -170,6 +175,10 @@ class ScanSession:
         self._grid = [(W.n_in, W.n_out, params, int(r.K_eff), int(r.n_blocks), int(r.L), int(r.B)) for r in rs]
         self._last = self._grid[-1]
         return [self._result(r) for r in rs]
+
+    def rewind(self, j: int):
+        """After tensor_kgrid(sequential=True): generator state as after trial j."""
+        sd._check(sd.load_library().sdh_scan_rewind(self._h, int(j)), "sdh_scan_rewind")
 
     def pick(self, j: int):
         """Choose which K of the last tensor_kgrid() the fetch calls return."""
@@ -280,7 +289,8 @@ def report_entry(layer: int, kind: str, n_in: int, n_out: int, params: ScanParam
 
 
 def autotune(session: "ScanSession", W: DenseWeight, params: ScanParams, schedule: Sequence[int], kind: str, layer: int,
-             ffn=None, min_mean: float = 0.0, min_p05: float = 0.0, max_iters: int = 0, gating_enabled: bool = True) -> dict:
+             ffn=None, min_mean: float = 0.0, min_p05: float = 0.0, max_iters: int = 0, gating_enabled: bool = True,
+             kgrid: bool = True) -> dict:
     """The K schedule of one tensor inside one builder run (sd_build.cpp:802-948): the base is fitted
     once, then one trial per distinct positive K in schedule order, each drawing its eval samples from
     the running stream; the first K whose gating passes is emitted. If none passes, the trial with the
@@ -293,9 +303,18 @@ def autotune(session: "ScanSession", W: DenseWeight, params: ScanParams, schedul
     if max_iters > 0:
         ks = ks[:max_iters]
     attempts, best, best_score, chosen = [], None, -1e30, None
+    # The whole schedule goes to the device as one call: one fit, ONE selection at the largest K (every trial's
+    # payload is a prefix of the sorted rows), each trial's metric passes on its own draws in the builder's order.
+    # The builder breaks at the first trial that passes and draws nothing for the later ones: the generator is
+    # rewound to that trial and its payload picked. The clamp rescales the stored values per K, and a schedule
+    # longer than one call holds is rare: both keep the trial-by-trial form.
+    clamp = params.delta_norm_clamp_down > 0.0 and kind == "ffn_down" and params.scheme == "coo"
+    batched = None
+    if kgrid and not clamp and 1 < len(ks) <= MAX_KGRID:
+        batched = session.tensor_kgrid(W, ScanParams(**{**params.__dict__, "K": ks[0]}), ks, kind, layer, ffn, sequential=True)
     for n, k in enumerate(ks):
         p = ScanParams(**{**params.__dict__, "K": k, "base_mode": (1 if n > 0 else params.base_mode)})
-        res = session.tensor(W, p, kind, layer, ffn)
+        res = batched[n] if batched is not None else session.tensor(W, p, kind, layer, ffn)
         e = report_entry(layer, kind, W.n_in, W.n_out, p, res, min_mean, min_p05, gating_enabled)
         attempts.append({"K_budget": k, "K_eff": res["K_eff"], "n_blocks": res["n_blocks"], "metric_value": e["gating_value"],
                          "metric_p05": e["gating_p05"], "pass": e["emit"], "seconds": res["gpu_ms"] / 1e3})
@@ -304,6 +323,10 @@ def autotune(session: "ScanSession", W: DenseWeight, params: ScanParams, schedul
         if e["emit"]:
             chosen = e
             break
+    if batched is not None:
+        last = len(attempts) - 1
+        session.rewind(last)
+        session.pick(last)                      # fetch*() returns the last trial run, as after trial-by-trial calls
     if chosen is None:
         chosen = dict(best) if best is not None else {"layer": layer, "kind": kind, "n_in": W.n_in, "n_out": W.n_out,
                                                       "decision": "metric_unavailable", "gating_pass": False}

@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "sdh_ffn_stack_create", "sdh_ffn_stack_destroy", "sdh_ffn_stack_forward", "sdh_ffn_stack_status", "sdh_ffn_stack_payload_bytes",
     "sdh_profile_enable", "sdh_profile_read", "sdh_profile_span_begin", "sdh_profile_span_end",
     "sdh_dense_create", "sdh_dense_destroy", "sdh_dense_bytes",
-    "sdh_scan_create", "sdh_scan_destroy", "sdh_scan_reseed", "sdh_scan_tensor", "sdh_scan_tensor_kgrid", "sdh_scan_pick", "sdh_scan_skip", "sdh_scan_fetch", "sdh_scan_fetch_packed", "sdh_scan_memo_clear", "sdh_imatrix_scale",
+    "sdh_scan_create", "sdh_scan_destroy", "sdh_scan_reseed", "sdh_scan_tensor", "sdh_scan_tensor_kgrid", "sdh_scan_pick", "sdh_scan_rewind", "sdh_scan_skip", "sdh_scan_fetch", "sdh_scan_fetch_packed", "sdh_scan_memo_clear", "sdh_imatrix_scale",
 ]
 
 
@@ -56,7 +56,7 @@ class SdhScanParams(C.Structure):
                 ("write_base", C.c_int32), ("write_row_scale", C.c_int32), ("base_max_samples", C.c_int64),
                 ("base_perm_trials", C.c_int32), ("want_proxy", C.c_int32), ("eval_cols", C.c_int64),
                 ("eval_x", C.c_int64), ("proxy_seed", C.c_int32), ("base_mode", C.c_int32), ("w_scale", C.c_void_p),
-                ("metrics_only", C.c_int32), ("reserved0", C.c_int32), ("delta_norm_clamp_down", C.c_double)]
+                ("metrics_only", C.c_int32), ("kgrid_draws", C.c_int32), ("delta_norm_clamp_down", C.c_double)]
 
 
 class SdhScanResult(C.Structure):
@@ -158,6 +158,7 @@ def load_library(path: str = LIB_PATH):
     lib.sdh_scan_tensor_kgrid.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.POINTER(SdhScanParams), C.POINTER(C.c_int64), C.c_int, C.POINTER(SdhScanResult)]
     lib.sdh_scan_pick.argtypes = [C.c_void_p, C.c_int]
+    lib.sdh_scan_rewind.argtypes = [C.c_void_p, C.c_int]
     lib.sdh_scan_fetch.argtypes = [C.c_void_p] + [C.c_void_p] * 7
     lib.sdh_scan_fetch_packed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.POINTER(C.c_int)]

@@ -165,3 +165,56 @@ def test_run_group_and_run_many_use_the_schedule(hip):
     for x, c in zip(ev.run_group(group), group):
         same(x, ev.run(c))
     ev.close()
+
+
+@pytest.mark.parametrize("case", ["coo_base_rs", "coo_nobase_proxy", "block16_base_rs", "coo_base_rs_imatrix", "metrics_only"])
+@pytest.mark.parametrize("min_mean", [0.0, 0.6, 2.0])          # first trial passes / some trial may pass / none passes
+def test_autotune_schedule_as_one_call(hip, case, min_mean):
+    """scan.autotune sends the whole K schedule as ONE sequential-draw call (kgrid_draws = 1: one fit, one selection
+    at the largest K, trial j's eval samples drawn after trial j-1's, sd_build.cpp:843-913) and rewinds the generator
+    to the trial the builder would have stopped at. Against the trial-by-trial form (kgrid=False): the chosen entry,
+    every attempt, the payload left on the handle and the stream position afterwards are identical."""
+    kw = {"coo_base_rs": dict(scheme="coo", base=True, row_scale=True, base_max_samples=96, base_perm_trials=2, eval_cols=16, eval_x=4),
+          "coo_nobase_proxy": dict(scheme="coo", base=False, row_scale=False, eval_cols=16, eval_x=4),
+          "block16_base_rs": dict(scheme="block", block=16, base=True, row_scale=True, base_max_samples=96, base_perm_trials=2,
+                                  eval_cols=16, eval_x=3),
+          "coo_base_rs_imatrix": dict(scheme="coo", base=True, row_scale=True, base_max_samples=96, base_perm_trials=2, eval_cols=16,
+                                      eval_x=4),
+          "metrics_only": dict(scheme="coo", base=True, row_scale=True, base_max_samples=96, base_perm_trials=2, eval_cols=16,
+                               eval_x=4, metrics_only=True)}[case]
+    Wnp = dense_trio(512, 1408, seed=11)
+    W = {k: SC.DenseWeight(v) for k, v in Wnp.items()}
+    kind = "ffn_up"
+    ws = None
+    if case.endswith("imatrix"):
+        imat = (np.random.default_rng(4).random(512).astype(np.float32) + 0.05) ** 2
+        ws = SC.imatrix_scale(imat, 512, eps=1e-8, power=1.0)
+    p = SC.ScanParams(seed=5, w_scale=ws, **kw)
+    ffn = (W["ffn_gate"], W["ffn_up"], W["ffn_down"])
+    schedule = [16, 16, 0, 48, 96, 200, 320]
+    probe = SC.ScanParams(K=4, eval_cols=8, eval_x=2, seed=5)
+    out = []
+    for kgrid in (True, False):
+        s = SC.ScanSession(5)
+        e = SC.autotune(s, W[kind], p, schedule, kind, 3, ffn, min_mean=min_mean, min_p05=0.0, kgrid=kgrid)
+        pay = None if p.metrics_only else s.fetch_packed()
+        after = s.tensor(W[kind], probe, kind, 3, ffn)           # the next draws of the stream
+        out.append((e, pay, after))
+        s.close()
+    (ea, pa, aa), (eb, pb, ab) = out
+    strip = lambda e: {k: v for k, v in e.items() if k != "autotune_attempts"}           # noqa: E731
+    assert strip(ea) == strip(eb)
+    assert len(ea["autotune_attempts"]) == len(eb["autotune_attempts"])
+    for x, y in zip(ea["autotune_attempts"], eb["autotune_attempts"]):
+        assert {k: v for k, v in x.items() if k != "seconds"} == {k: v for k, v in y.items() if k != "seconds"}
+    if min_mean == 2.0:
+        assert not ea["emit"] and [a["K_budget"] for a in ea["autotune_attempts"]] == [16, 48, 96, 200, 320]
+    if min_mean == 0.0:
+        assert ea["emit"] and len(ea["autotune_attempts"]) == 1
+    if pa is not None:
+        for k in pa:
+            if pa[k] is not None:
+                assert pa[k].shape == pb[k].shape and pa[k].tobytes() == pb[k].tobytes(), k
+    same(aa, ab)
+    for w in W.values():
+        w.close()
