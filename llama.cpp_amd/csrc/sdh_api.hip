@@ -495,9 +495,11 @@ static int nf_slot(DeviceWeight * w, hipStream_t s, int * slot_out) {
     return SDH_OK;
 }
 
+struct GluEpilogue { const float * gate; int64_t ldg; int act; const uint16_t * tab; };
+
 static int sdh_forward_impl(sdh_weight * h, const float * x, int64_t ldx, int64_t n_tokens,
                 float * y, int64_t ldy, int flags, void * stream,
-                float * ext_ws = nullptr, size_t ext_ws_bytes = 0) {
+                float * ext_ws = nullptr, size_t ext_ws_bytes = 0, const GluEpilogue * glu = nullptr) {
     // ext_ws: the caller-provided base-term workspace of sdh_forward_noalloc; with it this function makes no
     // allocating call (no workspace growth, no host-I/O staging, no fused launch: its first use allocates the
     // census counter and waits for the device)
@@ -574,6 +576,7 @@ static int sdh_forward_impl(sdh_weight * h, const float * x, int64_t ldx, int64_
         a.nf_counter = w->nf_ring + slot;
         a.zero_nonfinite = (flags & SDH_FWD_ZERO_NONFINITE) != 0;
         a.exact_order = (flags & SDH_FWD_EXACT_ORDER) != 0;
+        if (glu) { a.glu_gate = glu->gate + t0 * glu->ldg; a.glu_ldg = glu->ldg; a.glu_act = glu->act; a.glu_tab = glu->tab; }
 
         auto prof_begin = [&](int & pair) -> int {
             pair = -1;
@@ -729,9 +732,12 @@ static int ffn_gate_up(sdh_weight * hg, sdh_weight * hu, int act, const float * 
         }
     }
     // node by node on the device
+    // the gate node, then the up node with the activation in its epilogue: h = act(g) * up(x) is written by the up
+    // launch itself (no separate activation pass over three [T][n_ff] buffers; ubuf is no longer used)
+    (void) ubuf;
     if ((rc = sdh_forward(hg, dx, dldx, T, gbuf, n_ff, flags, s)) != SDH_OK) return rc;
-    if ((rc = sdh_forward(hu, dx, dldx, T, ubuf, n_ff, flags, s)) != SDH_OK) return rc;
-    return launch_glu(act, ls.gelu_tab, gbuf, ubuf, hbuf, T * n_ff, s);
+    const GluEpilogue ge{gbuf, n_ff, act, ls.gelu_tab};
+    return sdh_forward_impl(hu, dx, dldx, T, hbuf, n_ff, flags, s, nullptr, 0, &ge);
 }
 
 int sdh_ffn_last_fused(void) { return lib().ffn_last_fused; }

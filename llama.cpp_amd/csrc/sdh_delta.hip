@@ -201,6 +201,7 @@ DeltaParams make_delta_params(const DeviceWeight & w, const DeltaLaunch & a) {
     p.Ktot = is_block ? (int) (w.nb * w.block) : (int) w.K;
     p.L = (int) w.L; p.B = a.v_blocks > 0 ? a.v_blocks : (int) w.B; p.tall = w.tall ? 1 : 0;
     p.v_ld = a.v_ld > 0 ? a.v_ld : (int64_t) p.B * p.L;
+    p.glu_gate = a.glu_gate; p.glu_ldg = a.glu_ldg; p.glu_act = a.glu_act; p.glu_tab = a.glu_tab;
     p.G = 1;
     p.zero_nf = a.zero_nonfinite ? 1 : 0;
     p.x_vec_ok = (((uintptr_t) a.x % 16) == 0 && (a.ldx % 4) == 0) ? 1 : 0;

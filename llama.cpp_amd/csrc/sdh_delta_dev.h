@@ -34,6 +34,10 @@ struct DeltaParams {
     int x_vec_ok;           // x columns are 16-byte aligned
     int block_shift;        // log2(block) if a power of two, else -1
     int n_blk_in;           // ceil(n_in / block): block ids below this start inside x
+    const float * glu_gate; // ffn_up node of a gated FFN: gate outputs [T][glu_ldg], or null
+    int64_t glu_ldg;
+    int glu_act;
+    const uint16_t * glu_tab;
 };
 
 // host: fill the parameter block for one launch (sdh_delta.hip)
@@ -352,10 +356,6 @@ __device__ __forceinline__ float finish_output(const DeltaParams & p, float y, f
     }
     return out;
 }
-__device__ __forceinline__ void store_output(const DeltaParams & p, int o, int64_t t, float y, float scale) {
-    p.y[o + t * p.ldy] = finish_output(p, y, scale);
-}
-
 // act(g) * u: the gate activation of a parallel-gated FFN as ggml's CPU ops compute it on F32
 // (ggml_vec_swiglu_f32, ggml/src/ggml-cpu/vec.cpp:416 with ggml_silu_f32, vec.h:1061;
 // ggml_vec_geglu_f32, vec.h:1430-1443: thresholds at +-10, f16 table in between).
@@ -365,6 +365,14 @@ __device__ __forceinline__ float glu_value(int act, float g, float u, const uint
     if (g <= -10.0f) return 0.0f;
     if (g >= 10.0f) return g * u;
     return h2f(tab[__half_as_ushort(__float2half_rn(g))]) * u;
+}
+
+// One output of the op. As ffn_up inside a gated FFN (p.glu_gate set) the stored value is act(gate) * up: the node's
+// guard has already run on the up value, as the reference's per-node guard does before ggml_swiglu_split sees it.
+__device__ __forceinline__ void store_output(const DeltaParams & p, int o, int64_t t, float y, float scale) {
+    float out = finish_output(p, y, scale);
+    if (p.glu_gate) out = glu_value(p.glu_act, p.glu_gate[o + t * p.glu_ldg], out, p.glu_tab);
+    p.y[o + t * p.ldy] = out;
 }
 
 } // namespace sdh

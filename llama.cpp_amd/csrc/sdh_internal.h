@@ -132,6 +132,8 @@ struct DeltaLaunch {
     int  v_blocks = 0;      // 0: v is [T][B][L] (FWHT form); 1: v is [T][L], base blocks already summed (MFMA form, wide)
     int64_t v_ld = 0;       // 0: tokens are v_blocks*L (or B*L) apart; else the stride (the MFMA form, tall: the base term
                             // is written straight into y and the residual kernel updates y in place, v == y, v_ld == ldy)
+    // gated FFN, ffn_up node: the epilogue writes act(gate[t][o]) * y instead of y (the node's own guard runs first)
+    const float * glu_gate = nullptr; int64_t glu_ldg = 0; int glu_act = 0; const uint16_t * glu_tab = nullptr;
 };
 int launch_delta(const DeviceWeight & w, const DeltaLaunch & a, hipStream_t s);
 
