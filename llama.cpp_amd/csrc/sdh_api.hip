@@ -630,7 +630,7 @@ static int sdh_forward_impl(sdh_weight * h, const float * x, int64_t ldx, int64_
         int pair, rc = prof_begin(pair);
         if (rc != SDH_OK) return rc;
         // many tokens: token-tiled sparse x dense product (bit-exact order); few: per-token row kernels
-        static const int64_t spmm_min_t = [] { const char * e = getenv("SDH_SPMM_MIN_T"); return e ? (int64_t) atoll(e) : (int64_t) 8; }();
+        static const int64_t spmm_min_t = [] { const char * e = getenv("SDH_SPMM_MIN_T"); return e ? (int64_t) atoll(e) : (int64_t) 6; }();   // Mistral FFN layer, us: T=6 62.8 per-token vs 59 tiled, T=5 equal
         rc = 1;
         // the choice follows the CALL's token count, not the chunk's: a short last chunk must not switch a call to
         // the per-token kernels (same values within tolerance, but not the same bits as its other chunks)

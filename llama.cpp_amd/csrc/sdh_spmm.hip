@@ -33,8 +33,8 @@ static size_t spmm_tile_rows(const DeltaParams & p) {
     return BLOCK ? (size_t) p.n_in + (size_t) ((p.n_in + p.block - 1) / p.block) : (size_t) p.n_in;
 }
 
-template <typename IDX_T, typename VAL_T, bool BLOCK, bool VEC, int TT>
-__global__ __launch_bounds__(1024)
+template <typename IDX_T, typename VAL_T, bool BLOCK, bool VEC, int TT, int NTH>
+__global__ __launch_bounds__(NTH)
 void delta_spmm_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
 #pragma clang fp contract(off)
     extern __shared__ float xs[];                       // [n_in][TT]
@@ -43,10 +43,10 @@ void delta_spmm_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
     const int nt = (int) ((T - t0 < TT) ? (T - t0) : TT);
     for (int t = 0; t < nt; ++t) {
         const float * xt = p.x + (t0 + t) * p.ldx;
-        for (int i = tid; i < p.n_in; i += 1024) xs[tile_row<BLOCK>(p, i) * TT + t] = xt[i];
+        for (int i = tid; i < p.n_in; i += NTH) xs[tile_row<BLOCK>(p, i) * TT + t] = xt[i];
     }
     if (nt < TT) {                                      // ragged last tile: idle lanes read zeros
-        for (int i = tid; i < p.n_in; i += 1024)
+        for (int i = tid; i < p.n_in; i += NTH)
             for (int t = nt; t < TT; ++t) xs[tile_row<BLOCK>(p, i) * TT + t] = 0.0f;
     }
     __syncthreads();
@@ -55,7 +55,7 @@ void delta_spmm_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
     const bool t_ok = t < nt;
     const int64_t tok = t0 + (t_ok ? t : 0);
     const int r1 = min(p.n_out, ((int) blockIdx.y + 1) * rows_per_wg);
-    for (int o = (int) blockIdx.y * rows_per_wg + tid / TT; o < r1; o += 1024 / TT) {
+    for (int o = (int) blockIdx.y * rows_per_wg + tid / TT; o < r1; o += NTH / TT) {
         const VAL_T * vrow = reinterpret_cast<const VAL_T *>(p.val) + (size_t) o * p.Ktot;
         const IDX_T * irow = reinterpret_cast<const IDX_T *>(p.idx) + (size_t) o * (BLOCK ? p.nb : p.Ktot);
         float y = 0.0f;
@@ -123,8 +123,8 @@ void delta_spmm_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
 // VALU instructions per multiply-add and is issue-bound (rocprof: 141.5 M VALU wave-instructions for
 // 14.7 M wave-level multiply-adds, profiles/r01_d_prefill_pmc.json); this form needs ~3. Same
 // accumulation order per (row, token), so still bit-identical to the CPU op. Vector payload shapes only.
-template <typename IDX_T, typename VAL_T, bool BLOCK, int TT>
-__global__ __launch_bounds__(1024)
+template <typename IDX_T, typename VAL_T, bool BLOCK, int TT, int NTH>
+__global__ __launch_bounds__(NTH)
 void delta_spmm4_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
 #pragma clang fp contract(off)
     extern __shared__ float xs[];                       // [n_in][TT]
@@ -135,10 +135,10 @@ void delta_spmm4_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
     const int nt = (int) ((T - t0 < TT) ? (T - t0) : TT);
     for (int t = 0; t < nt; ++t) {
         const float * xt = p.x + (t0 + t) * p.ldx;
-        for (int i = tid; i < p.n_in; i += 1024) xs[tile_row<BLOCK>(p, i) * TT + t] = xt[i];
+        for (int i = tid; i < p.n_in; i += NTH) xs[tile_row<BLOCK>(p, i) * TT + t] = xt[i];
     }
     if (nt < TT) {
-        for (int i = tid; i < p.n_in; i += 1024)
+        for (int i = tid; i < p.n_in; i += NTH)
             for (int t = nt; t < TT; ++t) xs[tile_row<BLOCK>(p, i) * TT + t] = 0.0f;
     }
     __syncthreads();
@@ -146,7 +146,7 @@ void delta_spmm4_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
     const int tq = (tid % LPR) * 4;                     // first of this lane's four tokens within the tile
     const float4 * xq = reinterpret_cast<const float4 *>(xs + tq);     // xq[i * LPR] = x[i][tq .. tq+3]
     const int r1 = min(p.n_out, ((int) blockIdx.y + 1) * rows_per_wg);
-    for (int o = (int) blockIdx.y * rows_per_wg + tid / LPR; o < r1; o += 1024 / LPR) {
+    for (int o = (int) blockIdx.y * rows_per_wg + tid / LPR; o < r1; o += NTH / LPR) {
         const VAL_T * vrow = reinterpret_cast<const VAL_T *>(p.val) + (size_t) o * p.Ktot;
         const IDX_T * irow = reinterpret_cast<const IDX_T *>(p.idx) + (size_t) o * (BLOCK ? p.nb : p.Ktot);
         float y[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -223,19 +223,23 @@ void delta_spmm4_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
     }
 }
 
-template <typename IDX_T, typename VAL_T, bool BLOCK, bool VEC, int TT>
-static int launch_tt(const DeltaParams & p, int64_t T, hipStream_t s) {
+// NTH threads per workgroup. A tile fills the LDS of a CU, so a launch has at most tiles x ceil(n_out / rows of one
+// pass) workgroups: with 1024 threads and few tokens that is a handful (T=8, Mistral gate: 28 workgroups on 256 CUs —
+// a gated FFN layer took 75 us at 8 tokens against 36 us at 4). When the 1024-thread form would leave most CUs
+// without a workgroup the 256-thread form is used: a quarter of the rows per pass, four times the workgroups.
+template <typename IDX_T, typename VAL_T, bool BLOCK, bool VEC, int TT, int NTH>
+static int launch_tt_n(const DeltaParams & p, int64_t T, hipStream_t s) {
     const size_t lds = spmm_tile_rows<BLOCK>(p) * TT * sizeof(float);
     static const bool one_token = getenv("SDH_SPMM_ONE_TOKEN") != nullptr;      // dev: A/B against the four-token form
-    void (*kern)(const DeltaParams, int64_t, int) = delta_spmm_kernel<IDX_T, VAL_T, BLOCK, VEC, TT>;
+    void (*kern)(const DeltaParams, int64_t, int) = delta_spmm_kernel<IDX_T, VAL_T, BLOCK, VEC, TT, NTH>;
     int lanes_per_row = TT;
     if constexpr (VEC && TT % 4 == 0) {
-        if (!one_token) { kern = delta_spmm4_kernel<IDX_T, VAL_T, BLOCK, TT>; lanes_per_row = TT / 4; }
+        if (!one_token) { kern = delta_spmm4_kernel<IDX_T, VAL_T, BLOCK, TT, NTH>; lanes_per_row = TT / 4; }
     }
     SDH_HIP_CHECK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const int64_t tiles = (T + TT - 1) / TT;
     if (tiles > 0x7fffffff) { set_error("spmm: too many token tiles"); return SDH_ERR_UNSUPPORTED; }
-    const int rows_pass = 1024 / lanes_per_row;
+    const int rows_pass = NTH / lanes_per_row;
     // ~4 workgroups per CU in flight over the whole launch; a chunk is a whole number of row passes
     int64_t chunks = (4 * (int64_t) lib().num_cu + tiles - 1) / tiles;
     const int64_t max_chunks = (p.n_out + rows_pass - 1) / rows_pass;
@@ -245,9 +249,21 @@ static int launch_tt(const DeltaParams & p, int64_t T, hipStream_t s) {
     int rows_per_wg = (int) ((p.n_out + chunks - 1) / chunks);
     rows_per_wg = (rows_per_wg + rows_pass - 1) / rows_pass * rows_pass;
     const unsigned gy = (unsigned) ((p.n_out + rows_per_wg - 1) / rows_per_wg);
-    hipLaunchKernelGGL(kern, dim3((unsigned) tiles, gy), dim3(1024), lds, s, p, T, rows_per_wg);
+    hipLaunchKernelGGL(kern, dim3((unsigned) tiles, gy), dim3(NTH), lds, s, p, T, rows_per_wg);
     SDH_HIP_CHECK(hipGetLastError());
     return SDH_OK;
+}
+
+template <typename IDX_T, typename VAL_T, bool BLOCK, bool VEC, int TT>
+static int launch_tt(const DeltaParams & p, int64_t T, hipStream_t s) {
+    const int64_t tiles = (T + TT - 1) / TT;
+    const int lanes_per_row = (VEC && TT % 4 == 0) ? TT / 4 : TT;
+    const int64_t wgs_1024 = tiles * ((p.n_out + 1024 / lanes_per_row - 1) / (1024 / lanes_per_row));
+    static const int force = [] { const char * e = getenv("SDH_SPMM_NTH"); return e ? atoi(e) : 0; }();        // dev: A/B
+    // measured, Mistral FFN layer (gate, up, down; us): T=8 75 -> 59, T=16 77 -> 61, but T=32 87 -> 98 and T=64 98 -> 171:
+    // the narrow form pays once the wide one would leave three quarters of the CUs without a workgroup
+    const bool narrow = force ? force == 256 : 4 * wgs_1024 <= (int64_t) lib().num_cu;
+    return narrow ? launch_tt_n<IDX_T, VAL_T, BLOCK, VEC, TT, 256>(p, T, s) : launch_tt_n<IDX_T, VAL_T, BLOCK, VEC, TT, 1024>(p, T, s);
 }
 
 template <typename IDX_T, typename VAL_T, bool BLOCK, bool VEC>
