@@ -239,7 +239,11 @@ constexpr int FIT_ROWS_PER_STAGE = 8;
 // FT threads per workgroup, one bin each: the staging of a row is shared by FT bins, so FT = 1024 reads
 // each sampled row from L2 L/1024 times instead of L/256 times and keeps 16 waves per CU behind the
 // LDS round trips of a stage.
-template <int FT>
+// FAST: no imatrix weighting; a job whose block lies wholly inside the inputs (span == L) then takes the short body:
+// every sample of the job is valid for every bin (the permutation maps into [0, L)), the per-sample validity selects
+// drop out and the weight sum is the sample count — written once at the end, exactly what n += 1.0 per sample gives.
+// Samples past the end of the job read the zero-filled tail of the stage: +0.0 to both sums (exact).
+template <int FT, bool FAST>
 __global__ __launch_bounds__(FT)
 void scan_fit_lds_q8_kernel(DenseView W, int L, int tall, const FitJob * __restrict__ jobs, const int * __restrict__ rows,
                             const int * __restrict__ perms, const float * __restrict__ ws, double * __restrict__ out /* [n_jobs][3][L] */) {
@@ -321,11 +325,36 @@ void scan_fit_lds_q8_kernel(DenseView W, int L, int tall, const FitJob * __restr
     using set0 = std::integral_constant<int, 0>;
     using set1 = std::integral_constant<int, 1>;
     // one stage: parity P = (s0 / R) & 1 is its LDS buffer and the register set the stage after next is fetched into
-    auto stage = [&](auto par_c, auto other_c, int s0) {
+    const bool full = FAST && span == L;                               // uniform over the workgroup
+    auto stage = [&](auto par_c, auto other_c, auto fast_c, int s0) {
         constexpr int buf = decltype(par_c)::value;
         if (s0 + 2 * R < job.n_rows) fetch(par_c, s0 + 2 * R);
         // the R samples of the stage: all LDS reads first (branch-free, clamped), then the sums in sample order;
         // a sample past the end of the job, like one outside the block, adds +0.0 (exact)
+        if constexpr (decltype(fast_c)::value) {
+            int srcv[R];
+            float qv[R], dv[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int row = rows_s[min(s0 + k, job.n_rows - 1)];
+                const int p = tall ? row - job.b * L : row;
+                srcv[k] = perm_s[(u ^ p) & (L - 1)];
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                dv[k] = __half2float(ds[((size_t) buf * R + k) * nd + (srcv[k] >> 5)]);
+                qv[k] = (float) qs[((size_t) buf * R + k) * L + srcv[k]];
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const double v = (double) (qv[k] * dv[k]);                 // dense_at<Q8_0>: (float) q * d
+                s  += v;
+                s2 += v * v;
+            }
+            if (s0 + R < job.n_rows) commit(other_c);
+            __syncthreads();
+            return;
+        }
         int srcv[R];
         bool okv[R];
         float qv[R], dv[R], wv1[R];
@@ -368,9 +397,17 @@ void scan_fit_lds_q8_kernel(DenseView W, int L, int tall, const FitJob * __restr
     commit(set0{});
     if (R < job.n_rows) fetch(set1{}, R);
     __syncthreads();
-    for (int s0 = 0; s0 < job.n_rows; s0 += 2 * R) {
-        stage(set0{}, set1{}, s0);
-        if (s0 + R < job.n_rows) stage(set1{}, set0{}, s0 + R);
+    if (full) {
+        for (int s0 = 0; s0 < job.n_rows; s0 += 2 * R) {
+            stage(set0{}, set1{}, std::true_type{}, s0);
+            if (s0 + R < job.n_rows) stage(set1{}, set0{}, std::true_type{}, s0 + R);
+        }
+        n = (double) job.n_rows;
+    } else {
+        for (int s0 = 0; s0 < job.n_rows; s0 += 2 * R) {
+            stage(set0{}, set1{}, std::false_type{}, s0);
+            if (s0 + R < job.n_rows) stage(set1{}, set0{}, std::false_type{}, s0 + R);
+        }
     }
     double * o = out + (size_t) blockIdx.y * 3 * L;
     o[u] = s; o[L + u] = s2; o[2 * L + u] = n;
@@ -1485,14 +1522,20 @@ static int scan_grid_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * 
         if (W.type == SDH_TYPE_Q8_0 && L >= 1024 && L <= 4096 && fit_lds <= 160 * 1024 && !fit_gather_only) {
             static const bool fit_256 = getenv("SDH_SCAN_FIT_T256") != nullptr;               // A/B: the first shape
             static const bool attr_ok =
-                hipFuncSetAttribute((const void *) scan_fit_lds_q8_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
-                hipFuncSetAttribute((const void *) scan_fit_lds_q8_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+                hipFuncSetAttribute((const void *) scan_fit_lds_q8_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                hipFuncSetAttribute((const void *) scan_fit_lds_q8_kernel<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                hipFuncSetAttribute((const void *) scan_fit_lds_q8_kernel<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
             if (!attr_ok) { set_error("scan: raising the dynamic LDS limit failed"); return SDH_ERR_HIP; }
+            static const bool fit_slow = getenv("SDH_SCAN_FIT_GENERAL") != nullptr;          // A/B: the general body
+            const bool fast = !ws_dev && !fit_slow;                  // per job: blocks wholly inside the inputs take the short body
             if (fit_256)
-                hipLaunchKernelGGL(scan_fit_lds_q8_kernel<256>, dim3((unsigned) (L / 256), (unsigned) n_jobs), dim3(256), fit_lds, st,
+                hipLaunchKernelGGL((scan_fit_lds_q8_kernel<256, false>), dim3((unsigned) (L / 256), (unsigned) n_jobs), dim3(256), fit_lds, st,
+                                   W, (int) L, tall ? 1 : 0, pl.jobs_dev, pl.rows_dev, pl.perms_dev, ws_dev, s.dbl.p);
+            else if (fast)
+                hipLaunchKernelGGL((scan_fit_lds_q8_kernel<1024, true>), dim3((unsigned) (L / 1024), (unsigned) n_jobs), dim3(1024), fit_lds, st,
                                    W, (int) L, tall ? 1 : 0, pl.jobs_dev, pl.rows_dev, pl.perms_dev, ws_dev, s.dbl.p);
             else
-                hipLaunchKernelGGL(scan_fit_lds_q8_kernel<1024>, dim3((unsigned) (L / 1024), (unsigned) n_jobs), dim3(1024), fit_lds, st,
+                hipLaunchKernelGGL((scan_fit_lds_q8_kernel<1024, false>), dim3((unsigned) (L / 1024), (unsigned) n_jobs), dim3(1024), fit_lds, st,
                                    W, (int) L, tall ? 1 : 0, pl.jobs_dev, pl.rows_dev, pl.perms_dev, ws_dev, s.dbl.p);
         } else {
             SDH_LAUNCH_DT(W, scan_fit_kernel, dim3((unsigned) (L / threads), (unsigned) n_jobs), dim3(threads),

@@ -77,7 +77,7 @@ def test_scan_matches_reference_goldens(hip, name):
     assert o.u32() == g["next_u32"]
 
 
-@pytest.mark.parametrize("dims", [(512, 1408), (1408, 512), (1024, 1024), (288, 800)])
+@pytest.mark.parametrize("dims", [(512, 1408), (1408, 512), (1024, 1024), (288, 800), (2048, 1024), (1024, 2560), (2560, 1024)])
 @pytest.mark.parametrize("wtype", ["q8_0", "f16"])
 def test_base_fit_bit_exact(hip, dims, wtype):
     n_in, n_out = dims
