@@ -123,28 +123,35 @@ void delta_spmm_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
 // VALU instructions per multiply-add and is issue-bound (rocprof: 141.5 M VALU wave-instructions for
 // 14.7 M wave-level multiply-adds, profiles/r01_d_prefill_pmc.json); this form needs ~3. Same
 // accumulation order per (row, token), so still bit-identical to the CPU op. Vector payload shapes only.
-template <typename IDX_T, typename VAL_T, bool BLOCK, int TT, int NTH>
+template <typename IDX_T, typename VAL_T, bool BLOCK, int TT, int NTH, int TPL /* tokens per lane: 4, or 2 for two-token tiles */>
 __global__ __launch_bounds__(NTH)
 void delta_spmm4_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
 #pragma clang fp contract(off)
     extern __shared__ float xs[];                       // [n_in][TT]
-    static_assert(TT % 4 == 0, "four tokens per lane");
-    constexpr int LPR = TT / 4;                         // lanes per row
+    static_assert(TT % TPL == 0 && (TPL == 4 || TPL == 2), "four or two tokens per lane");
+    constexpr int LPR = TT / TPL;                       // lanes per row
+    typedef float float2v __attribute__((ext_vector_type(2)));
+    typedef float xvec __attribute__((ext_vector_type(TPL)));           // one LDS read: the lane's tokens of one input
     const int tid = threadIdx.x;
     const int64_t t0 = (int64_t) blockIdx.x * TT;
     const int nt = (int) ((T - t0 < TT) ? (T - t0) : TT);
-    for (int t = 0; t < nt; ++t) {
-        const float * xt = p.x + (t0 + t) * p.ldx;
-        for (int i = tid; i < p.n_in; i += NTH) xs[tile_row<BLOCK>(p, i) * TT + t] = xt[i];
-    }
-    if (nt < TT) {
-        for (int i = tid; i < p.n_in; i += NTH)
-            for (int t = nt; t < TT; ++t) xs[tile_row<BLOCK>(p, i) * TT + t] = 0.0f;
+    // the tile is written TPL tokens at a time: one 16- or 8-byte LDS store per (input, token group) instead of TPL
+    // 4-byte stores TT*4 bytes apart (8-way bank conflicts at TT = 8); tokens past the end of the batch are zero
+    for (int q = 0; q < TT; q += TPL) {
+        const float * xt[TPL];
+#pragma unroll
+        for (int u = 0; u < TPL; ++u) xt[u] = p.x + (t0 + min(q + u, nt - 1)) * p.ldx;
+        for (int i = tid; i < p.n_in; i += NTH) {
+            xvec v;
+#pragma unroll
+            for (int u = 0; u < TPL; ++u) v[u] = (q + u < nt) ? xt[u][i] : 0.0f;
+            *reinterpret_cast<xvec *>(xs + (size_t) tile_row<BLOCK>(p, i) * TT + q) = v;
+        }
     }
     __syncthreads();
 
-    const int tq = (tid % LPR) * 4;                     // first of this lane's four tokens within the tile
-    const float4 * xq = reinterpret_cast<const float4 *>(xs + tq);     // xq[i * LPR] = x[i][tq .. tq+3]
+    const int tq = (tid % LPR) * TPL;                   // first of this lane's tokens within the tile
+    const xvec * xq = reinterpret_cast<const xvec *>(xs + tq);         // xq[i * LPR] = x[i][tq .. tq+TPL-1]
     const int r1 = min(p.n_out, ((int) blockIdx.y + 1) * rows_per_wg);
     for (int o = (int) blockIdx.y * rows_per_wg + tid / LPR; o < r1; o += NTH / LPR) {
         const VAL_T * vrow = reinterpret_cast<const VAL_T *>(p.val) + (size_t) o * p.Ktot;
@@ -152,7 +159,7 @@ void delta_spmm4_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
         float y[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (p.v) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < TPL; ++u) {
                 const int64_t tok = t0 + ((tq + u < nt) ? tq + u : 0);
                 const float * vt = p.v + (size_t) tok * (size_t) p.v_ld;
                 if (p.tall) y[u] = vt[o];
@@ -161,13 +168,16 @@ void delta_spmm4_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
         }
         // two tokens per instruction: v_pk_mul_f32 / v_pk_add_f32 round each component as the scalar forms do
         // (contraction is off), so the sums keep the CPU op's bits at half the multiply and add instructions
-        typedef float float2v __attribute__((ext_vector_type(2)));
         float2v y01 = {y[0], y[1]}, y23 = {y[2], y[3]};
-        auto mac = [&](float v, const float4 x) {
-            const float2v vv = {v, v}, x01 = {x.x, x.y}, x23 = {x.z, x.w};
-            const float2v p01 = vv * x01, p23 = vv * x23;
+        auto mac = [&](float v, const xvec x) {
+            const float2v vv = {v, v}, x01 = {x[0], x[1]};
+            const float2v p01 = vv * x01;
             y01 = y01 + p01;
-            y23 = y23 + p23;
+            if constexpr (TPL == 4) {
+                const float2v x23 = {x[2], x[3]};
+                const float2v p23 = vv * x23;
+                y23 = y23 + p23;
+            }
         };
         if constexpr (BLOCK) {
             for (int bi = 0; bi < p.nb; ++bi) {
@@ -176,7 +186,7 @@ void delta_spmm4_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
                 if (blk < 0 || in0 >= p.n_in) continue;
                 const int len = (int) ((in0 + p.block < p.n_in) ? p.block : (p.n_in - in0));
                 const VAL_T * vb = vrow + (size_t) bi * p.block;
-                const float4 * xb = xq + (size_t) (in0 + blk) * LPR;        // tile_row(in0 + j) = in0 + blk + j inside the block
+                const xvec * xb = xq + (size_t) (in0 + blk) * LPR;        // tile_row(in0 + j) = in0 + blk + j inside the block
                 for (int j = 0; j < p.block; j += 8) {
                     Vec8<VAL_T> vv;
                     vv.load(vb + j);
@@ -219,7 +229,7 @@ void delta_spmm4_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
         const float scale = p.rs ? p.rs[o] : 1.0f;
         y[0] = y01[0]; y[1] = y01[1]; y[2] = y23[0]; y[3] = y23[1];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) if (tq + u < nt) store_output(p, o, t0 + tq + u, y[u], scale);
+        for (int u = 0; u < TPL; ++u) if (tq + u < nt) store_output(p, o, t0 + tq + u, y[u], scale);
     }
 }
 
@@ -234,7 +244,9 @@ static int launch_tt_n(const DeltaParams & p, int64_t T, hipStream_t s) {
     void (*kern)(const DeltaParams, int64_t, int) = delta_spmm_kernel<IDX_T, VAL_T, BLOCK, VEC, TT, NTH>;
     int lanes_per_row = TT;
     if constexpr (VEC && TT % 4 == 0) {
-        if (!one_token) { kern = delta_spmm4_kernel<IDX_T, VAL_T, BLOCK, TT, NTH>; lanes_per_row = TT / 4; }
+        if (!one_token) { kern = delta_spmm4_kernel<IDX_T, VAL_T, BLOCK, TT, NTH, 4>; lanes_per_row = TT / 4; }
+    } else if constexpr (VEC && TT == 2) {               // long inputs: both tokens of the tile in one lane, one 8-byte LDS read per entry
+        if (!one_token) { kern = delta_spmm4_kernel<IDX_T, VAL_T, BLOCK, TT, NTH, 2>; lanes_per_row = 1; }
     }
     SDH_HIP_CHECK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const int64_t tiles = (T + TT - 1) / TT;
@@ -257,7 +269,7 @@ static int launch_tt_n(const DeltaParams & p, int64_t T, hipStream_t s) {
 template <typename IDX_T, typename VAL_T, bool BLOCK, bool VEC, int TT>
 static int launch_tt(const DeltaParams & p, int64_t T, hipStream_t s) {
     const int64_t tiles = (T + TT - 1) / TT;
-    const int lanes_per_row = (VEC && TT % 4 == 0) ? TT / 4 : TT;
+    const int lanes_per_row = (VEC && TT % 4 == 0) ? TT / 4 : (VEC && TT == 2) ? 1 : TT;
     const int64_t wgs_1024 = tiles * ((p.n_out + 1024 / lanes_per_row - 1) / (1024 / lanes_per_row));
     static const int force = [] { const char * e = getenv("SDH_SPMM_NTH"); return e ? atoi(e) : 0; }();        // dev: A/B
     // measured, Mistral FFN layer (gate, up, down; us): T=8 75 -> 59, T=16 77 -> 61, but T=32 87 -> 98 and T=64 98 -> 171:
