@@ -1,0 +1,90 @@
+"""Differential fuzzing of sdh_forward against the oracle (test infrastructure; run on a GPU box):
+random shapes, schemes, dtypes, token counts and flag sets for a time budget; stops at the first mismatch and
+prints the case so that it can be turned into a test. Bars are those of tests/test_gpu_forward.py: EXACT_ORDER and
+the tiled SpMM path (T >= 6, no NO_SPMM) bit-identical to the oracle, the other fast paths within fast_tolerance,
+W0_MFMA within its f16 bound.      python3 tools/fuzz_forward.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    import llama_cpp_amd                                             # noqa: F401
+    from llama_cpp_amd import seeddelta as hip
+    from llama_cpp_amd.payload import make_payload, make_x
+    import oracle_py as O
+    from test_gpu_forward import fast_tolerance
+    hip.init(0)
+    rng = np.random.default_rng(seed)
+    t0, n, by = time.time(), 0, {}
+    last = t0
+    dims_pool = [64, 96, 128, 200, 256, 320, 512, 700, 1024, 1152, 1500, 2048, 2500, 4096, 5000]
+    while time.time() - t0 < budget:
+        n_in, n_out = int(rng.choice(dims_pool)), int(rng.choice(dims_pool))
+        n_in = (n_in + 7) // 8 * 8 if rng.random() < 0.7 else n_in
+        scheme = "coo" if rng.random() < 0.5 else "block"
+        block = int(rng.choice([8, 12, 16, 32]))
+        K = int(rng.choice([1, 8, 20, 32, 64, 96, 128, 256]))
+        base = bool(rng.random() < 0.7)
+        T = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 17, 40, 130, 300]))
+        kw = dict(scheme=scheme, K=K, block=block, base=base, row_scale=bool(rng.random() < 0.8), d13_random=bool(base and rng.random() < 0.5),
+                  seed=int(rng.integers(1 << 30)))
+        if rng.random() < 0.25:
+            kw.update(idx_dtype=np.int32 if rng.random() < 0.5 else np.int16, val_dtype=np.float32 if rng.random() < 0.5 else np.float16)
+        if n_in > 32767:
+            kw["idx_dtype"] = np.int32
+        try:
+            p = make_payload(n_in, n_out, **kw)
+        except Exception:
+            continue
+        x = make_x(n_in, T, seed=int(rng.integers(1 << 30)))
+        y_ref = O.forward(p, x, nth=8)
+        try:
+            w = hip.SeedDeltaWeight(p)
+        except hip.SeedDeltaError:
+            continue
+        flagsets = [("default", 0), ("exact", hip.FWD_EXACT_ORDER), ("no_fuse", hip.FWD_NO_FUSE), ("no_spmm", hip.FWD_NO_SPMM)]
+        if base:
+            flagsets.append(("w0_mfma", hip.FWD_W0_MFMA))
+        tol = None
+        for name, fl in flagsets:
+            y = w.forward_host(x, fl)
+            exact = name == "exact" or (name in ("default", "no_fuse") and T >= 6)
+            ok = True
+            if exact:
+                ok = np.array_equal(y.view(np.uint32), y_ref.view(np.uint32))
+                if not ok and name != "exact":                           # a shape the tiled path declines runs the fast kernels
+                    exact = False
+            if not exact:
+                if tol is None:
+                    tol = fast_tolerance(p, x, y_ref)
+                bound = tol
+                if name == "w0_mfma":
+                    W0 = np.abs(O.w0_tile(p, 0, n_out, 0, n_in).astype(np.float64))
+                    rs = np.abs(p.row_scale.astype(np.float64))[None, :] if p.row_scale is not None else 1.0
+                    bound = 1.5e-3 * rs * (np.abs(x.astype(np.float64)) @ W0.T) + tol
+                err = np.abs(y.astype(np.float64) - y_ref.astype(np.float64))
+                ok = bool(np.all(err <= bound))
+            by[name] = by.get(name, 0) + 1
+            if not ok:
+                print("MISMATCH", dict(n_in=n_in, n_out=n_out, T=T, flags=name, **{k: (v.__name__ if isinstance(v, type) else v) for k, v in kw.items()}))
+                sys.exit(1)
+        w.close()
+        n += 1
+        if time.time() - last > 20:
+            last = time.time()
+            print(f"  ... {n} payloads, {time.time() - t0:.0f}s", flush=True)
+    print(f"fuzz_forward: {n} payloads, runs by flag set {by}, {time.time() - t0:.0f}s, seed {seed}: all within their bars")
+
+
+if __name__ == "__main__":
+    main()
