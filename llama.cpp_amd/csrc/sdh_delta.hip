@@ -76,6 +76,157 @@ void delta_rows_kernel(const DeltaParams p) {
     }
 }
 
+// Many tokens of a block payload with long rows and long inputs (cfg3: block 32, K = 1536, n_in = 14336, T = 512),
+// where the SpMM form's lane-per-row walk re-fetches every payload line eight times and loses to the per-token
+// kernel. The per-token kernel in turn gathers 6 KB of activations per (row, token) through the L2 — 12.9 GB per
+// ubatch — and lives for one row: a wave's set-up, its L2 round trips and its reduction are all exposed.
+// Here the activations of NT tokens live in the LDS and a wave walks rows with all 64 lanes on a row (Ktot > 256),
+// coalesced 16-byte payload loads as in the per-token kernel: the L2 sees the payload once per NT tokens and the
+// gather becomes two 16-byte LDS reads per step and token. The tile is stored as two planes per token, plane h
+// holding floats 8c + 4h .. 8c + 4h + 3 of every 8-float chunk c, so that the lanes of a block read consecutive
+// 16-byte words (no bank conflicts inside a block). With the tile filling the LDS a CU holds sixteen waves, too few
+// to stand behind an L2 round trip per row, so everything a row needs from memory (index and value words, its scale,
+// up to four base terms) is requested one row ahead.
+// Per token the products and sums are delta_row_partial's (dot8, add_if in step order) and the lanes are summed in
+// group_reduce's pairing (lane i with lane i ^ m, m = 32 .. 1), so results are bit-identical to the one-token kernel;
+// only the data movement of the reduction differs: the m = 32 (and, for four tokens, m = 16) exchange swaps half
+// registers between the tokens' sums, which leaves token t's sum in a lane segment of its own, and the steps inside
+// a 16-lane row are DPP moves.
+template <int CTRL> __device__ __forceinline__ float dpp_partner(float a) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_reduce_to_lane0(float a) {      // valid in lane 0 of every 16-lane row
+    a = __fadd_rn(a, dpp_partner<0x108>(a));            // row_shl:8   lane i <- i + 8
+    a = __fadd_rn(a, dpp_partner<0x104>(a));            // row_shl:4
+    a = __fadd_rn(a, dpp_partner<0x4E>(a));             // quad_perm [2,3,0,1]
+    a = __fadd_rn(a, dpp_partner<0xB1>(a));             // quad_perm [1,0,3,2]
+    return a;
+}
+__device__ __forceinline__ float swap32_add(float a, float b) {         // lanes 0-31: a[i] + a[i+32]; lanes 32-63: b[i-32] + b[i]
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __fadd_rn(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float swap16_add(float a, float b) {         // even rows: a[row] + a[row+1]; odd rows: b[row-1] + b[row]
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __fadd_rn(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+template <typename IDX_T, typename VAL_T, int STEPS, int NT>
+__global__ __launch_bounds__(1024)
+void delta_rows_block_lds_kernel(const DeltaParams p, const int64_t T, const int rows_per_wg) {
+    extern __shared__ float4 xs4[];                     // [NT][2][n_in / 8]
+    static_assert(NT == 2 || NT == 4, "two or four tokens");
+    constexpr int NS = STEPS;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int nch = p.n_in >> 3;
+    const int64_t t0 = (int64_t) blockIdx.x * NT;
+    const int nt = (int) ((T - t0 < NT) ? (T - t0) : NT);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float * xt = p.x + (t0 + (t < nt ? t : nt - 1)) * p.ldx;
+        for (int c = tid; c < nch; c += 1024) {
+            xs4[(t * 2 + 0) * nch + c] = *reinterpret_cast<const float4 *>(xt + c * 8);
+            xs4[(t * 2 + 1) * nch + c] = *reinterpret_cast<const float4 *>(xt + c * 8 + 4);
+        }
+    }
+    __syncthreads();
+
+    const int r0 = (int) blockIdx.y * rows_per_wg;
+    const int r1 = min(p.n_out, r0 + rows_per_wg);
+    int e0[NS], bi[NS], off[NS];
+    bool eok[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        const int e = (u * 64 + lane) * 8;
+        eok[u] = e < p.Ktot;
+        e0[u] = eok[u] ? e : 0;
+        bi[u] = e0[u] >> p.block_shift;
+        off[u] = e0[u] & (p.block - 1);
+    }
+    const VAL_T * val = reinterpret_cast<const VAL_T *>(p.val);
+    const IDX_T * idx = reinterpret_cast<const IDX_T *>(p.idx);
+    // the token whose sum the reduction leaves in this lane's segment: halves hold tokens 0, 1; rows hold 0, 2, 1, 3
+    const int seg = NT == 2 ? (lane >> 5) : (lane >> 4);
+    const int my_t = NT == 2 ? seg : (((seg & 1) << 1) | (seg >> 1));
+    const bool lead = (lane & (64 / NT - 1)) == 0 && my_t < nt;
+    constexpr int NB = 4;
+    const int nbase = p.v ? (p.tall ? 1 : p.B) : 0;
+    const float * vt = p.v + (size_t) (t0 + (my_t < nt ? my_t : 0)) * (size_t) p.v_ld;
+    IDX_T blk_n[NS];
+    Vec8<VAL_T> vv_n[NS];
+    float vb_n[NB], scale_n = 1.0f;
+    auto request = [&](int on) {
+        const int orow = on < r1 ? on : r0;
+#pragma unroll
+        for (int u = 0; u < NS; ++u) blk_n[u] = idx[(size_t) orow * p.nb + bi[u]];
+#pragma unroll
+        for (int u = 0; u < NS; ++u) vv_n[u].load(val + (size_t) orow * p.Ktot + e0[u]);
+        if (lead) {
+            if (p.rs) scale_n = p.rs[orow];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) vb_n[b] = (b < nbase) ? vt[(size_t) b * p.L + orow] : 0.0f;
+        }
+    };
+    int o = r0 + wave;                                   // one row per wave and pass, uniform over the wave
+    request(o);
+    for (; o < r1; o += 16) {
+        int c0[NS];
+        bool ok[NS];
+        Vec8<VAL_T> vv[NS];
+        float vb[NB];
+        const float scale = scale_n;
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const int blk = idx_to_i32<IDX_T>(blk_n[u]);
+            const int raw = (blk << p.block_shift) + off[u];
+            ok[u] = eok[u] & ((unsigned) blk < (unsigned) p.n_blk_in) & (raw < p.n_in);
+            c0[u] = (ok[u] ? raw : 0) >> 3;
+            vv[u] = vv_n[u];
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) vb[b] = vb_n[b];
+        request(o + 16);
+        float acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float4 xa[NS], xb[NS];
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                xa[u] = xs4[(t * 2 + 0) * nch + c0[u]];
+                xb[u] = xs4[(t * 2 + 1) * nch + c0[u]];
+            }
+            acc[t] = 0.0f;
+#pragma unroll
+            for (int u = 0; u < NS; ++u) acc[t] = add_if(acc[t], ok[u], dot8<VAL_T>(vv[u], xa[u], xb[u]));
+            if (NT > 2 && (t & 1) && t + 1 < NT) __builtin_amdgcn_sched_barrier(0);    // two tokens' reads in flight, not four
+        }
+        float a;
+        if constexpr (NT == 2) {
+            a = swap32_add(acc[0], acc[1]);              // m = 32: token 0 in lanes 0-31, token 1 in lanes 32-63
+            a = swap16_add(a, a);                        // m = 16
+        } else {
+            const float a01 = swap32_add(acc[0], acc[1]);
+            const float a23 = swap32_add(acc[2], acc[3]);
+            a = swap16_add(a01, a23);                    // rows: tokens 0, 2, 1, 3
+        }
+        a = row16_reduce_to_lane0(a);                    // m = 8, 4, 2, 1
+        if (lead) {
+            float yh = 0.0f;
+            if (p.v) {
+                if (p.tall) yh = vb[0];
+                else {
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) if (b < nbase) yh += vb[b];
+                    for (int b = NB; b < nbase; ++b) yh += vt[(size_t) b * p.L + o];
+                }
+            }
+            store_output(p, o, t0 + my_t, yh + a, scale);
+        }
+    }
+}
+
 template <typename IDX_T, typename VAL_T, bool BLOCK>
 __global__ __launch_bounds__(256)
 void delta_rows_scalar_kernel(const DeltaParams p) {
@@ -175,6 +326,36 @@ static int launch_typed(const DeltaLaunch & a, DeltaParams & p, hipStream_t s) {
         return SDH_ERR_UNSUPPORTED;
     }
     dim3 grid((unsigned) a.T, gy);
+    // many tokens of a block payload: activations of two or four tokens in the LDS, rows walked wave by wave
+    if constexpr (BLOCK) {
+        static const bool no_lds = getenv("SDH_ROWS_NO_LDS") != nullptr;           // dev: A/B
+        const size_t col = (size_t) p.n_in * sizeof(float);
+        const size_t budget = 152 * 1024;
+        const int max_steps = sizeof(VAL_T) == 4 ? 3 : 4;          // fp32 values at four steps would spill (128 registers per lane)
+        if (vec_ok && a.T >= 8 && G == 64 && steps >= 1 && steps <= max_steps && !no_lds && col * 2 <= budget) {
+            const int nt = col * 4 <= budget ? 4 : 2;
+            const int64_t tiles = (a.T + nt - 1) / nt;
+            const int rows_pass = 16;                       // a row per wave
+            int64_t chunks = (4 * (int64_t) lib().num_cu + tiles - 1) / tiles;
+            const int64_t max_chunks = (p.n_out + rows_pass - 1) / rows_pass;
+            if (chunks > max_chunks) chunks = max_chunks;
+            if (chunks < 1) chunks = 1;
+            int rows_per_wg = (int) ((p.n_out + chunks - 1) / chunks);
+            rows_per_wg = (rows_per_wg + rows_pass - 1) / rows_pass * rows_pass;
+            const unsigned gl = (unsigned) ((p.n_out + rows_per_wg - 1) / rows_per_wg);
+            void (*kern)(const DeltaParams, int64_t, int) = nullptr;
+            switch (steps) {
+                case 1:  kern = nt == 4 ? delta_rows_block_lds_kernel<IDX_T, VAL_T, 1, 4> : delta_rows_block_lds_kernel<IDX_T, VAL_T, 1, 2>; break;
+                case 2:  kern = nt == 4 ? delta_rows_block_lds_kernel<IDX_T, VAL_T, 2, 4> : delta_rows_block_lds_kernel<IDX_T, VAL_T, 2, 2>; break;
+                case 3:  kern = nt == 4 ? delta_rows_block_lds_kernel<IDX_T, VAL_T, 3, 4> : delta_rows_block_lds_kernel<IDX_T, VAL_T, 3, 2>; break;
+                default: if constexpr (sizeof(VAL_T) == 2) kern = nt == 4 ? delta_rows_block_lds_kernel<IDX_T, VAL_T, 4, 4> : delta_rows_block_lds_kernel<IDX_T, VAL_T, 4, 2>; break;
+            }
+            SDH_HIP_CHECK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            hipLaunchKernelGGL(kern, dim3((unsigned) tiles, gl), dim3(1024), col * nt, s, p, a.T, rows_per_wg);
+            SDH_HIP_CHECK(hipGetLastError());
+            return SDH_OK;
+        }
+    }
     if (vec_ok) {
         switch (steps) {
             case 1:  hipLaunchKernelGGL((delta_rows_kernel<IDX_T, VAL_T, BLOCK, 1>), grid, dim3(256), 0, s, p); break;

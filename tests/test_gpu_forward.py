@@ -371,6 +371,50 @@ def test_prefill_spmm_is_bit_exact(hip, scheme, K, block, base, dims, T):
     check_fast(p, x, w.forward_host(x, hip.FWD_NO_SPMM), y_ref)
 
 
+ROW_KERNEL_CASES = [
+    # scheme, K, block, n_in, n_out, idx dtype, val dtype
+    ("coo", 64, 16, 1152, 864, np.int16, np.float16),
+    ("coo", 256, 16, 1152, 864, np.int16, np.float16),
+    ("block", 64, 16, 1152, 864, np.int16, np.float16),
+    ("block", 512, 32, 2048, 320, np.int16, np.float16),        # one step, four tokens in the LDS
+    ("block", 1024, 32, 2048, 320, np.int16, np.float16),       # two steps
+    ("block", 1536, 32, 2048, 320, np.int16, np.float16),       # three steps
+    ("block", 2048, 32, 2048, 320, np.int16, np.float16),       # four steps
+    ("block", 1536, 32, 10240, 200, np.int16, np.float16),      # long input: two tokens in the LDS
+    ("block", 2048, 64, 12288, 100, np.int16, np.float16),
+    ("block", 768, 16, 2048, 320, np.int32, np.float32),        # fp32 values, int32 block indices
+    ("block", 1536, 32, 10240, 200, np.int32, np.float32),
+    ("block", 2048, 32, 2048, 320, np.int16, np.float32),       # fp32 values at four steps: per-token kernel
+]
+
+
+@pytest.mark.parametrize("case", ROW_KERNEL_CASES, ids=lambda c: f"{c[0]}-K{c[1]}-b{c[2]}-{c[3]}x{c[4]}-{np.dtype(c[5]).name}-{np.dtype(c[6]).name}")
+@pytest.mark.parametrize("base", [False, True])
+@pytest.mark.parametrize("T", [5, 8, 9, 11, 130])
+def test_row_kernels_many_tokens_equal_one_token_calls(hip, case, base, T):
+    """Calls that stay on the row kernels (SpMM off or not applicable). From 8 tokens on, block payloads with
+    rows longer than 256 entries keep the activations of two or four tokens in the LDS and walk the rows with
+    a different reduction data path; each token's arithmetic and the pairing of the lane sums are the
+    one-token kernel's, so every token's output equals its own one-token call bit for bit — ragged token
+    counts (last tile with 1..3 tokens), bad block indices and a ragged last block included."""
+    scheme, K, block, n_in, n_out, idx_dtype, val_dtype = case
+    kw = dict(idx_dtype=idx_dtype, val_dtype=val_dtype)
+    if val_dtype is np.float32:
+        kw.update(rs_dtype=np.float32, base_dtype=np.float32, perm_dtype=np.int32)
+    p = make_payload(n_in, n_out, scheme=scheme, K=K, block=block, base=base, d13_random=base, seed=K + T, **kw)
+    if scheme == "block":
+        p.b_idx = p.b_idx.copy(); p.b_idx[::7, 1] = -1; p.b_idx[::5, 2] = n_in // block + 3
+    x = make_x(n_in, T, seed=T + 1)
+    w = hip.SeedDeltaWeight(p)
+    flags = hip.FWD_NO_SPMM | hip.FWD_NO_FUSE
+    pick = sorted(set(range(min(T, 6))) | {T - 1, T - 2})
+    single = np.concatenate([w.forward_host(x[t:t + 1], hip.FWD_NO_FUSE) for t in pick], axis=0)
+    y = w.forward_host(x, flags)
+    assert np.array_equal(bits(y[pick]), bits(single))
+    check_fast(p, x, y, O.forward(p, x, nth=8))
+    assert w.nonfinite_count() == 0
+
+
 def test_prefill_spmm_dtypes_and_bad_indices(hip):
     for idx_dtype, val_dtype in ((np.int32, np.float32), (np.int16, np.float32), (np.int32, np.float16)):
         for scheme in ("coo", "block"):
