@@ -92,25 +92,6 @@ void delta_rows_kernel(const DeltaParams p) {
 // only the data movement of the reduction differs: the m = 32 (and, for four tokens, m = 16) exchange swaps half
 // registers between the tokens' sums, which leaves token t's sum in a lane segment of its own, and the steps inside
 // a 16-lane row are DPP moves.
-template <int CTRL> __device__ __forceinline__ float dpp_partner(float a) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float row16_reduce_to_lane0(float a) {      // valid in lane 0 of every 16-lane row
-    a = __fadd_rn(a, dpp_partner<0x108>(a));            // row_shl:8   lane i <- i + 8
-    a = __fadd_rn(a, dpp_partner<0x104>(a));            // row_shl:4
-    a = __fadd_rn(a, dpp_partner<0x4E>(a));             // quad_perm [2,3,0,1]
-    a = __fadd_rn(a, dpp_partner<0xB1>(a));             // quad_perm [1,0,3,2]
-    return a;
-}
-__device__ __forceinline__ float swap32_add(float a, float b) {         // lanes 0-31: a[i] + a[i+32]; lanes 32-63: b[i-32] + b[i]
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __fadd_rn(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float swap16_add(float a, float b) {         // even rows: a[row] + a[row+1]; odd rows: b[row-1] + b[row]
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __fadd_rn(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-
 template <typename IDX_T, typename VAL_T, int STEPS, int NT>
 __global__ __launch_bounds__(1024)
 void delta_rows_block_lds_kernel(const DeltaParams p, const int64_t T, const int rows_per_wg) {

@@ -342,8 +342,38 @@ __device__ __forceinline__ void delta_row_partial_coo_lds4(const DeltaParams & p
 // reduce over the G lanes that own a row (G a power of two, groups aligned); every lane of the
 // group ends with the sum. (A DPP row-shift + v_readlane form of this reduction measured slower in the
 // fused decode launch, 7.78 vs 7.65 us on cfg3, and was dropped.)
+template <int CTRL> __device__ __forceinline__ float dpp_partner(float a) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_reduce_to_lane0(float a) {      // valid in lane 0 of every 16-lane row
+    a = __fadd_rn(a, dpp_partner<0x108>(a));            // row_shl:8   lane i <- i + 8
+    a = __fadd_rn(a, dpp_partner<0x104>(a));            // row_shl:4
+    a = __fadd_rn(a, dpp_partner<0x4E>(a));             // quad_perm [2,3,0,1]
+    a = __fadd_rn(a, dpp_partner<0xB1>(a));             // quad_perm [1,0,3,2]
+    return a;
+}
+__device__ __forceinline__ float swap32_add(float a, float b) {         // lanes 0-31: a[i] + a[i+32]; lanes 32-63: b[i-32] + b[i]
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __fadd_rn(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float swap16_add(float a, float b) {         // even rows: a[row] + a[row+1]; odd rows: b[row-1] + b[row]
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __fadd_rn(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+// Sum over the G lanes of a group (G a power of two <= 64, groups aligned), valid in the group's lane 0 — the only
+// lane any caller reads. The pairing is the butterfly's (lane i with lane i ^ m for m = G/2 .. 1, a rounded add per
+// step), so lane 0 holds the bits `for m: acc += shfl_xor(acc, m)` gives; but the partner arrives by a half-register
+// swap (m = 32, 16) or a DPP move inside the 16-lane row (m <= 8) instead of a ds_bpermute with its address
+// arithmetic and LDS-pipe round trip per step, which stood on every wave's critical path between its last
+// multiply-add and its store. The branches are uniform (G is a kernel argument).
 __device__ __forceinline__ float group_reduce(float acc, int G) {
-    for (int m = G >> 1; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    if (G > 32) acc = swap32_add(acc, acc);
+    if (G > 16) acc = swap16_add(acc, acc);
+    if (G > 8)  acc = __fadd_rn(acc, dpp_partner<0x108>(acc));          // row_shl:8   lane i <- i + 8
+    if (G > 4)  acc = __fadd_rn(acc, dpp_partner<0x104>(acc));          // row_shl:4
+    if (G > 2)  acc = __fadd_rn(acc, dpp_partner<0x4E>(acc));           // quad_perm [2,3,0,1]
+    if (G > 1)  acc = __fadd_rn(acc, dpp_partner<0xB1>(acc));           // quad_perm [1,0,3,2]
     return acc;
 }
 
