@@ -307,13 +307,16 @@ static int launch_typed(const DeltaLaunch & a, DeltaParams & p, hipStream_t s) {
         return SDH_ERR_UNSUPPORTED;
     }
     dim3 grid((unsigned) a.T, gy);
-    // many tokens of a block payload: activations of two or four tokens in the LDS, rows walked wave by wave
+    // many tokens of a block payload: activations of two or four tokens in the LDS, rows walked wave by wave. A tile fill
+    // per workgroup has to pay for itself: cfg3 (us per call, LDS form / per-token kernels): T=4 17.2 / 17.1, T=8 25.8 / 24.9,
+    // T=12 27.5 / 29.8, T=16 32.6 / 35.5, T=32 42.4 / 60.1, T=512 360 / 800
     if constexpr (BLOCK) {
         static const bool no_lds = getenv("SDH_ROWS_NO_LDS") != nullptr;           // dev: A/B
         const size_t col = (size_t) p.n_in * sizeof(float);
         const size_t budget = 152 * 1024;
         const int max_steps = sizeof(VAL_T) == 4 ? 3 : 4;          // fp32 values at four steps would spill (128 registers per lane)
-        if (vec_ok && a.T >= 8 && G == 64 && steps >= 1 && steps <= max_steps && !no_lds && col * 2 <= budget) {
+        static const int lds_min_t = getenv("SDH_ROWS_LDS_MIN_T") ? atoi(getenv("SDH_ROWS_LDS_MIN_T")) : 10;  // dev: A/B
+        if (vec_ok && a.T >= lds_min_t && G == 64 && steps >= 1 && steps <= max_steps && !no_lds && col * 2 <= budget) {
             const int nt = col * 4 <= budget ? 4 : 2;
             const int64_t tiles = (a.T + nt - 1) / nt;
             const int rows_pass = 16;                       // a row per wave

@@ -390,9 +390,9 @@ ROW_KERNEL_CASES = [
 
 @pytest.mark.parametrize("case", ROW_KERNEL_CASES, ids=lambda c: f"{c[0]}-K{c[1]}-b{c[2]}-{c[3]}x{c[4]}-{np.dtype(c[5]).name}-{np.dtype(c[6]).name}")
 @pytest.mark.parametrize("base", [False, True])
-@pytest.mark.parametrize("T", [5, 8, 9, 11, 130])
+@pytest.mark.parametrize("T", [5, 9, 10, 11, 13, 130])
 def test_row_kernels_many_tokens_equal_one_token_calls(hip, case, base, T):
-    """Calls that stay on the row kernels (SpMM off or not applicable). From 8 tokens on, block payloads with
+    """Calls that stay on the row kernels (SpMM off or not applicable). From 10 tokens on, block payloads with
     rows longer than 256 entries keep the activations of two or four tokens in the LDS and walk the rows with
     a different reduction data path; each token's arithmetic and the pairing of the lane sums are the
     one-token kernel's, so every token's output equals its own one-token call bit for bit — ragged token
