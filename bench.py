@@ -406,14 +406,15 @@ def run_ffn_stack(args, dev):
 
 
 PREFILL_WORKLOADS = ("cfg4_mistral_gate_coo_k128", "cfg4_mistral_gate_block16_k128",
-                     "cfg4_mistral_down_coo_k128", "cfg4_mistral_down_block16_k128")
+                     "cfg4_mistral_down_coo_k128", "cfg4_mistral_down_block16_k128",
+                     "cfg3_mistral_down_block32_k1536")
 MFMA_F16_PEAK_TFLOPS = 2500.0      # dense f16/bf16 MFMA (MI355X_MICROARCH.md); never the 2:1-sparsity figure
 VALU_F32_PEAK_TFLOPS = 157.3
 
 
 def run_prefill(args, dev):
-    """Prefill leg (config 4): Mistral-7B gate / down, K=128, COO vs block16, base on, one ubatch of T=512
-    tokens per call. Per workload: the default path (FWHT base + sparse x dense residual) and the W0-on-MFMA
+    """Prefill leg (config 4, and config 3's tensor): Mistral-7B gate / down, K=128, COO vs block16, and the down
+    tensor at block 32 / K=1536 (long rows: LDS rows kernel), base on, one ubatch of T=512 tokens per call. Per workload: the default path (FWHT base + sparse x dense residual) and the W0-on-MFMA
     base (SDH_FWD_W0_MFMA), each timed on one explicit stream with the library's events. Rooflines: HBM for the
     algorithmic bytes (payload as stored + 4*T*(n_in+n_out)); fp32 VALU for the residual's
     multiply-adds (2*K*n_out*T); dense f16 MFMA for the W0 contraction (2*n_in*n_out*T)."""
@@ -461,7 +462,7 @@ def run_prefill(args, dev):
         w.close()
         del x, y
         torch.cuda.empty_cache()
-    return {"metric": "prefill ubatch (T=512) per tensor, Mistral-7B K=128", "workloads": legs,
+    return {"metric": "prefill ubatch (T=512) per tensor, Mistral-7B (config 4: K=128; config 3: block 32, K=1536)", "workloads": legs,
             "timing": "HIP events recorded by the library on the explicit launch stream / reps",
             "reference_cpu_seconds": {"cfg4_mistral_gate_coo_k128": 1.21, "cfg4_mistral_gate_block16_k128": 0.83,
                                       "cfg4_mistral_down_coo_k128": 0.35, "cfg4_mistral_down_block16_k128": 0.24,

@@ -33,9 +33,9 @@ def main():
         n_in = (n_in + 7) // 8 * 8 if rng.random() < 0.7 else n_in
         scheme = "coo" if rng.random() < 0.5 else "block"
         block = int(rng.choice([8, 12, 16, 32]))
-        K = int(rng.choice([1, 8, 20, 32, 64, 96, 128, 256]))
+        K = int(rng.choice([1, 8, 20, 32, 64, 96, 128, 256, 384, 512, 1024, 1536]))
         base = bool(rng.random() < 0.7)
-        T = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 17, 40, 130, 300]))
+        T = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 17, 40, 130, 300]))
         kw = dict(scheme=scheme, K=K, block=block, base=base, row_scale=bool(rng.random() < 0.8), d13_random=bool(base and rng.random() < 0.5),
                   seed=int(rng.integers(1 << 30)))
         if rng.random() < 0.25:
