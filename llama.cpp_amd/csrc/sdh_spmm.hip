@@ -23,14 +23,97 @@ namespace sdh {
 // cycle (block 16 or 32, TT 8) every lane of a pass hit the same banks (rocprof: 87 % of the LDS cycles of a
 // Mistral gate block16 ubatch were bank conflicts, 8-way). With the spare row the start bank follows blk mod 8,
 // as scattered as the COO gathers are.
+//
+// COO: the rows are de-interleaved by fours, input i in row (i & 3) * n4 + (i >> 2) with n4 = ceil(n_in / 4). The
+// gathers do not care (any bijection serves), and the FILL can then read x sixteen bytes at a time: a lane loads
+// inputs 4g .. 4g+3 of each token of a group and stores input 4g+j's tokens to row j * n4 + g — consecutive lanes,
+// consecutive rows, as conflict-free as the one-input-per-lane fill was, at a quarter of the global loads. With few
+// tokens the fill IS the kernel (a 256-thread workgroup fills 128 KB through a chain of L2 round trips: 15 of the
+// 59 us of a Mistral FFN layer at 8 tokens were tile fills).
 template <bool BLOCK>
-__device__ __forceinline__ int tile_row(const DeltaParams & p, int i) {
-    if constexpr (!BLOCK) return i;
+__device__ __forceinline__ int tile_row(const DeltaParams & p, int i, int n4) {
+    if constexpr (!BLOCK) return (i & 3) * n4 + (i >> 2);
     return i + (p.block_shift >= 0 ? (i >> p.block_shift) : (i / p.block));
 }
 template <bool BLOCK>
 static size_t spmm_tile_rows(const DeltaParams & p) {
-    return BLOCK ? (size_t) p.n_in + (size_t) ((p.n_in + p.block - 1) / p.block) : (size_t) p.n_in;
+    return BLOCK ? (size_t) p.n_in + (size_t) ((p.n_in + p.block - 1) / p.block) : (size_t) ((p.n_in + 3) / 4) * 4;
+}
+
+// Tile fill, GRP tokens at a time (one 4*GRP-byte LDS store per input and token group; tokens past the end of the batch
+// are zero). xs: [rows][TT].
+template <bool BLOCK, int TT, int GRP, int NTH>
+__device__ __forceinline__ void spmm_fill_tile(const DeltaParams & p, float * xs, int64_t t0, int nt, int n4, int tid) {
+    typedef float gvec __attribute__((ext_vector_type(GRP)));
+    static_assert(TT % GRP == 0, "token groups tile the tile");
+    for (int q = 0; q < TT; q += GRP) {
+        if (q >= nt) {                                   // a whole group past the end of the batch
+            gvec z;
+#pragma unroll
+            for (int u = 0; u < GRP; ++u) z[u] = 0.0f;
+            for (int i = tid; i < p.n_in; i += NTH) *reinterpret_cast<gvec *>(xs + (size_t) tile_row<BLOCK>(p, i, n4) * TT + q) = z;
+            continue;
+        }
+        const float * xt[GRP];
+#pragma unroll
+        for (int u = 0; u < GRP; ++u) xt[u] = p.x + (t0 + min(q + u, nt - 1)) * p.ldx;
+        int i = tid;
+        if constexpr (!BLOCK) {
+            if (p.x_vec_ok) {                            // 16-byte loads: two quads of inputs per trip
+                const int nq = p.n_in >> 2;
+                auto put = [&](int g, const float4 (&v)[GRP]) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        gvec w;
+#pragma unroll
+                        for (int u = 0; u < GRP; ++u) {
+                            const float c = j == 0 ? v[u].x : j == 1 ? v[u].y : j == 2 ? v[u].z : v[u].w;
+                            w[u] = (q + u < nt) ? c : 0.0f;
+                        }
+                        *reinterpret_cast<gvec *>(xs + ((size_t) j * n4 + g) * TT + q) = w;
+                    }
+                };
+                int g = tid;
+                for (; g + NTH < nq; g += 2 * NTH) {
+                    float4 va[GRP], vb[GRP];
+#pragma unroll
+                    for (int u = 0; u < GRP; ++u) va[u] = *reinterpret_cast<const float4 *>(xt[u] + 4 * g);
+#pragma unroll
+                    for (int u = 0; u < GRP; ++u) vb[u] = *reinterpret_cast<const float4 *>(xt[u] + 4 * (g + NTH));
+                    put(g, va);
+                    put(g + NTH, vb);
+                }
+                for (; g < nq; g += NTH) {
+                    float4 va[GRP];
+#pragma unroll
+                    for (int u = 0; u < GRP; ++u) va[u] = *reinterpret_cast<const float4 *>(xt[u] + 4 * g);
+                    put(g, va);
+                }
+                i = 4 * nq + tid;                        // the inputs of a last partial quad, one by one below
+            }
+        }
+        // one input per lane and trip, four trips' loads in flight
+        for (; i + 3 * NTH < p.n_in; i += 4 * NTH) {
+            gvec v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int u = 0; u < GRP; ++u) v[k][u] = xt[u][i + k * NTH];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int u = 0; u < GRP; ++u) if (q + u >= nt) v[k][u] = 0.0f;
+                *reinterpret_cast<gvec *>(xs + (size_t) tile_row<BLOCK>(p, i + k * NTH, n4) * TT + q) = v[k];
+            }
+        }
+        for (; i < p.n_in; i += NTH) {
+            gvec v;
+#pragma unroll
+            for (int u = 0; u < GRP; ++u) v[u] = (q + u < nt) ? xt[u][i] : 0.0f;
+            *reinterpret_cast<gvec *>(xs + (size_t) tile_row<BLOCK>(p, i, n4) * TT + q) = v;
+        }
+    }
 }
 
 template <typename IDX_T, typename VAL_T, bool BLOCK, bool VEC, int TT, int NTH>
@@ -41,14 +124,8 @@ void delta_spmm_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
     const int tid = threadIdx.x;
     const int64_t t0 = (int64_t) blockIdx.x * TT;
     const int nt = (int) ((T - t0 < TT) ? (T - t0) : TT);
-    for (int t = 0; t < nt; ++t) {
-        const float * xt = p.x + (t0 + t) * p.ldx;
-        for (int i = tid; i < p.n_in; i += NTH) xs[tile_row<BLOCK>(p, i) * TT + t] = xt[i];
-    }
-    if (nt < TT) {                                      // ragged last tile: idle lanes read zeros
-        for (int i = tid; i < p.n_in; i += NTH)
-            for (int t = nt; t < TT; ++t) xs[tile_row<BLOCK>(p, i) * TT + t] = 0.0f;
-    }
+    const int n4 = (p.n_in + 3) >> 2;
+    spmm_fill_tile<BLOCK, TT, (TT % 4 == 0 ? 4 : TT % 2 == 0 ? 2 : 1), NTH>(p, xs, t0, nt, n4, tid);   // ragged last tile: zeros
     __syncthreads();
 
     const int t = tid % TT;
@@ -101,7 +178,7 @@ void delta_spmm_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
                     for (int u = 0; u < 8; ++u) {
                         const int i = idx_to_i32<IDX_T>(ii.get(u));
                         const bool ok = (unsigned) i < (unsigned) p.n_in;
-                        const float prod = val_to_f32<VAL_T>(vv.get(u)) * xs[(ok ? i : 0) * TT + t];
+                        const float prod = val_to_f32<VAL_T>(vv.get(u)) * xs[tile_row<false>(p, ok ? i : 0, n4) * TT + t];
                         y = ok ? y + prod : y;
                     }
                 }
@@ -109,7 +186,7 @@ void delta_spmm_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
                 for (int e = 0; e < p.Ktot; ++e) {
                     const int i = idx_to_i32<IDX_T>(irow[e]);
                     if ((unsigned) i >= (unsigned) p.n_in) continue;
-                    const float prod = val_to_f32<VAL_T>(vrow[e]) * xs[i * TT + t];
+                    const float prod = val_to_f32<VAL_T>(vrow[e]) * xs[tile_row<false>(p, i, n4) * TT + t];
                     y = y + prod;
                 }
             }
@@ -135,19 +212,8 @@ void delta_spmm4_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
     const int tid = threadIdx.x;
     const int64_t t0 = (int64_t) blockIdx.x * TT;
     const int nt = (int) ((T - t0 < TT) ? (T - t0) : TT);
-    // the tile is written TPL tokens at a time: one 16- or 8-byte LDS store per (input, token group) instead of TPL
-    // 4-byte stores TT*4 bytes apart (8-way bank conflicts at TT = 8); tokens past the end of the batch are zero
-    for (int q = 0; q < TT; q += TPL) {
-        const float * xt[TPL];
-#pragma unroll
-        for (int u = 0; u < TPL; ++u) xt[u] = p.x + (t0 + min(q + u, nt - 1)) * p.ldx;
-        for (int i = tid; i < p.n_in; i += NTH) {
-            xvec v;
-#pragma unroll
-            for (int u = 0; u < TPL; ++u) v[u] = (q + u < nt) ? xt[u][i] : 0.0f;
-            *reinterpret_cast<xvec *>(xs + (size_t) tile_row<BLOCK>(p, i) * TT + q) = v;
-        }
-    }
+    const int n4 = (p.n_in + 3) >> 2;
+    spmm_fill_tile<BLOCK, TT, TPL, NTH>(p, xs, t0, nt, n4, tid);
     __syncthreads();
 
     const int tq = (tid % LPR) * TPL;                   // first of this lane's tokens within the tile
@@ -219,10 +285,10 @@ void delta_spmm4_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
                 }
                 if (all_ok) {
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) mac(val_to_f32<VAL_T>(vv.get(u)), xq[ix[u] * LPR]);
+                    for (int u = 0; u < 8; ++u) mac(val_to_f32<VAL_T>(vv.get(u)), xq[tile_row<false>(p, ix[u], n4) * LPR]);
                 } else {
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) if ((unsigned) ix[u] < (unsigned) p.n_in) mac(val_to_f32<VAL_T>(vv.get(u)), xq[ix[u] * LPR]);
+                    for (int u = 0; u < 8; ++u) if ((unsigned) ix[u] < (unsigned) p.n_in) mac(val_to_f32<VAL_T>(vv.get(u)), xq[tile_row<false>(p, ix[u], n4) * LPR]);
                 }
             }
         }
@@ -232,6 +298,12 @@ void delta_spmm4_kernel(const DeltaParams p, int64_t T, int rows_per_wg) {
         for (int u = 0; u < TPL; ++u) if (tq + u < nt) store_output(p, o, t0 + tq + u, y[u], scale);
     }
 }
+
+// Two-token tiles: a lane takes both tokens of a row (half the LDS reads and payload unpacking per multiply-add) only
+// when the launch has tiles to spare; with few tokens that halves the lanes at work and the one-token form wins
+// (Mistral down tensor, T=8: 12.7 us against 27.8 us; FFN layer, COO / block16, us: T=64 98.6 / 79.7 against 106 / 83.4,
+// T=128 170 / 136 against 169 / 131, T=512 542 / 438 against 543 / 429).
+static inline bool spmm_two_per_lane(int64_t T) { return T >= 96; }
 
 // NTH threads per workgroup. A tile fills the LDS of a CU, so a launch has at most tiles x ceil(n_out / rows of one
 // pass) workgroups: with 1024 threads and few tokens that is a handful (T=8, Mistral gate: 28 workgroups on 256 CUs —
@@ -246,7 +318,7 @@ static int launch_tt_n(const DeltaParams & p, int64_t T, hipStream_t s) {
     if constexpr (VEC && TT % 4 == 0) {
         if (!one_token) { kern = delta_spmm4_kernel<IDX_T, VAL_T, BLOCK, TT, NTH, 4>; lanes_per_row = TT / 4; }
     } else if constexpr (VEC && TT == 2) {               // long inputs: both tokens of the tile in one lane, one 8-byte LDS read per entry
-        if (!one_token) { kern = delta_spmm4_kernel<IDX_T, VAL_T, BLOCK, TT, NTH, 2>; lanes_per_row = 1; }
+        if (!one_token && spmm_two_per_lane(T)) { kern = delta_spmm4_kernel<IDX_T, VAL_T, BLOCK, TT, NTH, 2>; lanes_per_row = 1; }
     }
     SDH_HIP_CHECK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const int64_t tiles = (T + TT - 1) / TT;
@@ -269,7 +341,7 @@ static int launch_tt_n(const DeltaParams & p, int64_t T, hipStream_t s) {
 template <typename IDX_T, typename VAL_T, bool BLOCK, bool VEC, int TT>
 static int launch_tt(const DeltaParams & p, int64_t T, hipStream_t s) {
     const int64_t tiles = (T + TT - 1) / TT;
-    const int lanes_per_row = (VEC && TT % 4 == 0) ? TT / 4 : (VEC && TT == 2) ? 1 : TT;
+    const int lanes_per_row = (VEC && TT % 4 == 0) ? TT / 4 : (VEC && TT == 2 && spmm_two_per_lane(T)) ? 1 : TT;
     const int64_t wgs_1024 = tiles * ((p.n_out + 1024 / lanes_per_row - 1) / (1024 / lanes_per_row));
     static const int force = [] { const char * e = getenv("SDH_SPMM_NTH"); return e ? atoi(e) : 0; }();        // dev: A/B
     // measured, Mistral FFN layer (gate, up, down; us): T=8 75 -> 59, T=16 77 -> 61, but T=32 87 -> 98 and T=64 98 -> 171:
