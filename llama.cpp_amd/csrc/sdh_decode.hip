@@ -611,6 +611,152 @@ void decode_pair_kernel(const PairArgs a) {
     }
 }
 
+// ---- gate | up in one launch, 2..4 tokens ----------------------------------------------------------
+// The pair launch for small decode batches: 2 * B * n_tok base workgroups (gate blocks of every token, then up
+// blocks), and a residual wave computes row o of BOTH tensors for all tokens with the multi-token partial sums of
+// the single-tensor launches (delta_row_partial_nt, or — XLDS, COO with 16 * n_in bytes in LDS — x staged
+// token-interleaved once per workgroup and shared by the two tensors: delta_row_partial_coo_lds4). Per token the
+// arithmetic is the one-token kernel's, so h equals the node-by-node result bit for bit.
+template <bool BLOCK, int STEPS, int LOG_E, int LOG_T, int NT, bool XLDS>
+__global__ __launch_bounds__(1 << LOG_T, 4)             // <= 128 VGPRs: two 512-thread workgroups per CU
+void decode_pair_nt_kernel(const PairArgs a, const int n_tok, const int64_t ldh) {
+    using Ly = BaseLay<LOG_E, LOG_T>;
+    constexpr int L = Ly::L;
+    constexpr int E = Ly::E;
+    constexpr int WAVES = (1 << LOG_T) / 64;
+    constexpr int THREADS = 1 << LOG_T;
+    static_assert(!XLDS || (!BLOCK && NT == 4), "the LDS-staged form is the COO one, four token slots");
+    extern __shared__ __align__(16) float xlds[];       // max(L floats, XLDS: 4 * n_in floats) + 4
+
+    if (a.census) {
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(&a.census_ctr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            bool all = false;
+            while (__builtin_amdgcn_s_memrealtime() - t0 < 2 * SPIN_TICKS) {
+                if (__hip_atomic_load(&a.census_ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= gridDim.x) { all = true; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (!all) __hip_atomic_fetch_add(&a.census_ctr[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+
+    const DeltaParams & pg = a.p[0];
+    const int B = pg.B;
+    const int per = B * n_tok, nb_tot = 2 * per;
+    if ((int) blockIdx.x < nb_tot) {
+        const bool second = (int) blockIdx.x >= per;
+        const int rem = (int) blockIdx.x - (second ? per : 0);
+        const int t = rem / B, b = rem - t * B;
+        const int tid = threadIdx.x;
+        __builtin_amdgcn_s_setprio(SDH_BASE_PRIO);
+        float y[E];
+        const BasePackDesc & pd = second ? a.pd[1] : a.pd[0];
+        base_transform<Ly, false, true>(pg.x + (size_t) t * pg.ldx, pg.n_in, 0, pg.x_vec_ok != 0, pd, b, xlds, tid, y);
+        unsigned long long * out = (second ? a.vg[1] : a.vg[0]) + (size_t) (t * B + b) * L;
+        const unsigned long long tag = (unsigned long long) (second ? a.epoch[1] : a.epoch[0]) << 32;
+#pragma unroll
+        for (int r = 0; r < E; ++r)
+            __hip_atomic_store(out + Ly::idx(Ly::J - 1, tid, r),
+                               tag | (unsigned long long) __float_as_uint(y[r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+
+    const int ridx = residual_index((int) blockIdx.x, nb_tot, a.ncu);
+    if (ridx < 0) { shadow_linger(a.linger); return; }
+    int * done;
+    for (int i = 0; i < a.resid_delay; ++i) __builtin_amdgcn_s_sleep(8);
+    if constexpr (XLDS) {
+        float4 * const xs4 = reinterpret_cast<float4 *>(xlds);
+        done = reinterpret_cast<int *>(xlds + 4 * (size_t) pg.n_in);
+        const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int i4 = threadIdx.x; i4 < (pg.n_in >> 2); i4 += THREADS) {       // host: n_in % 4 == 0, columns 16-byte aligned
+            const float4 c0 = *reinterpret_cast<const float4 *>(pg.x + 4 * (size_t) i4);
+            const float4 c1 = n_tok > 1 ? *reinterpret_cast<const float4 *>(pg.x + (size_t) pg.ldx + 4 * (size_t) i4) : z;
+            const float4 c2 = n_tok > 2 ? *reinterpret_cast<const float4 *>(pg.x + 2 * (size_t) pg.ldx + 4 * (size_t) i4) : z;
+            const float4 c3 = n_tok > 3 ? *reinterpret_cast<const float4 *>(pg.x + 3 * (size_t) pg.ldx + 4 * (size_t) i4) : z;
+            xs4[4 * i4 + 0] = make_float4(c0.x, c1.x, c2.x, c3.x);
+            xs4[4 * i4 + 1] = make_float4(c0.y, c1.y, c2.y, c3.y);
+            xs4[4 * i4 + 2] = make_float4(c0.z, c1.z, c2.z, c3.z);
+            xs4[4 * i4 + 3] = make_float4(c0.w, c1.w, c2.w, c3.w);
+        }
+        if (threadIdx.x == 0) *done = 0;
+        __syncthreads();
+    } else {
+        done = reinterpret_cast<int *>(xlds);
+        if (a.reset) reset_begin(done);
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int G = pg.G;
+    const int l = lane & (G - 1);
+    const int o = (ridx * WAVES + wave) * (64 / G) + (lane / G);
+    const bool row_ok = o < pg.n_out;
+    const int orow = row_ok ? o : 0;
+    const bool leader = row_ok && l == 0;
+    float sg = 1.0f, su = 1.0f;
+    if (leader && a.p[0].rs) sg = a.p[0].rs[o];
+    if (leader && a.p[1].rs) su = a.p[1].rs[o];
+
+    float accg[NT], accu[NT];
+    if constexpr (XLDS) {
+        const float4 * xs4 = reinterpret_cast<const float4 *>(xlds);
+        delta_row_partial_coo_lds4<uint16_t, uint16_t, STEPS, true>(a.p[0], xs4, orow, row_ok, l, G, accg);
+        delta_row_partial_coo_lds4<uint16_t, uint16_t, STEPS, true>(a.p[1], xs4, orow, row_ok, l, G, accu);
+    } else {
+        int xoff[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) xoff[t] = (t < n_tok ? t : 0) * (int) pg.ldx;
+        delta_row_partial_nt<uint16_t, uint16_t, BLOCK, STEPS, NT, true>(a.p[0], pg.x, xoff, orow, row_ok, l, G, accg);
+        delta_row_partial_nt<uint16_t, uint16_t, BLOCK, STEPS, NT, true>(a.p[1], pg.x, xoff, orow, row_ok, l, G, accu);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { accg[t] = group_reduce(accg[t], G); accu[t] = group_reduce(accu[t], G); }
+
+    if (leader) {
+        // tall: the base term of (token t, row o) is granule t * B * L + o of its tensor
+        bool ok = false;
+        float vg[NT], vu[NT];
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        do {
+            unsigned long long g0[NT], g1[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int gi = (t < n_tok ? t : 0) * B * L + o;
+                g0[t] = granule_load(a.vg[0], gi);
+                g1[t] = granule_load(a.vg[1], gi);
+            }
+            ok = true;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                ok = ok & ((((unsigned) (g0[t] >> 32) == a.epoch[0]) & ((unsigned) (g1[t] >> 32) == a.epoch[1])) | (t >= n_tok));
+                vg[t] = __uint_as_float((unsigned) g0[t]);
+                vu[t] = __uint_as_float((unsigned) g1[t]);
+            }
+            if (ok) break;
+            __builtin_amdgcn_s_sleep(SDH_POLL_SLEEP);
+        } while (__builtin_amdgcn_s_memrealtime() - t0 < SPIN_TICKS);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t < n_tok) {
+                float yg = vg[t] + accg[t], yu = vu[t] + accu[t];
+                if (!ok) yg = yu = __uint_as_float(0x7FC00000u);
+                yg = finish_output(a.p[0], yg, sg);
+                yu = finish_output(a.p[1], yu, su);
+                a.h[(size_t) t * (size_t) ldh + o] = glu_value(a.act, yg, yu, a.gelu_tab);
+            }
+        }
+    }
+    if (a.reset && reset_last_wave(done, lane, WAVES)) {
+        const int rows = WAVES * (64 / G), row0 = ridx * rows, n = min(rows, pg.n_out - row0);
+        for (int t = 0; t < n_tok; ++t) {
+            reset_granules(a.vg[0] + (size_t) t * B * L, row0, n, 1, L, lane);
+            reset_granules(a.vg[1] + (size_t) t * B * L, row0, n, 1, L, lane);
+        }
+    }
+}
+
 // ---- host side ----------------------------------------------------------------------------------
 // workgroup shape per base block length: L = 2^(LOG_E + LOG_T)
 #if defined(SDH_DECODE_L4096_T256)    // build variants (A/B): 256 threads x 16 elements was the first version
@@ -996,8 +1142,71 @@ static int launch_pair_steps(int steps, PairArgs & a, unsigned grid, hipStream_t
     }
 }
 
+template <bool BLOCK, int STEPS, int LOG_E, int LOG_T, int NT, bool XLDS>
+static int launch_pair_nt_inst(PairArgs & a, int n_tok, int64_t ldh, unsigned grid, size_t lds, hipStream_t s) {
+    static FusedKernelInfo ki;
+    static size_t occ_lds = 0;
+    LibState & ls = lib();
+    const auto kern = decode_pair_nt_kernel<BLOCK, STEPS, LOG_E, LOG_T, NT, XLDS>;
+    static const bool attr_ok = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    if (!attr_ok) return 1;
+    if (ki.occ < 0 || lds > occ_lds) {                  // residency depends on the LDS request: keep the largest seen
+        int occ = 0;
+        SDH_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 1 << LOG_T, lds));
+        ki.occ = occ; occ_lds = lds; ki.census_ok_grid = 0;
+    }
+    static const bool dbg = getenv("SDH_DEBUG") != nullptr;
+    if (ki.census_failed || (long long) grid > (long long) ki.occ * ls.num_cu) {
+        if (dbg) fprintf(stderr, "[sdh] %d-token gate|up launch declined: grid=%u occ=%d cus=%d lds=%zu census_failed=%d\n", n_tok, grid, ki.occ, ls.num_cu, lds, (int) ki.census_failed);
+        return 1;
+    }
+    if (grid > ki.census_ok_grid && a.epoch[0] == CAPTURE_TAG) return 1;       // capture before the first eager launch
+    if (grid > ki.census_ok_grid) {
+        if (!ls.census_ctr) SDH_HIP_CHECK(hipMalloc((void **) &ls.census_ctr, 16));
+        SDH_HIP_CHECK(hipMemsetAsync(ls.census_ctr, 0, 16, s));
+        PairArgs ca = a;
+        ca.census = 1;
+        ca.census_ctr = ls.census_ctr;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(1 << LOG_T), occ_lds, s, ca, n_tok, ldh);
+        SDH_HIP_CHECK(hipGetLastError());
+        unsigned h[2] = {0, 0};
+        SDH_HIP_CHECK(hipMemcpyAsync(h, ls.census_ctr, sizeof(h), hipMemcpyDeviceToHost, s));
+        SDH_HIP_CHECK(hipStreamSynchronize(s));
+        if (dbg) fprintf(stderr, "[sdh] %d-token gate|up census: grid=%u arrived=%u failures=%u\n", n_tok, grid, h[0], h[1]);
+        if (h[0] != grid || h[1] != 0) { ki.census_failed = true; return 1; }
+        ki.census_ok_grid = grid;
+    }
+    a.census = 0;
+    a.census_ctr = nullptr;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(1 << LOG_T), lds, s, a, n_tok, ldh);
+    SDH_HIP_CHECK(hipGetLastError());
+    return SDH_OK;
+}
+
+template <bool BLOCK, int LOG_E, int LOG_T>
+static int launch_pair_nt_steps(int steps, PairArgs & a, int n_tok, int64_t ldh, unsigned grid, size_t xlds_bytes, hipStream_t s) {
+    constexpr size_t base_lds = ((size_t) 1 << (LOG_E + LOG_T)) * 4 + 16;
+    if constexpr (!BLOCK) {
+        if (xlds_bytes) {
+            int rc = 1;                                // rows of two steps with four token slots spill (128 VGPRs)
+            if (steps == 1) rc = launch_pair_nt_inst<false, 1, LOG_E, LOG_T, 4, true>(a, n_tok, ldh, grid, std::max(base_lds, xlds_bytes), s);
+            if (rc != 1) return rc;
+        }
+    }
+    if (n_tok <= 2) {
+        switch (steps) {
+            case 1: return launch_pair_nt_inst<BLOCK, 1, LOG_E, LOG_T, 2, false>(a, n_tok, ldh, grid, base_lds, s);
+            case 2: return launch_pair_nt_inst<BLOCK, 2, LOG_E, LOG_T, 2, false>(a, n_tok, ldh, grid, base_lds, s);
+            default: return 1;
+        }
+    }
+    if (steps == 1) return launch_pair_nt_inst<BLOCK, 1, LOG_E, LOG_T, 4, false>(a, n_tok, ldh, grid, base_lds, s);
+    return 1;
+}
+
 int launch_decode_pair(DeviceWeight & g, DeviceWeight & u, int act, const uint16_t * gelu_tab,
-                       const float * x, float * h, int * nf_g, int * nf_u, bool zero_nonfinite, hipStream_t s) {
+                       const float * x, int64_t ldx, int n_tok, float * h, int64_t ldh,
+                       int * nf_g, int * nf_u, bool zero_nonfinite, hipStream_t s) {
     static const bool dbg = getenv("SDH_DEBUG") != nullptr;
 #define SDH_DECLINE(why) do { if (dbg) fprintf(stderr, "[sdh] gate|up launch declined: %s\n", why); return 1; } while (0)
     if (g.kind != u.kind || (g.kind != SDH_OP_BASE_BLOCK && g.kind != SDH_OP_BASE_COO)) SDH_DECLINE("not two base payloads of one kind");
@@ -1013,7 +1222,9 @@ int launch_decode_pair(DeviceWeight & g, DeviceWeight & u, int act, const uint16
 
     const bool is_block = (g.kind == SDH_OP_BASE_BLOCK);
     DeltaLaunch dl{};
-    dl.x = x; dl.ldx = g.n_in; dl.T = 1; dl.y = h; dl.ldy = g.n_out; dl.v = nullptr;
+    if (n_tok < 1 || n_tok > MAX_FUSED_TOKENS) SDH_DECLINE("token count");
+    if (n_tok > 1 && (ldx > INT32_MAX / 4 || !((((uintptr_t) x) % 16) == 0 && (ldx % 4) == 0))) SDH_DECLINE("token columns are not 16-byte aligned");
+    dl.x = x; dl.ldx = n_tok > 1 ? ldx : g.n_in; dl.T = n_tok; dl.y = h; dl.ldy = g.n_out; dl.v = nullptr;
     dl.zero_nonfinite = zero_nonfinite; dl.exact_order = false;
     PairArgs a{};
     dl.nf_counter = nf_g; a.p[0] = make_delta_params(g, dl);
@@ -1026,7 +1237,7 @@ int launch_decode_pair(DeviceWeight & g, DeviceWeight & u, int act, const uint16
     a.pd[0] = g.pack; a.pd[1] = u.pack;
     const int rows_per_block = ((1 << decode_log_t((int) g.L)) / 64) * (64 / G0);
     const int ncu = shadow_ncu();
-    const unsigned grid = shadow_grid(2 * (int) g.B, (a.p[0].n_out + rows_per_block - 1) / rows_per_block, ncu);
+    const unsigned grid = shadow_grid(2 * (int) g.B * n_tok, (a.p[0].n_out + rows_per_block - 1) / rows_per_block, ncu);
     a.vg[0] = reinterpret_cast<unsigned long long *>(g.handoff);
     a.vg[1] = reinterpret_cast<unsigned long long *>(u.handoff);
     a.epoch[0] = capturing ? CAPTURE_TAG : next_epoch(g.epoch);
@@ -1041,6 +1252,20 @@ int launch_decode_pair(DeviceWeight & g, DeviceWeight & u, int act, const uint16
     a.resid_delay = pair_delay < 0 ? 0 : (pair_delay > 64 ? 64 : pair_delay);
     a.ncu = ncu;
     a.linger = shadow_linger_ticks();
+    if (n_tok > 1) {
+        static const bool off = [] { const char * e = getenv("SDH_DECODE_PAIR_NT"); return e && atoi(e) == 0; }();       // dev: A/B
+        if (off) return 1;
+        static const bool xlds_off = [] { const char * e = getenv("SDH_DECODE_XLDS"); return e && atoi(e) == 0; }();
+        size_t xlds_bytes = (size_t) a.p[0].n_in * 16 + 16;
+        if (xlds_off || is_block || (a.p[0].n_in % 4) != 0 || xlds_bytes > 72 * 1024) xlds_bytes = 0;
+        switch (g.L) {
+            case 1024: return is_block ? launch_pair_nt_steps<true, 2, 8>(st0, a, n_tok, ldh, grid, 0, s) : launch_pair_nt_steps<false, 2, 8>(st0, a, n_tok, ldh, grid, xlds_bytes, s);
+            case 2048: return is_block ? launch_pair_nt_steps<true, SDH_L2048_LOG_E, SDH_L2048_LOG_T>(st0, a, n_tok, ldh, grid, 0, s)
+                                       : launch_pair_nt_steps<false, SDH_L2048_LOG_E, SDH_L2048_LOG_T>(st0, a, n_tok, ldh, grid, xlds_bytes, s);
+            default:   return is_block ? launch_pair_nt_steps<true, SDH_L4096_LOG_E, SDH_L4096_LOG_T>(st0, a, n_tok, ldh, grid, 0, s)
+                                       : launch_pair_nt_steps<false, SDH_L4096_LOG_E, SDH_L4096_LOG_T>(st0, a, n_tok, ldh, grid, xlds_bytes, s);
+        }
+    }
     switch (g.L) {
         case 1024: return is_block ? launch_pair_steps<true, 2, 8>(st0, a, grid, s) : launch_pair_steps<false, 2, 8>(st0, a, grid, s);
         case 2048: return is_block ? launch_pair_steps<true, SDH_L2048_LOG_E, SDH_L2048_LOG_T>(st0, a, grid, s)

@@ -75,6 +75,7 @@ struct DeviceWeight {
     // non-finite accounting: ring of per-call counters (no per-call memset on the hot path)
     static constexpr int NF_SLOTS = 256;
     int *    nf_ring = nullptr;  // device, NF_SLOTS ints
+    bool     nf_continue = false; // this launch continues the previous one's call (FFN token chunks): same counter slot
     uint64_t seq = 0;            // forwards issued
     hipStream_t last_stream = nullptr;
     // workspace for the base term v[T_chunk][B][L]
@@ -150,10 +151,11 @@ int launch_delta_spmm(const DeviceWeight & w, const DeltaLaunch & a, hipStream_t
 // Batch-1 decode with a base as ONE launch (sdh_decode.hip). Returns SDH_OK if launched, 1 if the
 // payload / call does not qualify (caller runs base + delta kernels instead), <0 on error.
 int launch_decode_fused(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s);
-// T = 1, gate and up tall base payloads of one shape: h[o] = act(gate(x)[o]) * up(x)[o] in one launch.
-// Returns SDH_OK, 1 if the pair does not qualify, <0 on error. nf_g / nf_u: the two nodes' counters.
+// 1..MAX_FUSED_TOKENS tokens, gate and up tall base payloads of one shape: h[t][o] = act(gate(x_t)[o]) * up(x_t)[o] in
+// one launch. Returns SDH_OK, 1 if the pair does not qualify, <0 on error. nf_g / nf_u: the two nodes' counters.
 int launch_decode_pair(DeviceWeight & g, DeviceWeight & u, int act, const uint16_t * gelu_tab,
-                       const float * x, float * h, int * nf_g, int * nf_u, bool zero_nonfinite, hipStream_t s);
+                       const float * x, int64_t ldx, int n_tok, float * h, int64_t ldh,
+                       int * nf_g, int * nf_u, bool zero_nonfinite, hipStream_t s);
 int launch_glu(int act, const uint16_t * gelu_tab, const float * g, const float * u, float * y, int64_t n, hipStream_t s);
 
 // Persistent FFN stack (sdh_stack.hip): n_layers gated FFN blocks at T = 1 in one launch.

@@ -315,6 +315,13 @@ def ffn_gate_up_host(gate: SeedDeltaWeight, up: SeedDeltaWeight, x: np.ndarray, 
     return h
 
 
+def ffn_gate_up_device(gate: SeedDeltaWeight, up: SeedDeltaWeight, act: int, x_ptr: int, ldx: int, T: int,
+                       h_ptr: int, ldh: int, flags: int = 0, stream: int = 0):
+    rc = load_library().sdh_ffn_gate_up(gate._h, up._h, act, x_ptr, ldx, T, h_ptr, ldh,
+                                        flags & ~FWD_HOST_IO, C.c_void_p(stream) if stream else None)
+    _check(rc, "sdh_ffn_gate_up")
+
+
 def ffn_forward_device(gate: SeedDeltaWeight, up: SeedDeltaWeight, down: SeedDeltaWeight, act: int,
                        x_ptr: int, ldx: int, T: int, y_ptr: int, ldy: int, flags: int = 0, stream: int = 0):
     rc = load_library().sdh_ffn_forward(gate._h, up._h, down._h, act, x_ptr, ldx, T, y_ptr, ldy,

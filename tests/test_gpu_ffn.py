@@ -85,8 +85,8 @@ def test_ffn_fast_path_vs_reference_graph(hip, name):
     wg, wu, wd = hip.SeedDeltaWeight(gate), hip.SeedDeltaWeight(up), hip.SeedDeltaWeight(down)
     smooth, full, h_or = h_bounds(gate, up, x, act)
     h = hip.ffn_gate_up_host(wg, wu, x, act)
-    # T = 1 with tall base gate/up of one shape and L >= 1024: the single gate|up launch must be taken
-    expect_fused = x.shape[0] == 1 and gate.base_d1 is not None and gate.base_d1.shape[1] >= 1024
+    # 1..4 tokens with tall base gate/up of one shape and L >= 1024: the single gate|up launch must be taken
+    expect_fused = x.shape[0] <= 4 and gate.base_d1 is not None and gate.base_d1.shape[1] >= 1024
     assert hip.ffn_last_fused() == expect_fused
     check_h(h, smooth, full, h_ref.astype(np.float64))
     y = hip.ffn_forward_host(wg, wu, wd, x, act)
@@ -116,6 +116,86 @@ def test_gate_up_single_launch_matches_node_by_node(hip, act, scheme, K, block, 
     # the plain ops on the same handles still work after the pair launches (shared granule buffers)
     yg = wg.forward_host(x)
     assert np.all(np.abs(yg - O.forward(gate, x)) <= fast_tolerance(gate, x, None))
+
+
+@pytest.mark.parametrize("act", [O.ACT_SILU, O.ACT_GELU])
+@pytest.mark.parametrize("scheme,K,block", [("coo", 32, 16), ("coo", 128, 16), ("block", 64, 16), ("block", 128, 32), ("block", 1024, 32)])
+@pytest.mark.parametrize("dims", [(1024, 2816), (2048, 5632), (4096, 9000), (4096, 14336)])
+def test_gate_up_small_batch_single_launch_is_bit_identical_to_node_by_node(hip, act, scheme, K, block, dims):
+    """2..4 tokens: the gate|up launch (base blocks of both tensors for every token, rows of both tensors per wave,
+    COO with x staged in LDS when it fits) gives every token the bits of its own one-token gate|up launch and of the
+    node-by-node device path; padded token columns included."""
+    torch = pytest.importorskip("torch")
+    n_embd, n_ff = dims
+    if K * 1 > 512 and n_embd < 2048:
+        pytest.skip("rows longer than the input")
+    kw = dict(scheme=scheme, K=K, block=block, base=True, d13_random=True)
+    gate, up = make_payload(n_embd, n_ff, seed=31, **kw), make_payload(n_embd, n_ff, seed=32, **kw)
+    wg, wu = hip.SeedDeltaWeight(gate), hip.SeedDeltaWeight(up)
+    xs = (2.0 * make_x(n_embd, 4, seed=19)).astype(np.float32)
+    single = []
+    for t in range(4):
+        single.append(hip.ffn_gate_up_host(wg, wu, xs[t:t + 1], act))
+    fused1 = hip.ffn_last_fused()                            # long rows x many rows exceed the co-residency limit: node by node
+    assert fused1 or K > 512
+    single = np.concatenate(single, axis=0)
+    two_steps = K > 512                                      # rows of two steps: four token slots would spill, 3-4 tokens go node by node
+    for T in (2, 3, 4):
+        for rep in range(2):
+            h = hip.ffn_gate_up_host(wg, wu, xs[:T], act)
+            assert hip.ffn_last_fused() == (fused1 and not (two_steps and T > 2)), (T, rep)
+            assert np.array_equal(bits(h), bits(single[:T])), (T, rep)
+        hn = hip.ffn_gate_up_host(wg, wu, xs[:T], act, hip.FWD_NO_FUSE)
+        assert not hip.ffn_last_fused()
+        assert np.array_equal(bits(hn), bits(single[:T]))
+    smooth, full, h_ref = h_bounds(gate, up, xs, act)
+    check_h(hip.ffn_gate_up_host(wg, wu, xs, act), smooth, full, h_ref)
+    # device buffers with padded columns
+    ldx = n_embd + 8
+    xd = torch.zeros((3, ldx), dtype=torch.float32, device="cuda")
+    xd[:, :n_embd] = torch.from_numpy(xs[1:4]).cuda()
+    hd = torch.zeros((3, n_ff), dtype=torch.float32, device="cuda")
+    st = torch.cuda.Stream()
+    hip.ffn_gate_up_device(wg, wu, act, xd.data_ptr(), ldx, 3, hd.data_ptr(), n_ff, 0, st.cuda_stream)
+    st.synchronize()
+    assert hip.ffn_last_fused() == (fused1 and not two_steps)
+    assert np.array_equal(bits(hd.cpu().numpy()), bits(single[1:4]))
+    assert wg.nonfinite_count() == 0 and wu.nonfinite_count() == 0
+
+
+@pytest.mark.parametrize("scheme,K,block", [("coo", 128, 16), ("block", 128, 16)])
+def test_ffn_five_to_eight_tokens_run_as_groups_of_four(hip, scheme, K, block):
+    """sdh_ffn_forward with 5..8 tokens goes through the single-launch forms in groups of up to four tokens: every
+    token's output is its one-token output bit for bit, and the non-finite counters cover the whole call."""
+    n_embd, n_ff = 2048, 5632
+    kw = dict(scheme=scheme, K=K, block=block, base=True, d13_random=True)
+    gate, up = make_payload(n_embd, n_ff, seed=41, **kw), make_payload(n_embd, n_ff, seed=42, **kw)
+    down = make_payload(n_ff, n_embd, seed=43, **kw)
+    wg, wu, wd = hip.SeedDeltaWeight(gate), hip.SeedDeltaWeight(up), hip.SeedDeltaWeight(down)
+    xs = make_x(n_embd, 8, seed=23)
+    single = np.concatenate([hip.ffn_forward_host(wg, wu, wd, xs[t:t + 1], O.ACT_SILU) for t in range(8)], axis=0)
+    for T in (5, 6, 7, 8):
+        y = hip.ffn_forward_host(wg, wu, wd, xs[:T], O.ACT_SILU)
+        assert hip.ffn_last_fused()
+        assert np.array_equal(bits(y), bits(single[:T])), T
+        assert wg.nonfinite_count() == 0 and wu.nonfinite_count() == 0 and wd.nonfinite_count() == 0
+    y9 = hip.ffn_forward_host(wg, wu, wd, np.concatenate([xs, xs[:1]]), O.ACT_SILU)       # 9 tokens: the tiled path
+    assert not hip.ffn_last_fused()
+    smooth, full, h_ref = h_bounds(gate, up, xs, O.ACT_SILU)
+    y_ref = O.forward(down, O.glu(O.ACT_SILU, O.forward(gate, xs), O.forward(up, xs)))
+    check_y(y9[:8], y_ref.astype(np.float64), down, h_ref.astype(np.float32), full)
+    # a non-finite gate output in every token: the gate node's counter reports the whole call, not the last group
+    bad = make_payload(n_embd, n_ff, seed=41, **kw)
+    if scheme == "coo":
+        bad.d_val[7, 0] = np.float16(np.inf); bad.d_idx[7, 0] = 3
+    else:
+        bad.b_val[7, 0, 3] = np.float16(np.inf); bad.b_idx[7, 0] = 0
+    wb = hip.SeedDeltaWeight(bad)
+    xb = xs[:7].copy()
+    xb[:, 3] = 1.0                                          # inf * x is non-finite for every token: 4 in the first group, 3 in the second
+    y = hip.ffn_forward_host(wb, wu, wd, xb, O.ACT_SILU, hip.FWD_ZERO_NONFINITE)
+    assert wb.nonfinite_count() == 7 and wu.nonfinite_count() == 0
+    assert np.all(np.isfinite(y))
 
 
 def test_gate_up_declines_gracefully(hip):
