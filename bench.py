@@ -309,6 +309,20 @@ def run_ffn(args, dev):
     fused = seeddelta.ffn_last_fused()
     ev_n, host_n = timed_on_stream(nodes, reps, st, seeddelta)
     us_block, us_nodes = ev_b * 1e3 / (reps * NL), ev_n * 1e3 / (reps * NL)
+    # small decode batches (speculative / batched decode) and the start of the tiled path, same layers
+    by_tokens = {}
+    for T in (2, 4, 8, 16):
+        xT = torch.randn((T, n_embd), dtype=torch.float32, device=dev)
+        yT = torch.empty((T, n_embd), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+
+        def block_t():
+            for wg, wu, wd in layers:
+                seeddelta.ffn_forward_device(wg, wu, wd, seeddelta.ACT_SILU, xT.data_ptr(), n_embd, T, yT.data_ptr(), n_embd, 0, sp)
+
+        ev_t, _ = timed_on_stream(block_t, max(4, reps // 8), st, seeddelta)
+        by_tokens[str(T)] = ev_t * 1e3 / (max(4, reps // 8) * NL)
+        del xT, yT
     for ws in layers:
         for w in ws:
             w.close()
@@ -317,7 +331,7 @@ def run_ffn(args, dev):
            "us_per_layer_host_clock": host_b * 1e3 / (reps * NL),
            "us_per_layer_node_by_node": us_nodes, "us_per_layer_node_by_node_host_clock": host_n * 1e3 / (reps * NL),
            "speedup_vs_node_by_node": us_nodes / us_block,
-           "gate_up_single_launch": bool(fused), "distinct_layers": NL,
+           "gate_up_single_launch": bool(fused), "distinct_layers": NL, "us_per_layer_by_tokens": by_tokens,
            "algorithmic_bytes_per_layer": alg,
            "timing": "HIP events recorded by the library on the explicit launch stream; host clock (synchronised) beside it",
            "roofline": {"bound": "hbm", "achieved": alg / us_block / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -638,7 +638,9 @@ static int sdh_forward_impl(sdh_weight * h, const float * x, int64_t ldx, int64_
         rc = 1;
         // the choice follows the CALL's token count, not the chunk's: a short last chunk must not switch a call to
         // the per-token kernels (same values within tolerance, but not the same bits as its other chunks)
-        if (n_tokens >= spmm_min_t && !a.exact_order && !(flags & SDH_FWD_NO_SPMM)) rc = launch_delta_spmm(*w, a, s);
+        static const int64_t rows_max_t = [] { const char * e = getenv("SDH_FFN_ROWS_MAX_T"); return e ? (int64_t) atoll(e) : (int64_t) 32; }();
+        const bool prefer_rows = (flags & SDH_FWD_INTERNAL_ROWS) && n_tokens <= rows_max_t;
+        if (n_tokens >= spmm_min_t && !a.exact_order && !(flags & SDH_FWD_NO_SPMM) && !prefer_rows) rc = launch_delta_spmm(*w, a, s);
         if (rc == 1) rc = launch_delta(*w, a, s);
         if (rc != SDH_OK) return rc;
         rc = prof_end(pair);
@@ -806,15 +808,17 @@ static int sdh_ffn_forward_impl(sdh_weight * hg, sdh_weight * hu, sdh_weight * h
         if ((rc = host_to_device(ls, ws[0], x, ldx, n_embd, n_tokens, s)) != SDH_OK) return rc;
         dx = ws[0]; dldx = n_embd; dy = ws[1]; dldy = d->n_out;
     }
-    const int sub = flags & ~SDH_FWD_HOST_IO;
-    // 5..8 tokens: groups of up to four through the single-launch forms (a gate|up launch and a fused down launch per
-    // group) instead of six node launches over token tiles. Mistral layer, us, COO / block16: 4 tokens 24.5 / 18.7, so
-    // 8 tokens 49 / 37 against 56 / 58 through the tiled path. Per token the result is its one-token result.
+    const int sub = (flags & ~SDH_FWD_HOST_IO) | (n_tokens > MAX_FUSED_TOKENS ? SDH_FWD_INTERNAL_ROWS : 0);
+    // 5..8 tokens, block payloads: groups of up to four through the single-launch forms (a gate|up launch and a fused
+    // down launch per group) instead of six node launches over token tiles. Mistral layer, block16, us: 4 tokens 18.7,
+    // 8 tokens 37.6 against 57.9 through the tiled path. COO payloads take the LDS rows kernel node by node instead
+    // (SDH_FWD_INTERNAL_ROWS: 41 us at 5..8 tokens against 49 in groups and 56 tiled; 51 at 16, 68 at 32 against 59 and
+    // 77 tiled; the tiled path wins again from ~48 tokens). Either way a token's result is its one-token result.
     static const int64_t ffn_group_max = [] { const char * e = getenv("SDH_FFN_GROUP_MAX"); return e ? (int64_t) atoll(e) : (int64_t) 8; }();
     DeviceWeight * u = reinterpret_cast<DeviceWeight *>(hu);
     const bool groups = n_tokens > MAX_FUSED_TOKENS && n_tokens <= ffn_group_max &&
                         !(sub & (SDH_FWD_NO_FUSE | SDH_FWD_EXACT_ORDER | SDH_FWD_NO_SPMM | SDH_FWD_W0_MFMA)) &&
-                        g != u && g != d && u != d;
+                        g != u && g != d && u != d && g->kind == SDH_OP_BASE_BLOCK;
     const int64_t step = groups ? MAX_FUSED_TOKENS : n_tokens;
     rc = SDH_OK;
     for (int64_t t0 = 0; t0 < n_tokens && rc == SDH_OK; t0 += step) {

@@ -92,15 +92,18 @@ void delta_rows_kernel(const DeltaParams p) {
 // only the data movement of the reduction differs: the m = 32 (and, for four tokens, m = 16) exchange swaps half
 // registers between the tokens' sums, which leaves token t's sum in a lane segment of its own, and the steps inside
 // a 16-lane row are DPP moves.
-template <typename IDX_T, typename VAL_T, int STEPS, int NT>
+template <typename IDX_T, typename VAL_T, int STEPS, int NT, int GC /* 64: rows of 64 lanes, else 0: p.G */>
 __global__ __launch_bounds__(1024)
 void delta_rows_block_lds_kernel(const DeltaParams p, const int64_t T, const int rows_per_wg) {
     extern __shared__ float4 xs4[];                     // [NT][2][n_in / 8]
-    static_assert(NT == 2 || NT == 4, "two or four tokens");
+    static_assert(NT == 2 || NT == 4 || NT == 8, "tokens per tile");
     constexpr int NS = STEPS;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    const int G = GC > 0 ? GC : p.G;                    // host: G >= 8, G >= NT
+    const int l = lane & (G - 1);
+    const int rows_wave = 64 / G;
     const int nch = p.n_in >> 3;
     const int64_t t0 = (int64_t) blockIdx.x * NT;
     const int nt = (int) ((T - t0 < NT) ? (T - t0) : NT);
@@ -120,7 +123,7 @@ void delta_rows_block_lds_kernel(const DeltaParams p, const int64_t T, const int
     bool eok[NS];
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
-        const int e = (u * 64 + lane) * 8;
+        const int e = (u * G + l) * 8;
         eok[u] = e < p.Ktot;
         e0[u] = eok[u] ? e : 0;
         bi[u] = e0[u] >> p.block_shift;
@@ -128,10 +131,9 @@ void delta_rows_block_lds_kernel(const DeltaParams p, const int64_t T, const int
     }
     const VAL_T * val = reinterpret_cast<const VAL_T *>(p.val);
     const IDX_T * idx = reinterpret_cast<const IDX_T *>(p.idx);
-    // the token whose sum the reduction leaves in this lane's segment: halves hold tokens 0, 1; rows hold 0, 2, 1, 3
-    const int seg = NT == 2 ? (lane >> 5) : (lane >> 4);
-    const int my_t = NT == 2 ? seg : (((seg & 1) << 1) | (seg >> 1));
-    const bool lead = (lane & (64 / NT - 1)) == 0 && my_t < nt;
+    // the token whose sum the transposing reduction leaves in this lane (transpose_reduce): its epilogue runs here
+    const int my_t = reduce_token_of_lane<NT>(G, l);
+    const bool lead = reduce_is_leader<NT>(G, l) && my_t < nt;
     constexpr int NB = 4;
     const int nbase = p.v ? (p.tall ? 1 : p.B) : 0;
     const float * vt = p.v + (size_t) (t0 + (my_t < nt ? my_t : 0)) * (size_t) p.v_ld;
@@ -150,9 +152,12 @@ void delta_rows_block_lds_kernel(const DeltaParams p, const int64_t T, const int
             for (int b = 0; b < NB; ++b) vb_n[b] = (b < nbase) ? vt[(size_t) b * p.L + orow] : 0.0f;
         }
     };
-    int o = r0 + wave;                                   // one row per wave and pass, uniform over the wave
+    const int stride = 16 * rows_wave;                  // rows per pass of the workgroup
+    int o = r0 + wave * rows_wave + lane / G;
     request(o);
-    for (; o < r1; o += 16) {
+    const int passes = (r1 - r0 + stride - 1) / stride;  // uniform over the workgroup
+    for (int it = 0; it < passes; ++it, o += stride) {
+        const bool row_ok = o < r1;
         int c0[NS];
         bool ok[NS];
         Vec8<VAL_T> vv[NS];
@@ -162,13 +167,13 @@ void delta_rows_block_lds_kernel(const DeltaParams p, const int64_t T, const int
         for (int u = 0; u < NS; ++u) {
             const int blk = idx_to_i32<IDX_T>(blk_n[u]);
             const int raw = (blk << p.block_shift) + off[u];
-            ok[u] = eok[u] & ((unsigned) blk < (unsigned) p.n_blk_in) & (raw < p.n_in);
+            ok[u] = row_ok & eok[u] & ((unsigned) blk < (unsigned) p.n_blk_in) & (raw < p.n_in);
             c0[u] = (ok[u] ? raw : 0) >> 3;
             vv[u] = vv_n[u];
         }
 #pragma unroll
         for (int b = 0; b < NB; ++b) vb[b] = vb_n[b];
-        request(o + 16);
+        request(o + stride);
         float acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -181,19 +186,128 @@ void delta_rows_block_lds_kernel(const DeltaParams p, const int64_t T, const int
             acc[t] = 0.0f;
 #pragma unroll
             for (int u = 0; u < NS; ++u) acc[t] = add_if(acc[t], ok[u], dot8<VAL_T>(vv[u], xa[u], xb[u]));
-            if (NT > 2 && (t & 1) && t + 1 < NT) __builtin_amdgcn_sched_barrier(0);    // two tokens' reads in flight, not four
+            if (NT > 2 && (t & 1) && t + 1 < NT) __builtin_amdgcn_sched_barrier(0);    // two tokens' reads in flight
         }
-        float a;
-        if constexpr (NT == 2) {
-            a = swap32_add(acc[0], acc[1]);              // m = 32: token 0 in lanes 0-31, token 1 in lanes 32-63
-            a = swap16_add(a, a);                        // m = 16
-        } else {
-            const float a01 = swap32_add(acc[0], acc[1]);
-            const float a23 = swap32_add(acc[2], acc[3]);
-            a = swap16_add(a01, a23);                    // rows: tokens 0, 2, 1, 3
+        const float a = transpose_reduce<NT, GC>(acc, G, lane);
+        if (row_ok && lead) {
+            float yh = 0.0f;
+            if (p.v) {
+                if (p.tall) yh = vb[0];
+                else {
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) if (b < nbase) yh += vb[b];
+                    for (int b = NB; b < nbase; ++b) yh += vt[(size_t) b * p.L + o];
+                }
+            }
+            store_output(p, o, t0 + my_t, yh + a, scale);
         }
-        a = row16_reduce_to_lane0(a);                    // m = 8, 4, 2, 1
+    }
+}
+
+// COO rows for several tokens with x in LDS (the fast-path arithmetic, not the tiled SpMM's exact order): the gated
+// FFN's node launches from 5 tokens up. The SpMM form gives a lane a whole row: with few tokens that is one token tile,
+// a few hundred waves, each walking 128 entries behind one 32-byte payload request at a time — far too little memory
+// parallelism to stream the payload (Mistral gate, 8 tokens: 15 us for 5.5 MB). Here a row has G lanes as in the
+// one-token kernel (coalesced 16-byte index / value loads, the whole row requested at once and the next pass's rows
+// a pass ahead), x of NT tokens sits token-interleaved in the de-interleaved tile rows of sdh_spmm.hip (one 16-byte
+// LDS read per entry and four tokens), and the NT sums of a row are reduced by the transposing butterfly
+// (transpose_reduce): token t's total lands in its own lane, so the NT epilogues of a row run side by side.
+// Per token: the products, the order of the adds and the pairing of the lane sums are delta_rows_kernel's.
+template <typename IDX_T, typename VAL_T, int STEPS, int NT>
+__global__ __launch_bounds__(1024)
+void delta_rows_coo_lds_kernel(const DeltaParams p, const int64_t T, const int rows_per_wg) {
+    extern __shared__ float xs[];                       // [4 * n4][NT]
+    static_assert(NT == 2 || NT == 4 || NT == 8, "tokens per tile");
+    constexpr int NS = STEPS;
+    constexpr int GRP = NT >= 4 ? 4 : 2;                // tokens per LDS read
+    typedef float gvec __attribute__((ext_vector_type(GRP)));
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int G = p.G;                                  // host: G >= 8, G >= NT
+    const int l = lane & (G - 1);
+    const int rows_wave = 64 / G;
+    const int n4 = (p.n_in + 3) >> 2;
+    const int64_t t0 = (int64_t) blockIdx.x * NT;
+    const int nt = (int) ((T - t0 < NT) ? (T - t0) : NT);
+    spmm_fill_tile<false, NT, GRP, 1024>(p, xs, t0, nt, n4, tid);
+    __syncthreads();
+
+    const int r0 = (int) blockIdx.y * rows_per_wg;
+    const int r1 = min(p.n_out, r0 + rows_per_wg);
+    int e0[NS];
+    bool eok[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        const int e = (u * G + l) * 8;
+        eok[u] = e < p.Ktot;
+        e0[u] = eok[u] ? e : 0;
+    }
+    const VAL_T * val = reinterpret_cast<const VAL_T *>(p.val);
+    const IDX_T * idx = reinterpret_cast<const IDX_T *>(p.idx);
+    const int my_t = reduce_token_of_lane<NT>(G, l);
+    const bool lead = reduce_is_leader<NT>(G, l) && my_t < nt;
+    constexpr int NB = 4;
+    const int nbase = p.v ? (p.tall ? 1 : p.B) : 0;
+    const float * vt = p.v + (size_t) (t0 + (my_t < nt ? my_t : 0)) * (size_t) p.v_ld;
+    Vec8<IDX_T> ii_n[NS];
+    Vec8<VAL_T> vv_n[NS];
+    float vb_n[NB], scale_n = 1.0f;
+    auto request = [&](int on) {
+        const int orow = on < r1 ? on : r0;
+#pragma unroll
+        for (int u = 0; u < NS; ++u) ii_n[u].load(idx + (size_t) orow * p.Ktot + e0[u]);
+#pragma unroll
+        for (int u = 0; u < NS; ++u) vv_n[u].load(val + (size_t) orow * p.Ktot + e0[u]);
         if (lead) {
+            if (p.rs) scale_n = p.rs[orow];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) vb_n[b] = (b < nbase) ? vt[(size_t) b * p.L + orow] : 0.0f;
+        }
+    };
+    const int stride = 16 * rows_wave;                  // rows per pass of the workgroup
+    int o = r0 + wave * rows_wave + lane / G;
+    request(o);
+    const int passes = (r1 - r0 + stride - 1) / stride;  // uniform over the workgroup
+    for (int it = 0; it < passes; ++it, o += stride) {
+        const bool row_ok = o < r1;
+        Vec8<IDX_T> ii[NS];
+        Vec8<VAL_T> vv[NS];
+        float vb[NB];
+        const float scale = scale_n;
+#pragma unroll
+        for (int u = 0; u < NS; ++u) { ii[u] = ii_n[u]; vv[u] = vv_n[u]; }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) vb[b] = vb_n[b];
+        request(o + stride);
+        float acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = 0.0f;
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const bool oku = row_ok & eok[u];
+#pragma unroll
+            for (int h = 0; h < 8; h += 4) {             // four entries' reads in flight
+                gvec xv[4][NT / GRP];
+                bool okj[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = idx_to_i32<IDX_T>(ii[u].get(h + j));
+                    okj[j] = oku & ((unsigned) i < (unsigned) p.n_in);
+                    const gvec * row = reinterpret_cast<const gvec *>(xs + (size_t) tile_row<false>(p, okj[j] ? i : 0, n4) * NT);
+#pragma unroll
+                    for (int q = 0; q < NT / GRP; ++q) xv[j][q] = row[q];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = val_to_f32<VAL_T>(vv[u].get(h + j));
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = add_if(acc[t], okj[j], __fmul_rn(v, xv[j][t / GRP][t % GRP]));
+                }
+            }
+        }
+        const float a = transpose_reduce<NT>(acc, G, lane);
+        if (row_ok && lead) {
             float yh = 0.0f;
             if (p.v) {
                 if (p.tall) yh = vb[0];
@@ -307,20 +421,20 @@ static int launch_typed(const DeltaLaunch & a, DeltaParams & p, hipStream_t s) {
         return SDH_ERR_UNSUPPORTED;
     }
     dim3 grid((unsigned) a.T, gy);
-    // many tokens of a block payload: activations of two or four tokens in the LDS, rows walked wave by wave. A tile fill
-    // per workgroup has to pay for itself: cfg3 (us per call, LDS form / per-token kernels): T=4 17.2 / 17.1, T=8 25.8 / 24.9,
-    // T=12 27.5 / 29.8, T=16 32.6 / 35.5, T=32 42.4 / 60.1, T=512 360 / 800
-    if constexpr (BLOCK) {
-        static const bool no_lds = getenv("SDH_ROWS_NO_LDS") != nullptr;           // dev: A/B
-        const size_t col = (size_t) p.n_in * sizeof(float);
+    // several tokens of a COO payload with x in LDS (delta_rows_coo_lds_kernel)
+    if constexpr (!BLOCK) {
+        static const int coo_lds_min_t = getenv("SDH_ROWS_COO_LDS_MIN_T") ? atoi(getenv("SDH_ROWS_COO_LDS_MIN_T")) : 5;   // dev: A/B
+        const size_t col = (size_t) ((p.n_in + 3) / 4) * 4 * sizeof(float);
         const size_t budget = 152 * 1024;
-        const int max_steps = sizeof(VAL_T) == 4 ? 3 : 4;          // fp32 values at four steps would spill (128 registers per lane)
-        static const int lds_min_t = getenv("SDH_ROWS_LDS_MIN_T") ? atoi(getenv("SDH_ROWS_LDS_MIN_T")) : 10;  // dev: A/B
-        if (vec_ok && a.T >= lds_min_t && G == 64 && steps >= 1 && steps <= max_steps && !no_lds && col * 2 <= budget) {
-            const int nt = col * 4 <= budget ? 4 : 2;
+        const int max_steps = sizeof(VAL_T) == 4 || sizeof(IDX_T) == 4 ? 1 : 2;
+        if (vec_ok && a.T >= coo_lds_min_t && G >= 8 && steps >= 1 && steps <= max_steps && col * 2 <= budget) {
+            int nt = col * 8 <= budget ? 8 : col * 4 <= budget ? 4 : 2;
+            while (nt > 2 && (nt > G || nt / 2 >= a.T)) nt >>= 1;   // no wider than the batch needs
             const int64_t tiles = (a.T + nt - 1) / nt;
-            const int rows_pass = 16;                       // a row per wave
-            int64_t chunks = (4 * (int64_t) lib().num_cu + tiles - 1) / tiles;
+            const int rows_pass = 16 * (64 / G);
+            // a workgroup fills its tile (up to 128 KB) before its first row: one round of workgroups, one per CU
+            static const int wgs_per_cu = getenv("SDH_ROWS_COO_WGS_PER_CU") ? atoi(getenv("SDH_ROWS_COO_WGS_PER_CU")) : 1;   // dev: A/B
+            int64_t chunks = (wgs_per_cu * (int64_t) lib().num_cu) / tiles;
             const int64_t max_chunks = (p.n_out + rows_pass - 1) / rows_pass;
             if (chunks > max_chunks) chunks = max_chunks;
             if (chunks < 1) chunks = 1;
@@ -328,11 +442,53 @@ static int launch_typed(const DeltaLaunch & a, DeltaParams & p, hipStream_t s) {
             rows_per_wg = (rows_per_wg + rows_pass - 1) / rows_pass * rows_pass;
             const unsigned gl = (unsigned) ((p.n_out + rows_per_wg - 1) / rows_per_wg);
             void (*kern)(const DeltaParams, int64_t, int) = nullptr;
-            switch (steps) {
-                case 1:  kern = nt == 4 ? delta_rows_block_lds_kernel<IDX_T, VAL_T, 1, 4> : delta_rows_block_lds_kernel<IDX_T, VAL_T, 1, 2>; break;
-                case 2:  kern = nt == 4 ? delta_rows_block_lds_kernel<IDX_T, VAL_T, 2, 4> : delta_rows_block_lds_kernel<IDX_T, VAL_T, 2, 2>; break;
-                case 3:  kern = nt == 4 ? delta_rows_block_lds_kernel<IDX_T, VAL_T, 3, 4> : delta_rows_block_lds_kernel<IDX_T, VAL_T, 3, 2>; break;
-                default: if constexpr (sizeof(VAL_T) == 2) kern = nt == 4 ? delta_rows_block_lds_kernel<IDX_T, VAL_T, 4, 4> : delta_rows_block_lds_kernel<IDX_T, VAL_T, 4, 2>; break;
+            if (steps == 1) kern = nt == 8 ? delta_rows_coo_lds_kernel<IDX_T, VAL_T, 1, 8> : nt == 4 ? delta_rows_coo_lds_kernel<IDX_T, VAL_T, 1, 4> : delta_rows_coo_lds_kernel<IDX_T, VAL_T, 1, 2>;
+            else if constexpr (sizeof(VAL_T) == 2 && sizeof(IDX_T) == 2)
+                kern = nt == 8 ? delta_rows_coo_lds_kernel<IDX_T, VAL_T, 2, 8> : nt == 4 ? delta_rows_coo_lds_kernel<IDX_T, VAL_T, 2, 4> : delta_rows_coo_lds_kernel<IDX_T, VAL_T, 2, 2>;
+            if (kern) {
+                SDH_HIP_CHECK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                hipLaunchKernelGGL(kern, dim3((unsigned) tiles, gl), dim3(1024), col * nt, s, p, a.T, rows_per_wg);
+                SDH_HIP_CHECK(hipGetLastError());
+                return SDH_OK;
+            }
+        }
+    }
+    // several tokens of a block payload: activations of 2 / 4 / 8 tokens in the LDS, rows walked pass by pass. A tile fill
+    // per workgroup has to pay for itself. Long rows (G = 64; cfg3, us per call, LDS form / per-token kernels): T=4 17.2 /
+    // 17.1, T=8 25.8 / 24.9, T=12 27.5 / 29.8, T=16 32.6 / 35.5, T=32 42.4 / 60.1, T=512 360 / 800: from 10 tokens on.
+    // Short rows come here from the gated FFN's node launches (SDH_FWD_INTERNAL_ROWS) and with 5 tokens: from 5 on.
+    if constexpr (BLOCK) {
+        static const bool no_lds = getenv("SDH_ROWS_NO_LDS") != nullptr;           // dev: A/B
+        static const int lds_min_t = getenv("SDH_ROWS_LDS_MIN_T") ? atoi(getenv("SDH_ROWS_LDS_MIN_T")) : 10;  // dev: A/B
+        static const int wgs_per_cu = getenv("SDH_ROWS_BLOCK_WGS_PER_CU") ? atoi(getenv("SDH_ROWS_BLOCK_WGS_PER_CU")) : 0;
+        const size_t col = (size_t) p.n_in * sizeof(float);
+        const size_t budget = 152 * 1024;
+        const int max_steps = sizeof(VAL_T) == 4 ? 3 : 4;          // fp32 values at four steps would spill (128 registers per lane)
+        const int64_t min_t = G == 64 ? lds_min_t : 5;
+        if (vec_ok && a.T >= min_t && G >= 8 && steps >= 1 && steps <= max_steps && !no_lds && col * 2 <= budget) {
+            int nt = (col * 8 <= budget && steps == 1) ? 8 : (col * 4 <= budget && steps <= 2) ? 4 : 2;     // register budget
+            while (nt > 2 && (nt > G || nt / 2 >= a.T)) nt >>= 1;  // no wider than the batch needs
+            const int64_t tiles = (a.T + nt - 1) / nt;
+            const int rows_pass = 16 * (64 / G);
+            // long rows: ~4 workgroups per CU over the launch; short rows: one round (the fill is a larger share)
+            const int wpc = wgs_per_cu > 0 ? wgs_per_cu : (G == 64 ? 4 : 1);
+            int64_t chunks = (wpc * (int64_t) lib().num_cu + tiles - 1) / tiles;
+            const int64_t max_chunks = (p.n_out + rows_pass - 1) / rows_pass;
+            if (chunks > max_chunks) chunks = max_chunks;
+            if (chunks < 1) chunks = 1;
+            int rows_per_wg = (int) ((p.n_out + chunks - 1) / chunks);
+            rows_per_wg = (rows_per_wg + rows_pass - 1) / rows_pass * rows_pass;
+            const unsigned gl = (unsigned) ((p.n_out + rows_per_wg - 1) / rows_per_wg);
+            void (*kern)(const DeltaParams, int64_t, int) = nullptr;
+            if (G == 64) {                                  // rows of 64 lanes: the reduction's steps are compile-time
+                switch (steps) {
+                    case 1:  kern = nt == 8 ? delta_rows_block_lds_kernel<IDX_T, VAL_T, 1, 8, 64> : nt == 4 ? delta_rows_block_lds_kernel<IDX_T, VAL_T, 1, 4, 64> : delta_rows_block_lds_kernel<IDX_T, VAL_T, 1, 2, 64>; break;
+                    case 2:  kern = nt == 4 ? delta_rows_block_lds_kernel<IDX_T, VAL_T, 2, 4, 64> : delta_rows_block_lds_kernel<IDX_T, VAL_T, 2, 2, 64>; break;
+                    case 3:  kern = delta_rows_block_lds_kernel<IDX_T, VAL_T, 3, 2, 64>; break;
+                    default: if constexpr (sizeof(VAL_T) == 2) kern = delta_rows_block_lds_kernel<IDX_T, VAL_T, 4, 2, 64>; break;
+                }
+            } else {                                        // G < 64: one step per lane
+                kern = nt == 8 ? delta_rows_block_lds_kernel<IDX_T, VAL_T, 1, 8, 0> : nt == 4 ? delta_rows_block_lds_kernel<IDX_T, VAL_T, 1, 4, 0> : delta_rows_block_lds_kernel<IDX_T, VAL_T, 1, 2, 0>;
             }
             SDH_HIP_CHECK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             hipLaunchKernelGGL(kern, dim3((unsigned) tiles, gl), dim3(1024), col * nt, s, p, a.T, rows_per_wg);

@@ -339,9 +339,6 @@ __device__ __forceinline__ void delta_row_partial_coo_lds4(const DeltaParams & p
     }
 }
 
-// reduce over the G lanes that own a row (G a power of two, groups aligned); every lane of the
-// group ends with the sum. (A DPP row-shift + v_readlane form of this reduction measured slower in the
-// fused decode launch, 7.78 vs 7.65 us on cfg3, and was dropped.)
 template <int CTRL> __device__ __forceinline__ float dpp_partner(float a) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), CTRL, 0xF, 0xF, true));
 }
@@ -404,5 +401,146 @@ __device__ __forceinline__ void store_output(const DeltaParams & p, int o, int64
     if (p.glu_gate) out = glu_value(p.glu_act, p.glu_gate[o + t * p.glu_ldg], out, p.glu_tab);
     p.y[o + t * p.ldy] = out;
 }
+
+// ---- token tiles of x in LDS (sdh_spmm.hip, delta_rows_*_lds kernels); layout notes in sdh_spmm.hip ----
+template <bool BLOCK>
+__device__ __forceinline__ int tile_row(const DeltaParams & p, int i, int n4) {
+    if constexpr (!BLOCK) return (i & 3) * n4 + (i >> 2);
+    return i + (p.block_shift >= 0 ? (i >> p.block_shift) : (i / p.block));
+}
+// Tile fill, GRP tokens at a time (one 4*GRP-byte LDS store per input and token group; tokens past the end of the batch
+// are zero). xs: [rows][TT].
+template <bool BLOCK, int TT, int GRP, int NTH>
+__device__ __forceinline__ void spmm_fill_tile(const DeltaParams & p, float * xs, int64_t t0, int nt, int n4, int tid) {
+    typedef float gvec __attribute__((ext_vector_type(GRP)));
+    static_assert(TT % GRP == 0, "token groups tile the tile");
+    for (int q = 0; q < TT; q += GRP) {
+        if (q >= nt) {                                   // a whole group past the end of the batch
+            gvec z;
+#pragma unroll
+            for (int u = 0; u < GRP; ++u) z[u] = 0.0f;
+            for (int i = tid; i < p.n_in; i += NTH) *reinterpret_cast<gvec *>(xs + (size_t) tile_row<BLOCK>(p, i, n4) * TT + q) = z;
+            continue;
+        }
+        const float * xt[GRP];
+#pragma unroll
+        for (int u = 0; u < GRP; ++u) xt[u] = p.x + (t0 + min(q + u, nt - 1)) * p.ldx;
+        int i = tid;
+        if constexpr (!BLOCK) {
+            if (p.x_vec_ok) {                            // 16-byte loads: two quads of inputs per trip
+                const int nq = p.n_in >> 2;
+                auto put = [&](int g, const float4 (&v)[GRP]) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        gvec w;
+#pragma unroll
+                        for (int u = 0; u < GRP; ++u) {
+                            const float c = j == 0 ? v[u].x : j == 1 ? v[u].y : j == 2 ? v[u].z : v[u].w;
+                            w[u] = (q + u < nt) ? c : 0.0f;
+                        }
+                        *reinterpret_cast<gvec *>(xs + ((size_t) j * n4 + g) * TT + q) = w;
+                    }
+                };
+                int g = tid;
+                for (; g + NTH < nq; g += 2 * NTH) {
+                    float4 va[GRP], vb[GRP];
+#pragma unroll
+                    for (int u = 0; u < GRP; ++u) va[u] = *reinterpret_cast<const float4 *>(xt[u] + 4 * g);
+#pragma unroll
+                    for (int u = 0; u < GRP; ++u) vb[u] = *reinterpret_cast<const float4 *>(xt[u] + 4 * (g + NTH));
+                    put(g, va);
+                    put(g + NTH, vb);
+                }
+                for (; g < nq; g += NTH) {
+                    float4 va[GRP];
+#pragma unroll
+                    for (int u = 0; u < GRP; ++u) va[u] = *reinterpret_cast<const float4 *>(xt[u] + 4 * g);
+                    put(g, va);
+                }
+                i = 4 * nq + tid;                        // the inputs of a last partial quad, one by one below
+            }
+        }
+        // one input per lane and trip, four trips' loads in flight
+        for (; i + 3 * NTH < p.n_in; i += 4 * NTH) {
+            gvec v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int u = 0; u < GRP; ++u) v[k][u] = xt[u][i + k * NTH];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int u = 0; u < GRP; ++u) if (q + u >= nt) v[k][u] = 0.0f;
+                *reinterpret_cast<gvec *>(xs + (size_t) tile_row<BLOCK>(p, i + k * NTH, n4) * TT + q) = v[k];
+            }
+        }
+        for (; i < p.n_in; i += NTH) {
+            gvec v;
+#pragma unroll
+            for (int u = 0; u < GRP; ++u) v[u] = (q + u < nt) ? xt[u][i] : 0.0f;
+            *reinterpret_cast<gvec *>(xs + (size_t) tile_row<BLOCK>(p, i, n4) * TT + q) = v;
+        }
+    }
+}
+
+
+// Lane's partner value under lane ^ m (m a power of two, uniform): half-register swaps for m = 32 / 16, DPP inside a
+// 16-lane row below. The data movement of one butterfly step for lanes on BOTH sides of the exchange.
+__device__ __forceinline__ float lane_xor_partner(float v, int m, int lane) {
+    switch (m) {
+        case 32: { const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                   return __uint_as_float((lane & 32) ? r[0] : r[1]); }
+        case 16: { const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                   return __uint_as_float((lane & 16) ? r[0] : r[1]); }
+        case 8:  return dpp_partner<0x128>(v);                                  // row_ror:8
+        case 4:  { const float a = dpp_partner<0x104>(v), b = dpp_partner<0x114>(v);     // row_shl:4 (i <- i+4), row_shr:4 (i <- i-4)
+                   return (lane & 4) ? b : a; }
+        case 2:  return dpp_partner<0x4E>(v);
+        default: return dpp_partner<0xB1>(v);
+    }
+}
+
+// NT sums per lane, G lanes per row (G >= NT, both powers of two): the butterfly of group_reduce for every token, with
+// the first log2(NT) steps transposing — at distance m the lanes with bit m clear keep the lower half of the tokens
+// they still hold and hand the upper half to their partner (and vice versa), so each step halves the values per lane
+// and every add is the butterfly's own pair (lane i with lane i ^ m). After those steps a lane holds ONE token's
+// partial sum; the remaining steps are plain. Token t's total ends in the lane of its row group whose bits
+// G/2, G/4, ... spell t (most significant first) and whose lower bits are 0 — reduce_token_of_lane / _is_leader —
+// with the bits lane 0 of the group would hold under group_reduce. One epilogue per token then runs on NT
+// different lanes at once instead of NT times on one.
+template <int NT, int GC = 0 /* G when known at compile time, else 0 */>
+__device__ __forceinline__ float transpose_reduce(float (&acc)[NT], int G_rt, int lane) {
+    const int G = GC > 0 ? GC : G_rt;
+    int m = G >> 1;
+#pragma unroll
+    for (int n = NT; n > 1; n >>= 1, m >>= 1) {
+        if (m == 32) {                                   // the swap itself transposes: one swap and one add per token pair
+#pragma unroll
+            for (int t = 0; t < n / 2; ++t) acc[t] = swap32_add(acc[t], acc[t + n / 2]);
+        } else if (m == 16) {
+#pragma unroll
+            for (int t = 0; t < n / 2; ++t) acc[t] = swap16_add(acc[t], acc[t + n / 2]);
+        } else {
+            const bool upper = (lane & m) != 0;
+#pragma unroll
+            for (int t = 0; t < n / 2; ++t) {
+                const float keep = upper ? acc[t + n / 2] : acc[t];
+                const float send = upper ? acc[t] : acc[t + n / 2];
+                acc[t] = __fadd_rn(keep, lane_xor_partner(send, m, lane));
+            }
+        }
+    }
+    return group_reduce(acc[0], G / NT);                 // the remaining steps: only the subgroup's lowest lane is read
+}
+template <int NT>
+__device__ __forceinline__ int reduce_token_of_lane(int G, int l) {            // l: lane within the row group
+    int t = 0, m = G >> 1;
+#pragma unroll
+    for (int n = NT; n > 1; n >>= 1, m >>= 1) t = (t << 1) | ((l & m) ? 1 : 0);
+    return t;
+}
+template <int NT>
+__device__ __forceinline__ bool reduce_is_leader(int G, int l) { return (l & (G / NT - 1)) == 0; }
 
 } // namespace sdh

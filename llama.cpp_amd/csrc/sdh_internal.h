@@ -122,6 +122,9 @@ int launch_base_apply_generic(const float * x, int64_t ldx, int n_in, int L, int
                               int64_t T, float * v, hipStream_t s);
 
 constexpr int MAX_FUSED_TOKENS = 4;
+// internal flag of sdh_forward_impl (gated FFN node launches): COO payloads with few tokens take the LDS rows kernel
+// (fast-path arithmetic) rather than the tiled SpMM
+constexpr int SDH_FWD_INTERNAL_ROWS = 0x40000000;
 
 struct DeltaLaunch {
     const float * x; int64_t ldx; int64_t T;

@@ -31,89 +31,8 @@ namespace sdh {
 // tokens the fill IS the kernel (a 256-thread workgroup fills 128 KB through a chain of L2 round trips: 15 of the
 // 59 us of a Mistral FFN layer at 8 tokens were tile fills).
 template <bool BLOCK>
-__device__ __forceinline__ int tile_row(const DeltaParams & p, int i, int n4) {
-    if constexpr (!BLOCK) return (i & 3) * n4 + (i >> 2);
-    return i + (p.block_shift >= 0 ? (i >> p.block_shift) : (i / p.block));
-}
-template <bool BLOCK>
 static size_t spmm_tile_rows(const DeltaParams & p) {
     return BLOCK ? (size_t) p.n_in + (size_t) ((p.n_in + p.block - 1) / p.block) : (size_t) ((p.n_in + 3) / 4) * 4;
-}
-
-// Tile fill, GRP tokens at a time (one 4*GRP-byte LDS store per input and token group; tokens past the end of the batch
-// are zero). xs: [rows][TT].
-template <bool BLOCK, int TT, int GRP, int NTH>
-__device__ __forceinline__ void spmm_fill_tile(const DeltaParams & p, float * xs, int64_t t0, int nt, int n4, int tid) {
-    typedef float gvec __attribute__((ext_vector_type(GRP)));
-    static_assert(TT % GRP == 0, "token groups tile the tile");
-    for (int q = 0; q < TT; q += GRP) {
-        if (q >= nt) {                                   // a whole group past the end of the batch
-            gvec z;
-#pragma unroll
-            for (int u = 0; u < GRP; ++u) z[u] = 0.0f;
-            for (int i = tid; i < p.n_in; i += NTH) *reinterpret_cast<gvec *>(xs + (size_t) tile_row<BLOCK>(p, i, n4) * TT + q) = z;
-            continue;
-        }
-        const float * xt[GRP];
-#pragma unroll
-        for (int u = 0; u < GRP; ++u) xt[u] = p.x + (t0 + min(q + u, nt - 1)) * p.ldx;
-        int i = tid;
-        if constexpr (!BLOCK) {
-            if (p.x_vec_ok) {                            // 16-byte loads: two quads of inputs per trip
-                const int nq = p.n_in >> 2;
-                auto put = [&](int g, const float4 (&v)[GRP]) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        gvec w;
-#pragma unroll
-                        for (int u = 0; u < GRP; ++u) {
-                            const float c = j == 0 ? v[u].x : j == 1 ? v[u].y : j == 2 ? v[u].z : v[u].w;
-                            w[u] = (q + u < nt) ? c : 0.0f;
-                        }
-                        *reinterpret_cast<gvec *>(xs + ((size_t) j * n4 + g) * TT + q) = w;
-                    }
-                };
-                int g = tid;
-                for (; g + NTH < nq; g += 2 * NTH) {
-                    float4 va[GRP], vb[GRP];
-#pragma unroll
-                    for (int u = 0; u < GRP; ++u) va[u] = *reinterpret_cast<const float4 *>(xt[u] + 4 * g);
-#pragma unroll
-                    for (int u = 0; u < GRP; ++u) vb[u] = *reinterpret_cast<const float4 *>(xt[u] + 4 * (g + NTH));
-                    put(g, va);
-                    put(g + NTH, vb);
-                }
-                for (; g < nq; g += NTH) {
-                    float4 va[GRP];
-#pragma unroll
-                    for (int u = 0; u < GRP; ++u) va[u] = *reinterpret_cast<const float4 *>(xt[u] + 4 * g);
-                    put(g, va);
-                }
-                i = 4 * nq + tid;                        // the inputs of a last partial quad, one by one below
-            }
-        }
-        // one input per lane and trip, four trips' loads in flight
-        for (; i + 3 * NTH < p.n_in; i += 4 * NTH) {
-            gvec v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-#pragma unroll
-                for (int u = 0; u < GRP; ++u) v[k][u] = xt[u][i + k * NTH];
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-#pragma unroll
-                for (int u = 0; u < GRP; ++u) if (q + u >= nt) v[k][u] = 0.0f;
-                *reinterpret_cast<gvec *>(xs + (size_t) tile_row<BLOCK>(p, i + k * NTH, n4) * TT + q) = v[k];
-            }
-        }
-        for (; i < p.n_in; i += NTH) {
-            gvec v;
-#pragma unroll
-            for (int u = 0; u < GRP; ++u) v[u] = (q + u < nt) ? xt[u][i] : 0.0f;
-            *reinterpret_cast<gvec *>(xs + (size_t) tile_row<BLOCK>(p, i, n4) * TT + q) = v;
-        }
-    }
 }
 
 template <typename IDX_T, typename VAL_T, bool BLOCK, bool VEC, int TT, int NTH>

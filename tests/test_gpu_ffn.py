@@ -164,9 +164,10 @@ def test_gate_up_small_batch_single_launch_is_bit_identical_to_node_by_node(hip,
 
 
 @pytest.mark.parametrize("scheme,K,block", [("coo", 128, 16), ("block", 128, 16)])
-def test_ffn_five_to_eight_tokens_run_as_groups_of_four(hip, scheme, K, block):
-    """sdh_ffn_forward with 5..8 tokens goes through the single-launch forms in groups of up to four tokens: every
-    token's output is its one-token output bit for bit, and the non-finite counters cover the whole call."""
+def test_ffn_five_to_eight_tokens_keep_one_token_results(hip, scheme, K, block):
+    """sdh_ffn_forward with 5..8 tokens: block payloads go through the single-launch forms in groups of up to four
+    tokens, COO payloads node by node through the LDS rows kernel. Either way every token's output is its one-token
+    output bit for bit, and the non-finite counters cover the whole call."""
     n_embd, n_ff = 2048, 5632
     kw = dict(scheme=scheme, K=K, block=block, base=True, d13_random=True)
     gate, up = make_payload(n_embd, n_ff, seed=41, **kw), make_payload(n_embd, n_ff, seed=42, **kw)
@@ -176,7 +177,7 @@ def test_ffn_five_to_eight_tokens_run_as_groups_of_four(hip, scheme, K, block):
     single = np.concatenate([hip.ffn_forward_host(wg, wu, wd, xs[t:t + 1], O.ACT_SILU) for t in range(8)], axis=0)
     for T in (5, 6, 7, 8):
         y = hip.ffn_forward_host(wg, wu, wd, xs[:T], O.ACT_SILU)
-        assert hip.ffn_last_fused()
+        assert hip.ffn_last_fused() == (scheme == "block")      # COO: node by node through the LDS rows kernel
         assert np.array_equal(bits(y), bits(single[:T])), T
         assert wg.nonfinite_count() == 0 and wu.nonfinite_count() == 0 and wd.nonfinite_count() == 0
     y9 = hip.ffn_forward_host(wg, wu, wd, np.concatenate([xs, xs[:1]]), O.ACT_SILU)       # 9 tokens: the tiled path
