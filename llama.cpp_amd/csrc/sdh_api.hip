@@ -627,6 +627,7 @@ static int sdh_forward_impl(sdh_weight * h, const float * x, int64_t ldx, int64_
                 rc = launch_w0_mfma(*w, xc, dldx, tc, ws, s);
                 if (rc == SDH_OK && !w->tall) a.v_blocks = 1;
             }
+            if (rc == 1 && w->base_ready && !noalloc && tc == n_tokens) rc = SDH_OK;   // the FFN path's gate|up base launch wrote ws
             if (rc == 1) rc = launch_base_apply(*w, xc, dldx, tc, ws, s);
             if (rc != SDH_OK) return rc;
             a.v = ws;
@@ -742,9 +743,24 @@ static int ffn_gate_up(sdh_weight * hg, sdh_weight * hu, int act, const float * 
     // the gate node, then the up node with the activation in its epilogue: h = act(g) * up(x) is written by the up
     // launch itself (no separate activation pass over three [T][n_ff] buffers; ubuf is no longer used)
     (void) ubuf;
-    if ((rc = sdh_forward(hg, dx, dldx, T, gbuf, n_ff, flags, s)) != SDH_OK) return rc;
+    // few tokens: the base terms of both tensors from ONE launch (2B blocks per token) into the tensors' workspaces
+    const size_t per_tok = (size_t) g->B * (size_t) g->L * 4;
+    const auto with_base = [](const DeviceWeight * w) { return w->kind == SDH_OP_BASE_COO || w->kind == SDH_OP_BASE_BLOCK; };
+    if (T > MAX_FUSED_TOKENS && T <= 64 && g != u && with_base(g) && with_base(u) && g->tall && u->tall &&
+        !(flags & (SDH_FWD_EXACT_ORDER | SDH_FWD_W0_MFMA)) && per_tok * (size_t) T <= ((size_t) 64 << 20)) {
+        if ((rc = ensure_ws(g, per_tok * (size_t) T)) != SDH_OK) return rc;
+        if ((rc = ensure_ws(u, per_tok * (size_t) T)) != SDH_OK) return rc;
+        rc = launch_base_apply_pair(*g, *u, dx, dldx, T, g->ws, u->ws, s);
+        if (rc < 0) return rc;
+        if (rc == SDH_OK) g->base_ready = u->base_ready = true;
+    }
+    rc = sdh_forward(hg, dx, dldx, T, gbuf, n_ff, flags, s);
+    g->base_ready = false;
+    if (rc != SDH_OK) { u->base_ready = false; return rc; }
     const GluEpilogue ge{gbuf, n_ff, act, ls.gelu_tab};
-    return sdh_forward_impl(hu, dx, dldx, T, hbuf, n_ff, flags, s, nullptr, 0, &ge);
+    rc = sdh_forward_impl(hu, dx, dldx, T, hbuf, n_ff, flags, s, nullptr, 0, &ge);
+    u->base_ready = false;
+    return rc;
 }
 
 int sdh_ffn_last_fused(void) { return lib().ffn_last_fused; }

@@ -80,6 +80,7 @@ struct DeviceWeight {
     hipStream_t last_stream = nullptr;
     // workspace for the base term v[T_chunk][B][L]
     float * ws = nullptr;
+    bool    base_ready = false;  // ws already holds the base terms of the next call's tokens (gate|up base launch of the FFN path)
     size_t  ws_bytes = 0;
 };
 
@@ -114,6 +115,8 @@ LibState & lib();
 
 // ---- kernel launchers (sdh_base.hip / sdh_delta.hip) -------------------------------------------
 // v[t][b][i] = (D3 H [D2 [P2] H] P1 D1 x_chunk)(i) for t in [0,T), b in [0,B)
+int launch_base_apply_pair(const DeviceWeight & w0, const DeviceWeight & w1, const float * x, int64_t ldx, int64_t T,
+                           float * v0, float * v1, hipStream_t s);
 int launch_base_apply(const DeviceWeight & w, const float * x, int64_t ldx, int64_t T,
                       float * v, hipStream_t s);
 
