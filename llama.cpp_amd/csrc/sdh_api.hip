@@ -487,10 +487,6 @@ static int device_to_host_sync(LibState & L, float * dst, int64_t ld, const floa
 // first half is in use (one small memset every NF_SLOTS/2 calls, none on the other calls)
 static int nf_slot(DeviceWeight * w, hipStream_t s, int * slot_out) {
     constexpr int NS = DeviceWeight::NF_SLOTS;
-    if (w->nf_continue && w->seq > 0) {                 // a later token group of one FFN call: the call's slot, seq stays
-        *slot_out = (int) ((w->seq - 1) % NS);
-        return SDH_OK;
-    }
     const int slot = (int) (w->seq % NS);
     if (w->seq > 0 && slot % (NS / 2) == 0) {
         SDH_HIP_CHECK(hipMemsetAsync(w->nf_ring + slot, 0, (NS / 2) * sizeof(int), s));
@@ -647,7 +643,7 @@ static int sdh_forward_impl(sdh_weight * h, const float * x, int64_t ldx, int64_
         rc = prof_end(pair);
         if (rc != SDH_OK) return rc;
     }
-    if (!(w->nf_continue && w->seq > 0)) w->seq++;
+    w->seq++;
     w->last_stream = s;
     ls.span_forwards++;
 
@@ -731,8 +727,7 @@ static int ffn_gate_up(sdh_weight * hg, sdh_weight * hu, int act, const float * 
                                 (flags & SDH_FWD_ZERO_NONFINITE) != 0, s);
         if (rc < 0) return rc;
         if (rc == SDH_OK) {
-            if (!(g->nf_continue && g->seq > 0)) g->seq++;
-            if (!(u->nf_continue && u->seq > 0)) u->seq++;
+            g->seq++; u->seq++;
             g->last_stream = u->last_stream = s;
             ls.span_forwards += 2;
             ls.ffn_last_fused = 1;
@@ -787,7 +782,8 @@ static int sdh_ffn_gate_up_impl(sdh_weight * hg, sdh_weight * hu, int act, const
         dx = ws[0]; dldx = n_embd;
     }
     float * hbuf = dense_h ? h : ws[1];
-    if ((rc = ffn_gate_up(hg, hu, act, dx, dldx, n_tokens, hbuf, ws[2], ws[3], flags & ~SDH_FWD_HOST_IO, s)) != SDH_OK) return rc;
+    const int sub = (flags & ~SDH_FWD_HOST_IO) | (n_tokens > MAX_FUSED_TOKENS ? SDH_FWD_INTERNAL_ROWS : 0);
+    if ((rc = ffn_gate_up(hg, hu, act, dx, dldx, n_tokens, hbuf, ws[2], ws[3], sub, s)) != SDH_OK) return rc;
     if (host_io) return device_to_host_sync(ls, h, ldh, hbuf, n_ff, n_tokens, s);
     if (!dense_h) {
         SDH_HIP_CHECK(hipMemcpy2DAsync(h, (size_t) ldh * 4, hbuf, (size_t) n_ff * 4, (size_t) n_ff * 4, T, hipMemcpyDeviceToDevice, s));
@@ -825,26 +821,12 @@ static int sdh_ffn_forward_impl(sdh_weight * hg, sdh_weight * hu, sdh_weight * h
         dx = ws[0]; dldx = n_embd; dy = ws[1]; dldy = d->n_out;
     }
     const int sub = (flags & ~SDH_FWD_HOST_IO) | (n_tokens > MAX_FUSED_TOKENS ? SDH_FWD_INTERNAL_ROWS : 0);
-    // 5..8 tokens, block payloads: groups of up to four through the single-launch forms (a gate|up launch and a fused
-    // down launch per group) instead of six node launches over token tiles. Mistral layer, block16, us: 4 tokens 18.7,
-    // 8 tokens 37.6 against 57.9 through the tiled path. COO payloads take the LDS rows kernel node by node instead
-    // (SDH_FWD_INTERNAL_ROWS: 41 us at 5..8 tokens against 49 in groups and 56 tiled; 51 at 16, 68 at 32 against 59 and
-    // 77 tiled; the tiled path wins again from ~48 tokens). Either way a token's result is its one-token result.
-    static const int64_t ffn_group_max = [] { const char * e = getenv("SDH_FFN_GROUP_MAX"); return e ? (int64_t) atoll(e) : (int64_t) 8; }();
-    DeviceWeight * u = reinterpret_cast<DeviceWeight *>(hu);
-    const bool groups = n_tokens > MAX_FUSED_TOKENS && n_tokens <= ffn_group_max &&
-                        !(sub & (SDH_FWD_NO_FUSE | SDH_FWD_EXACT_ORDER | SDH_FWD_NO_SPMM | SDH_FWD_W0_MFMA)) &&
-                        g != u && g != d && u != d && g->kind == SDH_OP_BASE_BLOCK;
-    const int64_t step = groups ? MAX_FUSED_TOKENS : n_tokens;
-    rc = SDH_OK;
-    for (int64_t t0 = 0; t0 < n_tokens && rc == SDH_OK; t0 += step) {
-        const int64_t tc = std::min<int64_t>(step, n_tokens - t0);
-        g->nf_continue = u->nf_continue = d->nf_continue = t0 > 0;
-        rc = ffn_gate_up(hg, hu, act, dx + t0 * dldx, dldx, tc, ws[2] + t0 * n_ff, ws[3], ws[4], sub, s);
-        if (rc == SDH_OK) rc = sdh_forward(hd, ws[2] + t0 * n_ff, n_ff, tc, dy + t0 * dldy, dldy, sub, s);
-    }
-    g->nf_continue = u->nf_continue = d->nf_continue = false;
-    if (rc != SDH_OK) return rc;
+    // 5..32 tokens: node by node, the residual through the LDS rows kernels (SDH_FWD_INTERNAL_ROWS) and the base terms of
+    // gate and up from one launch. Mistral layer, us, COO / block16: T=8 36 / 33 (56 / 58 through the tiled SpMM path, 49 /
+    // 37 as two groups of four tokens through the single-launch forms — tried, dropped), T=16 45 / 40 (59 / 59), T=32 62 /
+    // 55 (77 / 69); from ~48 tokens on the tiled path wins. A token's result is its one-token result.
+    if ((rc = ffn_gate_up(hg, hu, act, dx, dldx, n_tokens, ws[2], ws[3], ws[4], sub, s)) != SDH_OK) return rc;
+    if ((rc = sdh_forward(hd, ws[2], n_ff, n_tokens, dy, dldy, sub, s)) != SDH_OK) return rc;
     if (host_io) return device_to_host_sync(ls, y, ldy, dy, d->n_out, n_tokens, s);
     return SDH_OK;
 }

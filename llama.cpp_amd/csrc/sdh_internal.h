@@ -75,7 +75,6 @@ struct DeviceWeight {
     // non-finite accounting: ring of per-call counters (no per-call memset on the hot path)
     static constexpr int NF_SLOTS = 256;
     int *    nf_ring = nullptr;  // device, NF_SLOTS ints
-    bool     nf_continue = false; // this launch continues the previous one's call (FFN token chunks): same counter slot
     uint64_t seq = 0;            // forwards issued
     hipStream_t last_stream = nullptr;
     // workspace for the base term v[T_chunk][B][L]

@@ -165,9 +165,9 @@ def test_gate_up_small_batch_single_launch_is_bit_identical_to_node_by_node(hip,
 
 @pytest.mark.parametrize("scheme,K,block", [("coo", 128, 16), ("block", 128, 16)])
 def test_ffn_five_to_eight_tokens_keep_one_token_results(hip, scheme, K, block):
-    """sdh_ffn_forward with 5..8 tokens: block payloads go through the single-launch forms in groups of up to four
-    tokens, COO payloads node by node through the LDS rows kernel. Either way every token's output is its one-token
-    output bit for bit, and the non-finite counters cover the whole call."""
+    """sdh_ffn_forward with 5..8 tokens goes node by node through the LDS rows kernels (base terms of gate and up from
+    one launch): every token's output is its one-token output bit for bit, and the non-finite counters cover the
+    whole call."""
     n_embd, n_ff = 2048, 5632
     kw = dict(scheme=scheme, K=K, block=block, base=True, d13_random=True)
     gate, up = make_payload(n_embd, n_ff, seed=41, **kw), make_payload(n_embd, n_ff, seed=42, **kw)
@@ -177,15 +177,15 @@ def test_ffn_five_to_eight_tokens_keep_one_token_results(hip, scheme, K, block):
     single = np.concatenate([hip.ffn_forward_host(wg, wu, wd, xs[t:t + 1], O.ACT_SILU) for t in range(8)], axis=0)
     for T in (5, 6, 7, 8):
         y = hip.ffn_forward_host(wg, wu, wd, xs[:T], O.ACT_SILU)
-        assert hip.ffn_last_fused() == (scheme == "block")      # COO: node by node through the LDS rows kernel
+        assert not hip.ffn_last_fused()                          # node by node through the LDS rows kernels
         assert np.array_equal(bits(y), bits(single[:T])), T
         assert wg.nonfinite_count() == 0 and wu.nonfinite_count() == 0 and wd.nonfinite_count() == 0
-    y9 = hip.ffn_forward_host(wg, wu, wd, np.concatenate([xs, xs[:1]]), O.ACT_SILU)       # 9 tokens: the tiled path
+    y9 = hip.ffn_forward_host(wg, wu, wd, np.concatenate([xs, xs[:1]]), O.ACT_SILU)       # 9 tokens: two token tiles
     assert not hip.ffn_last_fused()
     smooth, full, h_ref = h_bounds(gate, up, xs, O.ACT_SILU)
     y_ref = O.forward(down, O.glu(O.ACT_SILU, O.forward(gate, xs), O.forward(up, xs)))
     check_y(y9[:8], y_ref.astype(np.float64), down, h_ref.astype(np.float32), full)
-    # a non-finite gate output in every token: the gate node's counter reports the whole call, not the last group
+    # a non-finite gate output in every token: the gate node's counter reports the whole call
     bad = make_payload(n_embd, n_ff, seed=41, **kw)
     if scheme == "coo":
         bad.d_val[7, 0] = np.float16(np.inf); bad.d_idx[7, 0] = 3
@@ -193,7 +193,7 @@ def test_ffn_five_to_eight_tokens_keep_one_token_results(hip, scheme, K, block):
         bad.b_val[7, 0, 3] = np.float16(np.inf); bad.b_idx[7, 0] = 0
     wb = hip.SeedDeltaWeight(bad)
     xb = xs[:7].copy()
-    xb[:, 3] = 1.0                                          # inf * x is non-finite for every token: 4 in the first group, 3 in the second
+    xb[:, 3] = 1.0                                          # inf * x is non-finite for every token
     y = hip.ffn_forward_host(wb, wu, wd, xb, O.ACT_SILU, hip.FWD_ZERO_NONFINITE)
     assert wb.nonfinite_count() == 7 and wu.nonfinite_count() == 0
     assert np.all(np.isfinite(y))
