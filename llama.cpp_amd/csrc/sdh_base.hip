@@ -87,64 +87,74 @@ void base_apply_lds_kernel(const float * __restrict__ x, int64_t ldx, int n_in, 
 // ---------------------------------------------------------------------------------------------
 // register / LDS-transpose kernel: one workgroup per (base block, token)
 // ---------------------------------------------------------------------------------------------
-template <int LOG_E, bool P32>
-__global__ __launch_bounds__(256)
+template <int LOG_E, bool P32, int LOG_T = 8>
+__global__ __launch_bounds__(1 << LOG_T)
 void base_apply_kernel(const float * __restrict__ x, int64_t ldx, int n_in, int B, int tall, int x_vec_ok,
                        const BasePackDesc pd, float * __restrict__ v) {
-    constexpr int L = BaseLay<LOG_E>::L;
+    using Ly = BaseLay<LOG_E, LOG_T>;
+    constexpr int L = Ly::L;
     __shared__ __align__(16) float lds[2 * L];
     const int b = blockIdx.x;
     const int64_t t = blockIdx.y;
     SDH_STAMP(0);
     float * out = v + ((size_t) t * B + b) * (size_t) L;
     float y[1 << LOG_E];
-    base_transform<BaseLay<LOG_E>, P32, false>(x + t * ldx, n_in, tall ? 0 : b * L, x_vec_ok != 0, pd, b, lds, threadIdx.x, y);
+    base_transform<Ly, P32, false>(x + t * ldx, n_in, tall ? 0 : b * L, x_vec_ok != 0, pd, b, lds, threadIdx.x, y);
 #pragma unroll
-    for (int r = 0; r < (1 << LOG_E); ++r) out[BaseLay<LOG_E>::idx(BaseLay<LOG_E>::J - 1, threadIdx.x, r)] = y[r];
+    for (int r = 0; r < (1 << LOG_E); ++r) out[Ly::idx(Ly::J - 1, threadIdx.x, r)] = y[r];
     SDH_STAMP(9);
+}
+
+// L = 4096 runs 512 threads x 8 elements (the decode kernels' shape) instead of 256 x 16: shorter per block and no
+// slower in bulk. Mistral FFN layer, us, 256- / 512-thread form: T=8 35.8 / 34.0, T=32 62.4 / 60.5, T=512 534 / 529.
+// SDH_BASE_WIDE_WG=0 selects the 256-thread form (A/B).
+static bool base_wide_wg(int64_t) {
+    static const bool off = [] { const char * e = getenv("SDH_BASE_WIDE_WG"); return e && atoi(e) == 0; }();
+    return !off;
 }
 
 // Two tensors of one shape over the same activations (gate and up of a gated FFN) in one launch: blocks 0..B-1 are the
 // first tensor's, B..2B-1 the second's. The transform is base_apply_kernel's.
-template <int LOG_E, bool P32>
-__global__ __launch_bounds__(256)
+template <int LOG_E, bool P32, int LOG_T = 8>
+__global__ __launch_bounds__(1 << LOG_T)
 void base_apply_pair_kernel(const float * __restrict__ x, int64_t ldx, int n_in, int B, int tall, int x_vec_ok,
                             const BasePackDesc pd0, const BasePackDesc pd1, float * __restrict__ v0, float * __restrict__ v1) {
-    constexpr int L = BaseLay<LOG_E>::L;
+    using Ly = BaseLay<LOG_E, LOG_T>;
+    constexpr int L = Ly::L;
     __shared__ __align__(16) float lds[2 * L];
     const bool second = (int) blockIdx.x >= B;
     const int b = (int) blockIdx.x - (second ? B : 0);
     const int64_t t = blockIdx.y;
     float * out = (second ? v1 : v0) + ((size_t) t * B + b) * (size_t) L;
     float y[1 << LOG_E];
-    base_transform<BaseLay<LOG_E>, P32, false>(x + t * ldx, n_in, tall ? 0 : b * L, x_vec_ok != 0, second ? pd1 : pd0, b, lds, threadIdx.x, y);
+    base_transform<Ly, P32, false>(x + t * ldx, n_in, tall ? 0 : b * L, x_vec_ok != 0, second ? pd1 : pd0, b, lds, threadIdx.x, y);
 #pragma unroll
-    for (int r = 0; r < (1 << LOG_E); ++r) out[BaseLay<LOG_E>::idx(BaseLay<LOG_E>::J - 1, threadIdx.x, r)] = y[r];
+    for (int r = 0; r < (1 << LOG_E); ++r) out[Ly::idx(Ly::J - 1, threadIdx.x, r)] = y[r];
 }
 
-template <int LOG_E>
+template <int LOG_E, int LOG_T = 8>
 static void launch_reg_pair(const DeviceWeight & w0, const DeviceWeight & w1, const float * x, int64_t ldx, int64_t T,
                             float * v0, float * v1, hipStream_t s) {
     dim3 grid((unsigned) (2 * w0.B), (unsigned) T);
     const int x_vec_ok = (((uintptr_t) x % 16) == 0 && (ldx % 4) == 0) ? 1 : 0;
     if (w0.pack.wide32) {
-        hipLaunchKernelGGL((base_apply_pair_kernel<LOG_E, true>), grid, dim3(256), 0, s,
+        hipLaunchKernelGGL((base_apply_pair_kernel<LOG_E, true, LOG_T>), grid, dim3(1 << LOG_T), 0, s,
                            x, ldx, (int) w0.n_in, (int) w0.B, w0.tall ? 1 : 0, x_vec_ok, w0.pack, w1.pack, v0, v1);
     } else {
-        hipLaunchKernelGGL((base_apply_pair_kernel<LOG_E, false>), grid, dim3(256), 0, s,
+        hipLaunchKernelGGL((base_apply_pair_kernel<LOG_E, false, LOG_T>), grid, dim3(1 << LOG_T), 0, s,
                            x, ldx, (int) w0.n_in, (int) w0.B, w0.tall ? 1 : 0, x_vec_ok, w0.pack, w1.pack, v0, v1);
     }
 }
 
-template <int LOG_E>
+template <int LOG_E, int LOG_T = 8>
 static void launch_reg(const DeviceWeight & w, const float * x, int64_t ldx, int64_t T, float * v, hipStream_t s) {
     dim3 grid((unsigned) w.B, (unsigned) T);
     const int x_vec_ok = (((uintptr_t) x % 16) == 0 && (ldx % 4) == 0) ? 1 : 0;
     if (w.pack.wide32) {
-        hipLaunchKernelGGL((base_apply_kernel<LOG_E, true>), grid, dim3(256), 0, s,
+        hipLaunchKernelGGL((base_apply_kernel<LOG_E, true, LOG_T>), grid, dim3(1 << LOG_T), 0, s,
                            x, ldx, (int) w.n_in, (int) w.B, w.tall ? 1 : 0, x_vec_ok, w.pack, v);
     } else {
-        hipLaunchKernelGGL((base_apply_kernel<LOG_E, false>), grid, dim3(256), 0, s,
+        hipLaunchKernelGGL((base_apply_kernel<LOG_E, false, LOG_T>), grid, dim3(1 << LOG_T), 0, s,
                            x, ldx, (int) w.n_in, (int) w.B, w.tall ? 1 : 0, x_vec_ok, w.pack, v);
     }
 }
@@ -189,7 +199,7 @@ int launch_base_apply(const DeviceWeight & w, const float * x, int64_t ldx, int6
     switch (L) {
         case 1024: launch_reg<2>(w, x, ldx, T, v, s); break;
         case 2048: launch_reg<3>(w, x, ldx, T, v, s); break;
-        case 4096: launch_reg<4>(w, x, ldx, T, v, s); break;
+        case 4096: if (base_wide_wg(T * w.B)) launch_reg<3, 9>(w, x, ldx, T, v, s); else launch_reg<4>(w, x, ldx, T, v, s); break;
         case 8192: launch_reg<5>(w, x, ldx, T, v, s); break;
         default:
             return launch_base_apply_generic(x, ldx, (int) w.n_in, L, (int) w.B, w.tall, w.d1, w.d2, w.d3, w.p1, w.p2, T, v, s);
@@ -206,7 +216,7 @@ int launch_base_apply_pair(const DeviceWeight & w0, const DeviceWeight & w1, con
     switch ((int) w0.L) {
         case 1024: launch_reg_pair<2>(w0, w1, x, ldx, T, v0, v1, s); break;
         case 2048: launch_reg_pair<3>(w0, w1, x, ldx, T, v0, v1, s); break;
-        case 4096: launch_reg_pair<4>(w0, w1, x, ldx, T, v0, v1, s); break;
+        case 4096: if (base_wide_wg(2 * T * w0.B)) launch_reg_pair<3, 9>(w0, w1, x, ldx, T, v0, v1, s); else launch_reg_pair<4>(w0, w1, x, ldx, T, v0, v1, s); break;
         case 8192: launch_reg_pair<5>(w0, w1, x, ldx, T, v0, v1, s); break;
         default: return 1;
     }
