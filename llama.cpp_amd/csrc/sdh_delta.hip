@@ -107,16 +107,6 @@ void delta_rows_block_lds_kernel(const DeltaParams p, const int64_t T, const int
     const int nch = p.n_in >> 3;
     const int64_t t0 = (int64_t) blockIdx.x * NT;
     const int nt = (int) ((T - t0 < NT) ? (T - t0) : NT);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const float * xt = p.x + (t0 + (t < nt ? t : nt - 1)) * p.ldx;
-        for (int c = tid; c < nch; c += 1024) {
-            xs4[(t * 2 + 0) * nch + c] = *reinterpret_cast<const float4 *>(xt + c * 8);
-            xs4[(t * 2 + 1) * nch + c] = *reinterpret_cast<const float4 *>(xt + c * 8 + 4);
-        }
-    }
-    __syncthreads();
-
     const int r0 = (int) blockIdx.y * rows_per_wg;
     const int r1 = min(p.n_out, r0 + rows_per_wg);
     int e0[NS], bi[NS], off[NS];
@@ -154,7 +144,22 @@ void delta_rows_block_lds_kernel(const DeltaParams p, const int64_t T, const int
     };
     const int stride = 16 * rows_wave;                  // rows per pass of the workgroup
     int o = r0 + wave * rows_wave + lane / G;
-    request(o);
+    request(o);                                          // the first rows' payload travels while the tile is filled
+    for (int c = tid; c < nch; c += 1024) {              // all tokens of a chunk per trip: 2 NT 16-byte loads in flight
+        float4 va[NT], vb2[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float * xt = p.x + (t0 + (t < nt ? t : nt - 1)) * p.ldx;
+            va[t] = *reinterpret_cast<const float4 *>(xt + c * 8);
+            vb2[t] = *reinterpret_cast<const float4 *>(xt + c * 8 + 4);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            xs4[(t * 2 + 0) * nch + c] = va[t];
+            xs4[(t * 2 + 1) * nch + c] = vb2[t];
+        }
+    }
+    __syncthreads();
     const int passes = (r1 - r0 + stride - 1) / stride;  // uniform over the workgroup
     for (int it = 0; it < passes; ++it, o += stride) {
         const bool row_ok = o < r1;
@@ -230,9 +235,6 @@ void delta_rows_coo_lds_kernel(const DeltaParams p, const int64_t T, const int r
     const int n4 = (p.n_in + 3) >> 2;
     const int64_t t0 = (int64_t) blockIdx.x * NT;
     const int nt = (int) ((T - t0 < NT) ? (T - t0) : NT);
-    spmm_fill_tile<false, NT, GRP, 1024>(p, xs, t0, nt, n4, tid);
-    __syncthreads();
-
     const int r0 = (int) blockIdx.y * rows_per_wg;
     const int r1 = min(p.n_out, r0 + rows_per_wg);
     int e0[NS];
@@ -267,7 +269,9 @@ void delta_rows_coo_lds_kernel(const DeltaParams p, const int64_t T, const int r
     };
     const int stride = 16 * rows_wave;                  // rows per pass of the workgroup
     int o = r0 + wave * rows_wave + lane / G;
-    request(o);
+    request(o);                                          // the first rows' payload travels while the tile is filled
+    spmm_fill_tile<false, NT, GRP, 1024>(p, xs, t0, nt, n4, tid);
+    __syncthreads();
     const int passes = (r1 - r0 + stride - 1) / stride;  // uniform over the workgroup
     for (int it = 0; it < passes; ++it, o += stride) {
         const bool row_ok = o < r1;

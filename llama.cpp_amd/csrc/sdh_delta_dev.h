@@ -414,6 +414,38 @@ template <bool BLOCK, int TT, int GRP, int NTH>
 __device__ __forceinline__ void spmm_fill_tile(const DeltaParams & p, float * xs, int64_t t0, int nt, int n4, int tid) {
     typedef float gvec __attribute__((ext_vector_type(GRP)));
     static_assert(TT % GRP == 0, "token groups tile the tile");
+    if constexpr (!BLOCK && TT <= 8) {
+        if (p.x_vec_ok) {                                // all TT tokens of a quad of inputs per trip: TT 16-byte loads in flight
+            const int nq = p.n_in >> 2;
+            const float * xt[TT];
+#pragma unroll
+            for (int t = 0; t < TT; ++t) xt[t] = p.x + (t0 + min(t, nt - 1)) * p.ldx;
+            for (int g = tid; g < nq; g += NTH) {
+                float4 v[TT];
+#pragma unroll
+                for (int t = 0; t < TT; ++t) v[t] = *reinterpret_cast<const float4 *>(xt[t] + 4 * g);
+#pragma unroll
+                for (int q = 0; q < TT; q += GRP) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        gvec w;
+#pragma unroll
+                        for (int u = 0; u < GRP; ++u) {
+                            const float4 & c4 = v[q + u];
+                            const float c = j == 0 ? c4.x : j == 1 ? c4.y : j == 2 ? c4.z : c4.w;
+                            w[u] = (q + u < nt) ? c : 0.0f;
+                        }
+                        *reinterpret_cast<gvec *>(xs + ((size_t) j * n4 + g) * TT + q) = w;
+                    }
+                }
+            }
+            for (int i = 4 * nq + tid; i < p.n_in; i += NTH) {       // the inputs of a last partial quad
+#pragma unroll
+                for (int t = 0; t < TT; ++t) xs[(size_t) tile_row<false>(p, i, n4) * TT + t] = (t < nt) ? xt[t][i] : 0.0f;
+            }
+            return;
+        }
+    }
     for (int q = 0; q < TT; q += GRP) {
         if (q >= nt) {                                   // a whole group past the end of the batch
             gvec z;
