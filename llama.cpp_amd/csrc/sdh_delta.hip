@@ -22,6 +22,7 @@
 //   delta_exact_kernel       — verification mode: one lane per output, the reference's sequential
 //                              order with separately rounded multiply and add; bit-identical.
 #include "sdh_internal.h"
+#include <type_traits>
 #include "sdh_delta_dev.h"
 
 namespace sdh {
@@ -126,25 +127,31 @@ void delta_rows_block_lds_kernel(const DeltaParams p, const int64_t T, const int
     const bool lead = reduce_is_leader<NT>(G, l) && my_t < nt;
     constexpr int NB = 4;
     const int nbase = p.v ? (p.tall ? 1 : p.B) : 0;
-    const float * vt = p.v + (size_t) (t0 + (my_t < nt ? my_t : 0)) * (size_t) p.v_ld;
-    IDX_T blk_n[NS];
-    Vec8<VAL_T> vv_n[NS];
-    float vb_n[NB], scale_n = 1.0f;
-    auto request = [&](int on) {
-        const int orow = on < r1 ? on : r0;
+    // a row's operands from memory; two sets used in turn (the loop is unrolled by two passes), so that the set a
+    // pass computes on is not copied out of the set the next pass's loads land in
+    struct Pre { IDX_T blk[NS]; Vec8<VAL_T> vv[NS]; float vb[NB]; float scale; };
+    Pre pa, pb;
+    pa.scale = pb.scale = 1.0f;
+    const unsigned vt_off = (unsigned) ((t0 + (my_t < nt ? my_t : 0)) * p.v_ld);       // host: the buffers here are < 4 GiB
+    auto at = [](auto * base, unsigned i) {            // uniform base + 32-bit offset: no 64-bit vector address arithmetic
+        using T = std::remove_pointer_t<decltype(base)>;
+        return reinterpret_cast<T *>(reinterpret_cast<const char *>(base) + (size_t) (i * (unsigned) sizeof(T)));
+    };
+    auto request = [&](Pre & d, int on) {
+        const unsigned orow = (unsigned) (on < r1 ? on : r0);
 #pragma unroll
-        for (int u = 0; u < NS; ++u) blk_n[u] = idx[(size_t) orow * p.nb + bi[u]];
+        for (int u = 0; u < NS; ++u) d.blk[u] = *at(idx, orow * (unsigned) p.nb + (unsigned) bi[u]);
 #pragma unroll
-        for (int u = 0; u < NS; ++u) vv_n[u].load(val + (size_t) orow * p.Ktot + e0[u]);
+        for (int u = 0; u < NS; ++u) d.vv[u].load(at(val, orow * (unsigned) p.Ktot + (unsigned) e0[u]));
         if (lead) {
-            if (p.rs) scale_n = p.rs[orow];
+            if (p.rs) d.scale = *at(p.rs, orow);
 #pragma unroll
-            for (int b = 0; b < NB; ++b) vb_n[b] = (b < nbase) ? vt[(size_t) b * p.L + orow] : 0.0f;
+            for (int b = 0; b < NB; ++b) d.vb[b] = (b < nbase) ? *at(p.v, vt_off + (unsigned) b * (unsigned) p.L + orow) : 0.0f;
         }
     };
     const int stride = 16 * rows_wave;                  // rows per pass of the workgroup
     int o = r0 + wave * rows_wave + lane / G;
-    request(o);                                          // the first rows' payload travels while the tile is filled
+    request(pa, o);                                      // the first rows' payload travels while the tile is filled
     for (int c = tid; c < nch; c += 1024) {              // all tokens of a chunk per trip: 2 NT 16-byte loads in flight
         float4 va[NT], vb2[NT];
 #pragma unroll
@@ -160,25 +167,18 @@ void delta_rows_block_lds_kernel(const DeltaParams p, const int64_t T, const int
         }
     }
     __syncthreads();
-    const int passes = (r1 - r0 + stride - 1) / stride;  // uniform over the workgroup
-    for (int it = 0; it < passes; ++it, o += stride) {
+    auto pass = [&](const Pre & cur, Pre & nxt, int o) {
         const bool row_ok = o < r1;
         int c0[NS];
         bool ok[NS];
-        Vec8<VAL_T> vv[NS];
-        float vb[NB];
-        const float scale = scale_n;
 #pragma unroll
         for (int u = 0; u < NS; ++u) {
-            const int blk = idx_to_i32<IDX_T>(blk_n[u]);
+            const int blk = idx_to_i32<IDX_T>(cur.blk[u]);
             const int raw = (blk << p.block_shift) + off[u];
             ok[u] = row_ok & eok[u] & ((unsigned) blk < (unsigned) p.n_blk_in) & (raw < p.n_in);
             c0[u] = (ok[u] ? raw : 0) >> 3;
-            vv[u] = vv_n[u];
         }
-#pragma unroll
-        for (int b = 0; b < NB; ++b) vb[b] = vb_n[b];
-        request(o + stride);
+        request(nxt, o + stride);
         float acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -190,22 +190,28 @@ void delta_rows_block_lds_kernel(const DeltaParams p, const int64_t T, const int
             }
             acc[t] = 0.0f;
 #pragma unroll
-            for (int u = 0; u < NS; ++u) acc[t] = add_if(acc[t], ok[u], dot8<VAL_T>(vv[u], xa[u], xb[u]));
+            for (int u = 0; u < NS; ++u) acc[t] = add_if(acc[t], ok[u], dot8<VAL_T>(cur.vv[u], xa[u], xb[u]));
             if (NT > 2 && (t & 1) && t + 1 < NT) __builtin_amdgcn_sched_barrier(0);    // two tokens' reads in flight
         }
         const float a = transpose_reduce<NT, GC>(acc, G, lane);
         if (row_ok && lead) {
             float yh = 0.0f;
             if (p.v) {
-                if (p.tall) yh = vb[0];
+                if (p.tall) yh = cur.vb[0];
                 else {
 #pragma unroll
-                    for (int b = 0; b < NB; ++b) if (b < nbase) yh += vb[b];
-                    for (int b = NB; b < nbase; ++b) yh += vt[(size_t) b * p.L + o];
+                    for (int b = 0; b < NB; ++b) if (b < nbase) yh += cur.vb[b];
+                    for (int b = NB; b < nbase; ++b) yh += *at(p.v, vt_off + (unsigned) b * (unsigned) p.L + (unsigned) o);
                 }
             }
-            store_output(p, o, t0 + my_t, yh + a, scale);
+            store_output(p, o, t0 + my_t, yh + a, cur.scale);
         }
+    };
+    const int passes = (r1 - r0 + stride - 1) / stride;  // uniform over the workgroup
+    for (int it = 0; it < passes; it += 2) {
+        pass(pa, pb, o);
+        o += stride;
+        if (it + 1 < passes) { pass(pb, pa, o); o += stride; }
     }
 }
 
@@ -469,7 +475,9 @@ static int launch_typed(const DeltaLaunch & a, DeltaParams & p, hipStream_t s) {
         const size_t budget = 152 * 1024;
         const int max_steps = sizeof(VAL_T) == 4 ? 3 : 4;          // fp32 values at four steps would spill (128 registers per lane)
         const int64_t min_t = G == 64 ? lds_min_t : 5;
-        if (vec_ok && a.T >= min_t && G >= 8 && steps >= 1 && steps <= max_steps && !no_lds && col * 2 <= budget) {
+        const bool off32 = (size_t) p.n_out * (size_t) p.Ktot * sizeof(VAL_T) < ((size_t) 1 << 32) && (size_t) p.n_out * (size_t) p.nb * sizeof(IDX_T) < ((size_t) 1 << 32) &&
+                           (!p.v || ((size_t) a.T * (size_t) p.v_ld + (size_t) p.B * (size_t) p.L) * 4 < ((size_t) 1 << 32));
+        if (vec_ok && a.T >= min_t && G >= 8 && steps >= 1 && steps <= max_steps && !no_lds && col * 2 <= budget && off32) {
             int nt = (col * 8 <= budget && steps == 1) ? 8 : (col * 4 <= budget && steps <= 2) ? 4 : 2;     // register budget
             while (nt > 2 && (nt > G || nt / 2 >= a.T)) nt >>= 1;  // no wider than the batch needs
             const int64_t tiles = (a.T + nt - 1) / nt;
