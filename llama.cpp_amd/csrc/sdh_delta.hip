@@ -273,6 +273,10 @@ void delta_rows_coo_lds_kernel(const DeltaParams p, const int64_t T, const int r
             for (int b = 0; b < NB; ++b) vb_n[b] = (b < nbase) ? vt[(size_t) b * p.L + orow] : 0.0f;
         }
     };
+    // eight tokens are two 16-byte reads per entry: odd lanes take the halves in the other order, so that one read
+    // instruction touches both halves of the 32-byte rows — all sixteen 16-byte bank slots instead of the eight of one
+    // parity (the sums of the odd lanes sit in swapped slots until just before the reduction)
+    const int half_sw = NT == 8 ? (lane & 1) : 0;
     const int stride = 16 * rows_wave;                  // rows per pass of the workgroup
     int o = r0 + wave * rows_wave + lane / G;
     request(o);                                          // the first rows' payload travels while the tile is filled
@@ -306,7 +310,7 @@ void delta_rows_coo_lds_kernel(const DeltaParams p, const int64_t T, const int r
                     okj[j] = oku & ((unsigned) i < (unsigned) p.n_in);
                     const gvec * row = reinterpret_cast<const gvec *>(xs + (size_t) tile_row<false>(p, okj[j] ? i : 0, n4) * NT);
 #pragma unroll
-                    for (int q = 0; q < NT / GRP; ++q) xv[j][q] = row[q];
+                    for (int q = 0; q < NT / GRP; ++q) xv[j][q] = row[q ^ half_sw];
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -314,6 +318,13 @@ void delta_rows_coo_lds_kernel(const DeltaParams p, const int64_t T, const int r
 #pragma unroll
                     for (int t = 0; t < NT; ++t) acc[t] = add_if(acc[t], okj[j], __fmul_rn(v, xv[j][t / GRP][t % GRP]));
                 }
+            }
+        }
+        if constexpr (NT == 8) {                         // odd lanes accumulated tokens 4..7 in slots 0..3: put them back
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float lo = half_sw ? acc[t + 4] : acc[t], hi = half_sw ? acc[t] : acc[t + 4];
+                acc[t] = lo; acc[t + 4] = hi;
             }
         }
         const float a = transpose_reduce<NT>(acc, G, lane);
