@@ -456,7 +456,10 @@ def run_prefill(args, dev):
         y = torch.empty((T, n_out), dtype=torch.float32, device=dev)
         torch.cuda.synchronize()
         leg = {"algorithmic_bytes": alg, "tokens": T}
-        for tag, flags in (("default", 0), ("w0_mfma", seeddelta.FWD_W0_MFMA)):
+        # rows_lds: SDH_FWD_NO_SPMM, the residual through the LDS rows kernels (the fast path's arithmetic: within the
+        # tolerance of tests/test_gpu_forward.py, each token bit-identical to its one-token result) instead of the tiled
+        # SpMM, whose rows are bit-identical to the CPU op; the gated FFN entry points use it for COO payloads
+        for tag, flags in (("default", 0), ("w0_mfma", seeddelta.FWD_W0_MFMA), ("rows_lds", seeddelta.FWD_NO_SPMM)):
             fn = lambda: w.forward_device(x.data_ptr(), n_in, T, y.data_ptr(), n_out, flags=flags, stream=sp)   # noqa: E731
             ev_ms, host_ms = timed_on_stream(fn, args.prefill_reps, st, seeddelta, warm=3)
             ms = ev_ms / args.prefill_reps

@@ -636,7 +636,10 @@ static int sdh_forward_impl(sdh_weight * h, const float * x, int64_t ldx, int64_
         // the choice follows the CALL's token count, not the chunk's: a short last chunk must not switch a call to
         // the per-token kernels (same values within tolerance, but not the same bits as its other chunks)
         static const int64_t rows_max_t = [] { const char * e = getenv("SDH_FFN_ROWS_MAX_T"); return e ? (int64_t) atoll(e) : (int64_t) 32; }();
-        const bool prefer_rows = (flags & SDH_FWD_INTERNAL_ROWS) && n_tokens <= rows_max_t;
+        // COO: the LDS rows kernel beats the tiled path at every token count measured (Mistral layer, us: T=64 78 against 86,
+        // T=256 247 / 290, T=512 482 / 548, T=1024 864 / 953); block payloads: up to 32 tokens (T=40 69 against 63)
+        const bool coo_kind = w->kind == SDH_OP_COO || w->kind == SDH_OP_BASE_COO;
+        const bool prefer_rows = (flags & SDH_FWD_INTERNAL_ROWS) && (coo_kind || n_tokens <= rows_max_t);
         if (n_tokens >= spmm_min_t && !a.exact_order && !(flags & SDH_FWD_NO_SPMM) && !prefer_rows) rc = launch_delta_spmm(*w, a, s);
         if (rc == 1) rc = launch_delta(*w, a, s);
         if (rc != SDH_OK) return rc;
@@ -741,7 +744,7 @@ static int ffn_gate_up(sdh_weight * hg, sdh_weight * hu, int act, const float * 
     // few tokens: the base terms of both tensors from ONE launch (2B blocks per token) into the tensors' workspaces
     const size_t per_tok = (size_t) g->B * (size_t) g->L * 4;
     const auto with_base = [](const DeviceWeight * w) { return w->kind == SDH_OP_BASE_COO || w->kind == SDH_OP_BASE_BLOCK; };
-    if (T > MAX_FUSED_TOKENS && T <= 64 && g != u && with_base(g) && with_base(u) && g->tall && u->tall &&
+    if (T > MAX_FUSED_TOKENS && T <= 1024 && g != u && with_base(g) && with_base(u) && g->tall && u->tall &&
         !(flags & (SDH_FWD_EXACT_ORDER | SDH_FWD_W0_MFMA)) && per_tok * (size_t) T <= ((size_t) 64 << 20)) {
         if ((rc = ensure_ws(g, per_tok * (size_t) T)) != SDH_OK) return rc;
         if ((rc = ensure_ws(u, per_tok * (size_t) T)) != SDH_OK) return rc;
@@ -821,10 +824,11 @@ static int sdh_ffn_forward_impl(sdh_weight * hg, sdh_weight * hu, sdh_weight * h
         dx = ws[0]; dldx = n_embd; dy = ws[1]; dldy = d->n_out;
     }
     const int sub = (flags & ~SDH_FWD_HOST_IO) | (n_tokens > MAX_FUSED_TOKENS ? SDH_FWD_INTERNAL_ROWS : 0);
-    // 5..32 tokens: node by node, the residual through the LDS rows kernels (SDH_FWD_INTERNAL_ROWS) and the base terms of
-    // gate and up from one launch. Mistral layer, us, COO / block16: T=8 36 / 33 (56 / 58 through the tiled SpMM path, 49 /
-    // 37 as two groups of four tokens through the single-launch forms — tried, dropped), T=16 45 / 40 (59 / 59), T=32 62 /
-    // 55 (77 / 69); from ~48 tokens on the tiled path wins. A token's result is its one-token result.
+    // 5 tokens and more: node by node, the residual through the LDS rows kernels (SDH_FWD_INTERNAL_ROWS: COO payloads at
+    // every token count, block payloads up to 32 tokens) and, up to 64 tokens, the base terms of gate and up from one
+    // launch. Mistral layer, us, COO / block16: T=8 31 / 30 (56 / 58 through the tiled SpMM path, 49 / 37 as two groups of
+    // four tokens through the single-launch forms — tried, dropped), T=16 38 / 38 (59 / 59), T=32 52 / 53 (77 / 69), T=512
+    // 482 / 401 (548 COO tiled). On the rows kernels a token's result is its one-token result.
     if ((rc = ffn_gate_up(hg, hu, act, dx, dldx, n_tokens, ws[2], ws[3], ws[4], sub, s)) != SDH_OK) return rc;
     if ((rc = sdh_forward(hd, ws[2], n_ff, n_tokens, dy, dldy, sub, s)) != SDH_OK) return rc;
     if (host_io) return device_to_host_sync(ls, y, ldy, dy, d->n_out, n_tokens, s);
