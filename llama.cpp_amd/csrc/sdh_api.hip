@@ -639,7 +639,10 @@ static int sdh_forward_impl(sdh_weight * h, const float * x, int64_t ldx, int64_
         // COO: the LDS rows kernel beats the tiled path at every token count measured (Mistral layer, us: T=64 78 against 86,
         // T=256 247 / 290, T=512 482 / 548, T=1024 864 / 953); block payloads: up to 32 tokens (T=40 69 against 63)
         const bool coo_kind = w->kind == SDH_OP_COO || w->kind == SDH_OP_BASE_COO;
-        const bool prefer_rows = (flags & SDH_FWD_INTERNAL_ROWS) && (coo_kind || n_tokens <= rows_max_t);
+        // block payloads whose input is so long that only two tokens fit the LDS (Mistral down): the rows kernel as well
+        // (T=512 ubatch: 0.086 against 0.126 ms tiled), where the eight-token tile of gate / up favours the tiled path
+        const bool two_token_tile = (size_t) w->n_in * 16 > (size_t) 152 * 1024;
+        const bool prefer_rows = (flags & SDH_FWD_INTERNAL_ROWS) && (coo_kind || two_token_tile || n_tokens <= rows_max_t);
         if (n_tokens >= spmm_min_t && !a.exact_order && !(flags & SDH_FWD_NO_SPMM) && !prefer_rows) rc = launch_delta_spmm(*w, a, s);
         if (rc == 1) rc = launch_delta(*w, a, s);
         if (rc != SDH_OK) return rc;
