@@ -282,6 +282,43 @@ def test_ffn_block_under_graph_capture(hip, act):
     assert wg.nonfinite_count() == 0 and wu.nonfinite_count() == 0 and wd.nonfinite_count() == 0
 
 
+@pytest.mark.parametrize("scheme", ["block", "coo"])
+def test_ffn_small_batch_block_under_graph_capture(hip, scheme):
+    """Three tokens per call: the several-token gate|up launch (COO: x staged in LDS) and the fused several-token down
+    launch recorded into a HIP graph and replayed with changing inputs, an eager call on the same handles in between;
+    the captured launches clear the granules they read, so every replay equals the eager result bit for bit."""
+    kw = dict(scheme=scheme, K=64, block=16, base=True, d13_random=True)
+    gate, up = make_payload(2048, 5632, seed=51, **kw), make_payload(2048, 5632, seed=52, **kw)
+    down = make_payload(5632, 2048, seed=53, **kw)
+    wg, wu, wd = hip.SeedDeltaWeight(gate), hip.SeedDeltaWeight(up), hip.SeedDeltaWeight(down)
+    xs = make_x(2048, 12, seed=14)
+    want = [hip.ffn_forward_host(wg, wu, wd, xs[3 * i:3 * i + 3], O.ACT_SILU) for i in range(4)]
+    assert hip.ffn_last_fused()
+    xd = torch.zeros((3, 2048), dtype=torch.float32, device="cuda")
+    yd = torch.zeros((3, 2048), dtype=torch.float32, device="cuda")
+    ye = torch.zeros((3, 2048), dtype=torch.float32, device="cuda")
+    xe = torch.from_numpy(xs[9:12]).cuda()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        hip.ffn_forward_device(wg, wu, wd, O.ACT_SILU, xd.data_ptr(), 2048, 3, yd.data_ptr(), 2048, 0, side.cuda_stream)
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            hip.ffn_forward_device(wg, wu, wd, O.ACT_SILU, xd.data_ptr(), 2048, 3, yd.data_ptr(), 2048, 0,
+                                   torch.cuda.current_stream().cuda_stream)
+            assert hip.ffn_last_fused()
+        for i in range(3):
+            xd.copy_(torch.from_numpy(xs[3 * i:3 * i + 3]))
+            g.replay()
+            g.replay()
+            if i == 1:
+                hip.ffn_forward_device(wg, wu, wd, O.ACT_SILU, xe.data_ptr(), 2048, 3, ye.data_ptr(), 2048, 0, side.cuda_stream)
+            side.synchronize()
+            assert np.array_equal(bits(yd.cpu().numpy()), bits(want[i])), f"replay {i}"
+        assert np.array_equal(bits(ye.cpu().numpy()), bits(want[3]))
+    assert wg.nonfinite_count() == 0 and wu.nonfinite_count() == 0 and wd.nonfinite_count() == 0
+
+
 def test_glu_kernel_vs_oracle(hip):
     rng = np.random.default_rng(8)
     n = 100003
