@@ -754,6 +754,27 @@ static int ffn_gate_up(sdh_weight * hg, sdh_weight * hu, int act, const float * 
         rc = launch_base_apply_pair(*g, *u, dx, dldx, T, g->ws, u->ws, s);
         if (rc < 0) return rc;
         if (rc == SDH_OK) g->base_ready = u->base_ready = true;
+        // ... and, for COO payloads, the rows of both tensors from one launch over one tile of x, writing h directly
+        if (rc == SDH_OK && !(flags & (SDH_FWD_NO_FUSE | SDH_FWD_NO_SPMM))) {
+            int sg = 0, su = 0;
+            if ((rc = nf_slot(g, s, &sg)) != SDH_OK) return rc;
+            if ((rc = nf_slot(u, s, &su)) != SDH_OK) return rc;
+            DeltaLaunch ag{};
+            ag.x = dx; ag.ldx = dldx; ag.T = T; ag.y = hbuf; ag.ldy = n_ff;
+            ag.zero_nonfinite = (flags & SDH_FWD_ZERO_NONFINITE) != 0;
+            DeltaLaunch au = ag;
+            ag.v = g->ws; ag.nf_counter = g->nf_ring + sg;
+            au.v = u->ws; au.nf_counter = u->nf_ring + su;
+            rc = launch_delta_rows_pair(*g, *u, ag, au, act, ls.gelu_tab, hbuf, n_ff, s);
+            if (rc < 0) { g->base_ready = u->base_ready = false; return rc; }
+            if (rc == SDH_OK) {
+                g->base_ready = u->base_ready = false;
+                g->seq++; u->seq++;
+                g->last_stream = u->last_stream = s;
+                ls.span_forwards += 2;
+                return SDH_OK;
+            }
+        }
     }
     rc = sdh_forward(hg, dx, dldx, T, gbuf, n_ff, flags, s);
     g->base_ready = false;

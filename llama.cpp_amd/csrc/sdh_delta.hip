@@ -22,6 +22,7 @@
 //   delta_exact_kernel       — verification mode: one lane per output, the reference's sequential
 //                              order with separately rounded multiply and add; bit-identical.
 #include "sdh_internal.h"
+#include <algorithm>
 #include <type_traits>
 #include "sdh_delta_dev.h"
 
@@ -343,6 +344,131 @@ void delta_rows_coo_lds_kernel(const DeltaParams p, const int64_t T, const int r
     }
 }
 
+// Gate and up of a gated FFN (COO, tall, one shape, I16 / F16) in ONE rows launch: the tile of x is filled once and
+// serves both tensors, a wave forms row o of the gate, then row o of up, and the leader lanes write
+// h[t][o] = act(gate) * up — delta_rows_coo_lds_kernel twice plus store_output's activation epilogue, minus one tile
+// fill, one launch boundary and the gate buffer. Same arithmetic per (tensor, row, token), each node's own non-finite
+// guard before the activation.
+template <int STEPS, int NT>
+__global__ __launch_bounds__(1024)
+void delta_rows_coo_lds_pair_kernel(const DeltaParams pg, const DeltaParams pu, const int64_t T, const int rows_per_wg,
+                                    const int act, const uint16_t * __restrict__ tab, float * __restrict__ h, const int64_t ldh) {
+    extern __shared__ float xs[];                       // [4 * n4][NT]
+    static_assert(NT == 2 || NT == 4 || NT == 8, "tokens per tile");
+    constexpr int NS = STEPS;
+    constexpr int GRP = NT >= 4 ? 4 : 2;
+    typedef float gvec __attribute__((ext_vector_type(GRP)));
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int G = pg.G;                                 // host: one row shape for both tensors, G >= 8, G >= NT
+    const int l = lane & (G - 1);
+    const int rows_wave = 64 / G;
+    const int n4 = (pg.n_in + 3) >> 2;
+    const int64_t t0 = (int64_t) blockIdx.x * NT;
+    const int nt = (int) ((T - t0 < NT) ? (T - t0) : NT);
+    const int r0 = (int) blockIdx.y * rows_per_wg;
+    const int r1 = min(pg.n_out, r0 + rows_per_wg);
+    int e0[NS];
+    bool eok[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        const int e = (u * G + l) * 8;
+        eok[u] = e < pg.Ktot;
+        e0[u] = eok[u] ? e : 0;
+    }
+    const int my_t = reduce_token_of_lane<NT>(G, l);
+    const bool lead = reduce_is_leader<NT>(G, l) && my_t < nt;
+    const unsigned tok = (unsigned) (t0 + (my_t < nt ? my_t : 0));
+    struct Pre { Vec8<uint16_t> ig[NS], vg[NS], iu[NS], vu[NS]; float bg, bu, sg, su; };
+    Pre pa, pb;
+    pa.sg = pa.su = pb.sg = pb.su = 1.0f;
+    pa.bg = pa.bu = pb.bg = pb.bu = 0.0f;
+    auto at = [](auto * base, unsigned i) {
+        using E = std::remove_pointer_t<decltype(base)>;
+        return reinterpret_cast<E *>(reinterpret_cast<const char *>(base) + (size_t) (i * (unsigned) sizeof(E)));
+    };
+    const uint16_t * gi = reinterpret_cast<const uint16_t *>(pg.idx), * gv = reinterpret_cast<const uint16_t *>(pg.val);
+    const uint16_t * ui = reinterpret_cast<const uint16_t *>(pu.idx), * uv = reinterpret_cast<const uint16_t *>(pu.val);
+    auto request = [&](Pre & d, int on) {
+        const unsigned orow = (unsigned) (on < r1 ? on : r0);
+        const unsigned ro = orow * (unsigned) pg.Ktot;
+#pragma unroll
+        for (int u = 0; u < NS; ++u) d.ig[u].load(at(gi, ro + (unsigned) e0[u]));
+#pragma unroll
+        for (int u = 0; u < NS; ++u) d.vg[u].load(at(gv, ro + (unsigned) e0[u]));
+#pragma unroll
+        for (int u = 0; u < NS; ++u) d.iu[u].load(at(ui, ro + (unsigned) e0[u]));
+#pragma unroll
+        for (int u = 0; u < NS; ++u) d.vu[u].load(at(uv, ro + (unsigned) e0[u]));
+        if (lead) {                                      // tall: the base term of (token, row o) is element o of the token's block array
+            if (pg.rs) d.sg = *at(pg.rs, orow);
+            if (pu.rs) d.su = *at(pu.rs, orow);
+            d.bg = *at(pg.v, tok * (unsigned) pg.v_ld + orow);
+            d.bu = *at(pu.v, tok * (unsigned) pu.v_ld + orow);
+        }
+    };
+    const int half_sw = NT == 8 ? (lane & 1) : 0;       // see delta_rows_coo_lds_kernel
+    const int stride = 16 * rows_wave;
+    int o = r0 + wave * rows_wave + lane / G;
+    request(pa, o);
+    spmm_fill_tile<false, NT, GRP, 1024>(pg, xs, t0, nt, n4, tid);
+    __syncthreads();
+    auto row_sum = [&](const Vec8<uint16_t> (&ii)[NS], const Vec8<uint16_t> (&vv)[NS], bool row_ok) -> float {
+        float acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = 0.0f;
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const bool oku = row_ok & eok[u];
+#pragma unroll
+            for (int hh = 0; hh < 8; hh += 4) {
+                gvec xv[4][NT / GRP];
+                bool okj[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = idx_to_i32<uint16_t>(ii[u].get(hh + j));
+                    okj[j] = oku & ((unsigned) i < (unsigned) pg.n_in);
+                    const gvec * row = reinterpret_cast<const gvec *>(xs + (size_t) tile_row<false>(pg, okj[j] ? i : 0, n4) * NT);
+#pragma unroll
+                    for (int q = 0; q < NT / GRP; ++q) xv[j][q] = row[q ^ half_sw];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = val_to_f32<uint16_t>(vv[u].get(hh + j));
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = add_if(acc[t], okj[j], __fmul_rn(v, xv[j][t / GRP][t % GRP]));
+                }
+            }
+        }
+        if constexpr (NT == 8) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float lo = half_sw ? acc[t + 4] : acc[t], hi = half_sw ? acc[t] : acc[t + 4];
+                acc[t] = lo; acc[t + 4] = hi;
+            }
+        }
+        return transpose_reduce<NT>(acc, G, lane);
+    };
+    auto pass = [&](const Pre & cur, Pre & nxt, int o) {
+        const bool row_ok = o < r1;
+        request(nxt, o + stride);
+        const float ag = row_sum(cur.ig, cur.vg, row_ok);
+        const float au = row_sum(cur.iu, cur.vu, row_ok);
+        if (row_ok && lead) {
+            const float yg = finish_output(pg, cur.bg + ag, cur.sg);
+            const float yu = finish_output(pu, cur.bu + au, cur.su);
+            h[(size_t) (t0 + my_t) * (size_t) ldh + o] = glu_value(act, yg, yu, tab);
+        }
+    };
+    const int passes = (r1 - r0 + stride - 1) / stride;
+    for (int it = 0; it < passes; it += 2) {
+        pass(pa, pb, o);
+        o += stride;
+        if (it + 1 < passes) { pass(pb, pa, o); o += stride; }
+    }
+}
+
 template <typename IDX_T, typename VAL_T, bool BLOCK>
 __global__ __launch_bounds__(256)
 void delta_rows_scalar_kernel(const DeltaParams p) {
@@ -575,6 +701,44 @@ int launch_delta(const DeviceWeight & w, const DeltaLaunch & a, hipStream_t s) {
     if (i16 && !f16) return launch_typed<uint16_t, uint32_t, false>(a, p, s);
     if (!i16 && f16) return launch_typed<uint32_t, uint16_t, false>(a, p, s);
     return launch_typed<uint32_t, uint32_t, false>(a, p, s);
+}
+
+// Gate and up rows of a gated FFN in one launch (delta_rows_coo_lds_pair_kernel). ag / au: the two nodes' launches with
+// their base terms in v (tall). Returns SDH_OK if launched, 1 if the pair does not fit this form.
+int launch_delta_rows_pair(const DeviceWeight & g, const DeviceWeight & u, const DeltaLaunch & ag, const DeltaLaunch & au,
+                           int act, const uint16_t * gelu_tab, float * h, int64_t ldh, hipStream_t s) {
+    static const bool off = [] { const char * e = getenv("SDH_ROWS_PAIR"); return e && atoi(e) == 0; }();          // dev: A/B
+    if (off || ag.T < 5 || ag.exact_order) return 1;
+    if (g.kind != SDH_OP_BASE_COO || u.kind != SDH_OP_BASE_COO || !g.tall || !u.tall) return 1;
+    if (g.idx_type != SDH_TYPE_I16 || g.val_type != SDH_TYPE_F16 || u.idx_type != SDH_TYPE_I16 || u.val_type != SDH_TYPE_F16) return 1;
+    if (g.n_in != u.n_in || g.n_out != u.n_out || !ag.v || !au.v || ag.x != au.x || ag.ldx != au.ldx) return 1;
+    DeltaParams pg = make_delta_params(g, ag), pu = make_delta_params(u, au);
+    if (pg.Ktot != pu.Ktot) return 1;
+    int G = 1, steps = 0;
+    if (!delta_vector_shape(pg, false, &G, &steps) || steps != 1 || G < 8) return 1;
+    pg.G = pu.G = G;
+    const size_t col = (size_t) ((pg.n_in + 3) / 4) * 4 * sizeof(float);
+    const size_t budget = 152 * 1024;
+    if (col * 2 > budget) return 1;
+    if ((size_t) pg.n_out * (size_t) pg.Ktot * 2 >= ((size_t) 1 << 32) ||
+        ((size_t) ag.T * (size_t) std::max(pg.v_ld, pu.v_ld) + (size_t) pg.n_out) * 4 >= ((size_t) 1 << 32)) return 1;    // 32-bit offsets
+    int nt = col * 8 <= budget ? 8 : col * 4 <= budget ? 4 : 2;
+    while (nt > 2 && (nt > G || nt / 2 >= ag.T)) nt >>= 1;
+    const int64_t tiles = (ag.T + nt - 1) / nt;
+    const int rows_pass = 16 * (64 / G);
+    int64_t chunks = (int64_t) lib().num_cu / tiles;
+    const int64_t max_chunks = (pg.n_out + rows_pass - 1) / rows_pass;
+    if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks < 1) chunks = 1;
+    int rows_per_wg = (int) ((pg.n_out + chunks - 1) / chunks);
+    rows_per_wg = (rows_per_wg + rows_pass - 1) / rows_pass * rows_pass;
+    const unsigned gl = (unsigned) ((pg.n_out + rows_per_wg - 1) / rows_per_wg);
+    void (*kern)(const DeltaParams, const DeltaParams, int64_t, int, int, const uint16_t *, float *, int64_t) =
+        nt == 8 ? delta_rows_coo_lds_pair_kernel<1, 8> : nt == 4 ? delta_rows_coo_lds_pair_kernel<1, 4> : delta_rows_coo_lds_pair_kernel<1, 2>;
+    SDH_HIP_CHECK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(kern, dim3((unsigned) tiles, gl), dim3(1024), col * nt, s, pg, pu, ag.T, rows_per_wg, act, gelu_tab, h, ldh);
+    SDH_HIP_CHECK(hipGetLastError());
+    return SDH_OK;
 }
 
 } // namespace sdh

@@ -161,6 +161,8 @@ int launch_decode_fused(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s);
 int launch_decode_pair(DeviceWeight & g, DeviceWeight & u, int act, const uint16_t * gelu_tab,
                        const float * x, int64_t ldx, int n_tok, float * h, int64_t ldh,
                        int * nf_g, int * nf_u, bool zero_nonfinite, hipStream_t s);
+int launch_delta_rows_pair(const DeviceWeight & g, const DeviceWeight & u, const DeltaLaunch & ag, const DeltaLaunch & au,
+                           int act, const uint16_t * gelu_tab, float * h, int64_t ldh, hipStream_t s);
 int launch_glu(int act, const uint16_t * gelu_tab, const float * g, const float * u, float * y, int64_t n, hipStream_t s);
 
 // Persistent FFN stack (sdh_stack.hip): n_layers gated FFN blocks at T = 1 in one launch.
