@@ -469,6 +469,106 @@ void delta_rows_coo_lds_pair_kernel(const DeltaParams pg, const DeltaParams pu, 
     }
 }
 
+// The block-payload form of the gate | up rows launch (delta_rows_block_lds_kernel's tile and row walk, rows of one
+// step per lane): one fill of the two planes per token serves both tensors.
+template <int NT>
+__global__ __launch_bounds__(1024)
+void delta_rows_block_lds_pair_kernel(const DeltaParams pg, const DeltaParams pu, const int64_t T, const int rows_per_wg,
+                                      const int act, const uint16_t * __restrict__ tab, float * __restrict__ h, const int64_t ldh) {
+    extern __shared__ float4 xs4[];                     // [NT][2][n_in / 8]
+    static_assert(NT == 2 || NT == 4 || NT == 8, "tokens per tile");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int G = pg.G;                                 // host: one row shape for both tensors, 8 <= G, NT <= G, one step
+    const int l = lane & (G - 1);
+    const int rows_wave = 64 / G;
+    const int nch = pg.n_in >> 3;
+    const int64_t t0 = (int64_t) blockIdx.x * NT;
+    const int nt = (int) ((T - t0 < NT) ? (T - t0) : NT);
+    const int r0 = (int) blockIdx.y * rows_per_wg;
+    const int r1 = min(pg.n_out, r0 + rows_per_wg);
+    const int e = l * 8;
+    const bool eok = e < pg.Ktot;
+    const int e0 = eok ? e : 0;
+    const int bi = e0 >> pg.block_shift, off = e0 & (pg.block - 1);
+    const int my_t = reduce_token_of_lane<NT>(G, l);
+    const bool lead = reduce_is_leader<NT>(G, l) && my_t < nt;
+    const unsigned tok = (unsigned) (t0 + (my_t < nt ? my_t : 0));
+    struct Pre { uint16_t kg, ku; Vec8<uint16_t> vg, vu; float bg, bu, sg, su; };
+    Pre pa, pb;
+    pa.sg = pa.su = pb.sg = pb.su = 1.0f;
+    pa.bg = pa.bu = pb.bg = pb.bu = 0.0f;
+    auto at = [](auto * base, unsigned i) {
+        using E = std::remove_pointer_t<decltype(base)>;
+        return reinterpret_cast<E *>(reinterpret_cast<const char *>(base) + (size_t) (i * (unsigned) sizeof(E)));
+    };
+    const uint16_t * gi = reinterpret_cast<const uint16_t *>(pg.idx), * gv = reinterpret_cast<const uint16_t *>(pg.val);
+    const uint16_t * ui = reinterpret_cast<const uint16_t *>(pu.idx), * uv = reinterpret_cast<const uint16_t *>(pu.val);
+    auto request = [&](Pre & d, int on) {
+        const unsigned orow = (unsigned) (on < r1 ? on : r0);
+        d.kg = *at(gi, orow * (unsigned) pg.nb + (unsigned) bi);
+        d.ku = *at(ui, orow * (unsigned) pu.nb + (unsigned) bi);
+        d.vg.load(at(gv, orow * (unsigned) pg.Ktot + (unsigned) e0));
+        d.vu.load(at(uv, orow * (unsigned) pu.Ktot + (unsigned) e0));
+        if (lead) {
+            if (pg.rs) d.sg = *at(pg.rs, orow);
+            if (pu.rs) d.su = *at(pu.rs, orow);
+            d.bg = *at(pg.v, tok * (unsigned) pg.v_ld + orow);
+            d.bu = *at(pu.v, tok * (unsigned) pu.v_ld + orow);
+        }
+    };
+    const int stride = 16 * rows_wave;
+    int o = r0 + wave * rows_wave + lane / G;
+    request(pa, o);
+    for (int c = tid; c < nch; c += 1024) {
+        float4 va[NT], vb2[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float * xt = pg.x + (t0 + (t < nt ? t : nt - 1)) * pg.ldx;
+            va[t] = *reinterpret_cast<const float4 *>(xt + c * 8);
+            vb2[t] = *reinterpret_cast<const float4 *>(xt + c * 8 + 4);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            xs4[(t * 2 + 0) * nch + c] = va[t];
+            xs4[(t * 2 + 1) * nch + c] = vb2[t];
+        }
+    }
+    __syncthreads();
+    auto row_sum = [&](uint16_t k, const Vec8<uint16_t> & vv, bool row_ok) -> float {
+        const int blk = idx_to_i32<uint16_t>(k);
+        const int raw = (blk << pg.block_shift) + off;
+        const bool ok = row_ok & eok & ((unsigned) blk < (unsigned) pg.n_blk_in) & (raw < pg.n_in);
+        const int c0 = (ok ? raw : 0) >> 3;
+        float acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float4 xa = xs4[(t * 2 + 0) * nch + c0];
+            const float4 xb = xs4[(t * 2 + 1) * nch + c0];
+            acc[t] = add_if(0.0f, ok, dot8<uint16_t>(vv, xa, xb));
+        }
+        return transpose_reduce<NT>(acc, G, lane);
+    };
+    auto pass = [&](const Pre & cur, Pre & nxt, int o) {
+        const bool row_ok = o < r1;
+        request(nxt, o + stride);
+        const float ag = row_sum(cur.kg, cur.vg, row_ok);
+        const float au = row_sum(cur.ku, cur.vu, row_ok);
+        if (row_ok && lead) {
+            const float yg = finish_output(pg, cur.bg + ag, cur.sg);
+            const float yu = finish_output(pu, cur.bu + au, cur.su);
+            h[(size_t) (t0 + my_t) * (size_t) ldh + o] = glu_value(act, yg, yu, tab);
+        }
+    };
+    const int passes = (r1 - r0 + stride - 1) / stride;
+    for (int it = 0; it < passes; it += 2) {
+        pass(pa, pb, o);
+        o += stride;
+        if (it + 1 < passes) { pass(pb, pa, o); o += stride; }
+    }
+}
+
 template <typename IDX_T, typename VAL_T, bool BLOCK>
 __global__ __launch_bounds__(256)
 void delta_rows_scalar_kernel(const DeltaParams p) {
@@ -709,17 +809,21 @@ int launch_delta_rows_pair(const DeviceWeight & g, const DeviceWeight & u, const
                            int act, const uint16_t * gelu_tab, float * h, int64_t ldh, hipStream_t s) {
     static const bool off = [] { const char * e = getenv("SDH_ROWS_PAIR"); return e && atoi(e) == 0; }();          // dev: A/B
     if (off || ag.T < 5 || ag.exact_order) return 1;
-    if (g.kind != SDH_OP_BASE_COO || u.kind != SDH_OP_BASE_COO || !g.tall || !u.tall) return 1;
+    const bool is_block = g.kind == SDH_OP_BASE_BLOCK;
+    if (g.kind != u.kind || (g.kind != SDH_OP_BASE_COO && !is_block) || !g.tall || !u.tall) return 1;
     if (g.idx_type != SDH_TYPE_I16 || g.val_type != SDH_TYPE_F16 || u.idx_type != SDH_TYPE_I16 || u.val_type != SDH_TYPE_F16) return 1;
     if (g.n_in != u.n_in || g.n_out != u.n_out || !ag.v || !au.v || ag.x != au.x || ag.ldx != au.ldx) return 1;
     DeltaParams pg = make_delta_params(g, ag), pu = make_delta_params(u, au);
-    if (pg.Ktot != pu.Ktot) return 1;
+    if (pg.Ktot != pu.Ktot || pg.nb != pu.nb || pg.block != pu.block) return 1;
     int G = 1, steps = 0;
-    if (!delta_vector_shape(pg, false, &G, &steps) || steps != 1 || G < 8) return 1;
+    if (!delta_vector_shape(pg, is_block, &G, &steps) || !delta_vector_shape(pu, is_block, &G, &steps) || steps != 1 || G < 8) return 1;
     pg.G = pu.G = G;
-    const size_t col = (size_t) ((pg.n_in + 3) / 4) * 4 * sizeof(float);
+    // block payloads with eight-token tiles leave the rows kernels for the tiled path above 32 tokens (sdh_forward_impl)
+    if (is_block && ag.T > 32 && (size_t) pg.n_in * 16 <= (size_t) 152 * 1024) return 1;
+    const size_t col = is_block ? (size_t) pg.n_in * sizeof(float) : (size_t) ((pg.n_in + 3) / 4) * 4 * sizeof(float);
     const size_t budget = 152 * 1024;
     if (col * 2 > budget) return 1;
+    if (is_block && (pg.n_in % 8) != 0) return 1;
     if ((size_t) pg.n_out * (size_t) pg.Ktot * 2 >= ((size_t) 1 << 32) ||
         ((size_t) ag.T * (size_t) std::max(pg.v_ld, pu.v_ld) + (size_t) pg.n_out) * 4 >= ((size_t) 1 << 32)) return 1;    // 32-bit offsets
     int nt = col * 8 <= budget ? 8 : col * 4 <= budget ? 4 : 2;
@@ -734,7 +838,8 @@ int launch_delta_rows_pair(const DeviceWeight & g, const DeviceWeight & u, const
     rows_per_wg = (rows_per_wg + rows_pass - 1) / rows_pass * rows_pass;
     const unsigned gl = (unsigned) ((pg.n_out + rows_per_wg - 1) / rows_per_wg);
     void (*kern)(const DeltaParams, const DeltaParams, int64_t, int, int, const uint16_t *, float *, int64_t) =
-        nt == 8 ? delta_rows_coo_lds_pair_kernel<1, 8> : nt == 4 ? delta_rows_coo_lds_pair_kernel<1, 4> : delta_rows_coo_lds_pair_kernel<1, 2>;
+        is_block ? (nt == 8 ? delta_rows_block_lds_pair_kernel<8> : nt == 4 ? delta_rows_block_lds_pair_kernel<4> : delta_rows_block_lds_pair_kernel<2>)
+                 : (nt == 8 ? delta_rows_coo_lds_pair_kernel<1, 8> : nt == 4 ? delta_rows_coo_lds_pair_kernel<1, 4> : delta_rows_coo_lds_pair_kernel<1, 2>);
     SDH_HIP_CHECK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(kern, dim3((unsigned) tiles, gl), dim3(1024), col * nt, s, pg, pu, ag.T, rows_per_wg, act, gelu_tab, h, ldh);
     SDH_HIP_CHECK(hipGetLastError());
