@@ -577,6 +577,7 @@ static int sdh_forward_impl(sdh_weight * h, const float * x, int64_t ldx, int64_
         a.zero_nonfinite = (flags & SDH_FWD_ZERO_NONFINITE) != 0;
         a.exact_order = (flags & SDH_FWD_EXACT_ORDER) != 0;
         if (glu) { a.glu_gate = glu->gate + t0 * glu->ldg; a.glu_ldg = glu->ldg; a.glu_act = glu->act; a.glu_tab = glu->tab; }
+        if (tc == n_tokens) a.x4 = w->x4_hint;
 
         auto prof_begin = [&](int & pair) -> int {
             pair = -1;
@@ -717,7 +718,7 @@ static int ffn_check(sdh_weight * hg, sdh_weight * hu, int act, const void * x, 
 
 // h[t] = act(gate(x[t])) * up(x[t]) on device buffers; gbuf / ubuf: [T][n_ff] scratch for the node-by-node path
 static int ffn_gate_up(sdh_weight * hg, sdh_weight * hu, int act, const float * dx, int64_t dldx, int64_t T,
-                       float * hbuf, float * gbuf, float * ubuf, int flags, hipStream_t s) {
+                       float * hbuf, float * gbuf, float * ubuf, int flags, hipStream_t s, float * h4buf = nullptr) {
     LibState & ls = lib();
     DeviceWeight * g = reinterpret_cast<DeviceWeight *>(hg);
     DeviceWeight * u = reinterpret_cast<DeviceWeight *>(hu);
@@ -729,7 +730,7 @@ static int ffn_gate_up(sdh_weight * hg, sdh_weight * hu, int act, const float * 
         int sg = 0, su = 0;
         if ((rc = nf_slot(g, s, &sg)) != SDH_OK) return rc;
         if ((rc = nf_slot(u, s, &su)) != SDH_OK) return rc;
-        rc = launch_decode_pair(*g, *u, act, ls.gelu_tab, dx, dldx, (int) T, hbuf, n_ff, g->nf_ring + sg, u->nf_ring + su,
+        rc = launch_decode_pair(*g, *u, act, ls.gelu_tab, dx, dldx, (int) T, hbuf, n_ff, h4buf, g->nf_ring + sg, u->nf_ring + su,
                                 (flags & SDH_FWD_ZERO_NONFINITE) != 0, s);
         if (rc < 0) return rc;
         if (rc == SDH_OK) {
@@ -837,10 +838,11 @@ static int sdh_ffn_forward_impl(sdh_weight * hg, sdh_weight * hu, sdh_weight * h
     hipStream_t s = resolve_stream(stream, flags);
     const bool host_io = (flags & SDH_FWD_HOST_IO) != 0;
     const size_t T = (size_t) n_tokens;
-    const size_t sec[5] = {host_io ? T * (size_t) n_embd : 0, host_io ? T * (size_t) d->n_out : 0,
-                           T * (size_t) n_ff, T * (size_t) n_ff, T * (size_t) n_ff};
-    float * ws[5];
-    if ((rc = ffn_workspace(ls, s, sec, 5, ws)) != SDH_OK) return rc;
+    const bool few = n_tokens > 1 && n_tokens <= MAX_FUSED_TOKENS;
+    const size_t sec[6] = {host_io ? T * (size_t) n_embd : 0, host_io ? T * (size_t) d->n_out : 0,
+                           T * (size_t) n_ff, T * (size_t) n_ff, T * (size_t) n_ff, few ? 4 * (size_t) n_ff : 0};
+    float * ws[6];
+    if ((rc = ffn_workspace(ls, s, sec, 6, ws)) != SDH_OK) return rc;
     const float * dx = x; int64_t dldx = ldx;
     float * dy = y; int64_t dldy = ldy;
     if (host_io) {
@@ -853,8 +855,12 @@ static int sdh_ffn_forward_impl(sdh_weight * hg, sdh_weight * hu, sdh_weight * h
     // launch. Mistral layer, us, COO / block16: T=8 31 / 30 (56 / 58 through the tiled SpMM path, 49 / 37 as two groups of
     // four tokens through the single-launch forms — tried, dropped), T=16 38 / 38 (59 / 59), T=32 52 / 53 (77 / 69), T=512
     // 482 / 401 (548 COO tiled). On the rows kernels a token's result is its one-token result.
-    if ((rc = ffn_gate_up(hg, hu, act, dx, dldx, n_tokens, ws[2], ws[3], ws[4], sub, s)) != SDH_OK) return rc;
-    if ((rc = sdh_forward(hd, ws[2], n_ff, n_tokens, dy, dldy, sub, s)) != SDH_OK) return rc;
+    if ((rc = ffn_gate_up(hg, hu, act, dx, dldx, n_tokens, ws[2], ws[3], ws[4], sub, s, few ? ws[5] : nullptr)) != SDH_OK) return rc;
+    // 2..4 tokens through the gate|up launch: it left h token-interleaved as well, which the down launch gathers from
+    if (few && ls.ffn_last_fused) d->x4_hint = ws[5];
+    rc = sdh_forward(hd, ws[2], n_ff, n_tokens, dy, dldy, sub, s);
+    d->x4_hint = nullptr;
+    if (rc != SDH_OK) return rc;
     if (host_io) return device_to_host_sync(ls, y, ldy, dy, d->n_out, n_tokens, s);
     return SDH_OK;
 }

@@ -59,6 +59,7 @@ struct FusedArgs {
     int        delay_xcd_only;    // 1: only residual workgroups on a base workgroup's XCD take the head-start delay
     int        census;            // 1: census launch (no computation)
     unsigned * census_ctr;        // [0] arrivals, [1] failures
+    const float4 * x4;            // several tokens, COO: token-interleaved x in global memory (DeltaLaunch::x4) or null
 };
 
 // Element i of a buffer as (uniform base + 32-bit byte offset): keeps the base in scalar registers
@@ -433,9 +434,12 @@ void decode_fused_nt_xlds_kernel(const DeltaParams p, const BasePackDesc pd, con
     const int ridx = residual_index((int) blockIdx.x, n_base_wg, fa.ncu);
     if (ridx < 0) { shadow_linger(fa.linger); return; }
     float4 * const xs4 = reinterpret_cast<float4 *>(xlds);
-    int * const done = reinterpret_cast<int *>(xlds + 4 * (size_t) p.n_in);      // behind the staged activations
+    int * const done = fa.x4 ? reinterpret_cast<int *>(xlds) : reinterpret_cast<int *>(xlds + 4 * (size_t) p.n_in);      // behind the staged activations
     for (int i = 0; i < fa.resid_delay; ++i) __builtin_amdgcn_s_sleep(8);
-    {   // stage x: 4 inputs x 4 tokens per thread and pass (host: n_in % 4 == 0, columns 16-byte aligned)
+    if (fa.x4) {                                         // the producer left x token-interleaved in global memory: nothing to stage
+        if (threadIdx.x == 0) *done = 0;
+        __syncthreads();
+    } else {   // stage x: 4 inputs x 4 tokens per thread and pass (host: n_in % 4 == 0, columns 16-byte aligned)
         const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         for (int i4 = threadIdx.x; i4 < (p.n_in >> 2); i4 += THREADS) {
             const float4 a = *reinterpret_cast<const float4 *>(p.x + 4 * (size_t) i4);
@@ -462,7 +466,8 @@ void decode_fused_nt_xlds_kernel(const DeltaParams p, const BasePackDesc pd, con
     if (leader && p.rs) scale = p.rs[o];
 
     float acc[4];
-    delta_row_partial_coo_lds4<uint16_t, uint16_t, STEPS, true>(p, xs4, orow, row_ok, l, G, acc);
+    if (fa.x4) delta_row_partial_coo_lds4<uint16_t, uint16_t, STEPS, true>(p, fa.x4, orow, row_ok, l, G, acc);     // global gathers
+    else       delta_row_partial_coo_lds4<uint16_t, uint16_t, STEPS, true>(p, xs4, orow, row_ok, l, G, acc);
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = group_reduce(acc[t], G);
 
@@ -514,6 +519,7 @@ struct PairArgs {
     int          act;
     const uint16_t * gelu_tab;
     float *      h;
+    float4 *     h4;              // several tokens: also h token-interleaved, h4[o] = (h_0[o] .. h_3[o]), or null
     int          resid_delay;
     int          ncu;
     int          linger;
@@ -737,6 +743,7 @@ void decode_pair_nt_kernel(const PairArgs a, const int n_tok, const int64_t ldh)
             if (ok) break;
             __builtin_amdgcn_s_sleep(SDH_POLL_SLEEP);
         } while (__builtin_amdgcn_s_memrealtime() - t0 < SPIN_TICKS);
+        float hv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             if (t < n_tok) {
@@ -744,9 +751,11 @@ void decode_pair_nt_kernel(const PairArgs a, const int n_tok, const int64_t ldh)
                 if (!ok) yg = yu = __uint_as_float(0x7FC00000u);
                 yg = finish_output(a.p[0], yg, sg);
                 yu = finish_output(a.p[1], yu, su);
-                a.h[(size_t) t * (size_t) ldh + o] = glu_value(a.act, yg, yu, a.gelu_tab);
+                hv[t] = glu_value(a.act, yg, yu, a.gelu_tab);
+                a.h[(size_t) t * (size_t) ldh + o] = hv[t];
             }
         }
+        if (a.h4) a.h4[o] = make_float4(hv[0], hv[1], hv[2], hv[3]);
     }
     if (a.reset && reset_last_wave(done, lane, WAVES)) {
         const int rows = WAVES * (64 / G), row0 = ridx * rows, n = min(rows, pg.n_out - row0);
@@ -1064,8 +1073,13 @@ int launch_decode_fused(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s) 
         // (One token through this form measured slower than the plain one-token kernel: Mistral gate 7.85 vs
         // 6.81 us, Gemma-4B gate 7.23 vs 6.62 us — the staging pass sits in front of the payload stream.)
         static const bool xlds_off = [] { const char * e = getenv("SDH_DECODE_XLDS"); return e && atoi(e) == 0; }();
-        const size_t xlds_bytes = std::max((size_t) w.L * 4, (size_t) p.n_in * 16) + 16;
-        if (!xlds_off && !is_block && steps <= 2 && (p.n_in % 4) == 0 && xlds_bytes <= 72 * 1024 && (w.tall || w.B <= 4)) {
+        static const bool x4_off = [] { const char * e = getenv("SDH_DECODE_X4"); return e && atoi(e) == 0; }();             // dev: A/B
+        // Mistral FFN layer, us, with / without: 2 tokens 18.6 / 17.9 (two plain gathers per entry beat one 16-byte gather half of which is padding),
+        // 3 tokens 20.7 / 22.6, 4 tokens 22.3 / 24.5
+        const bool use_x4 = a.x4 != nullptr && !x4_off && n_tok >= 3;
+        fa.x4 = use_x4 ? reinterpret_cast<const float4 *>(a.x4) : nullptr;
+        const size_t xlds_bytes = use_x4 ? (size_t) w.L * 4 + 16 : std::max((size_t) w.L * 4, (size_t) p.n_in * 16) + 16;
+        if ((!xlds_off || use_x4) && !is_block && steps <= 2 && (p.n_in % 4) == 0 && xlds_bytes <= 72 * 1024 && (w.tall || w.B <= 4)) {
             int rc = 1;
             switch (w.L) {
                 case 1024: rc = launch_ntx_steps<2, 8>(steps, n_tok, p, w.pack, fa, grid, xlds_bytes, s); break;
@@ -1074,6 +1088,7 @@ int launch_decode_fused(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s) 
             }
             if (rc != 1) return rc;                    // launched or failed; 1: does not fit, try the plain multi-token launch
         }
+        fa.x4 = nullptr;
         switch (w.L) {
             case 1024: return is_block ? launch_nt_steps<true, 2, 8>(steps, n_tok, p, w.pack, fa, grid, s) : launch_nt_steps<false, 2, 8>(steps, n_tok, p, w.pack, fa, grid, s);
             case 2048: return is_block ? launch_nt_steps<true, SDH_L2048_LOG_E, SDH_L2048_LOG_T>(steps, n_tok, p, w.pack, fa, grid, s)
@@ -1205,7 +1220,7 @@ static int launch_pair_nt_steps(int steps, PairArgs & a, int n_tok, int64_t ldh,
 }
 
 int launch_decode_pair(DeviceWeight & g, DeviceWeight & u, int act, const uint16_t * gelu_tab,
-                       const float * x, int64_t ldx, int n_tok, float * h, int64_t ldh,
+                       const float * x, int64_t ldx, int n_tok, float * h, int64_t ldh, float * h4,
                        int * nf_g, int * nf_u, bool zero_nonfinite, hipStream_t s) {
     static const bool dbg = getenv("SDH_DEBUG") != nullptr;
 #define SDH_DECLINE(why) do { if (dbg) fprintf(stderr, "[sdh] gate|up launch declined: %s\n", why); return 1; } while (0)
@@ -1245,6 +1260,7 @@ int launch_decode_pair(DeviceWeight & g, DeviceWeight & u, int act, const uint16
     static const bool force_reset = getenv("SDH_DECODE_FORCE_RESET") != nullptr;
     a.reset = (capturing || force_reset) ? 1 : 0;
     a.act = act; a.gelu_tab = gelu_tab; a.h = h;
+    a.h4 = n_tok > 1 ? reinterpret_cast<float4 *>(h4) : nullptr;
     // the pair's residual role streams two payloads and is the longer chain: no head start by default
     // (FFN block, Mistral layer: 12.10 / 12.22 / 12.24 / 12.39 us per layer with 0 / 1 / 2 / 3 units when
     // both launches shared one setting)

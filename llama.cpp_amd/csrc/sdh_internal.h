@@ -79,6 +79,7 @@ struct DeviceWeight {
     hipStream_t last_stream = nullptr;
     // workspace for the base term v[T_chunk][B][L]
     float * ws = nullptr;
+    const float * x4_hint = nullptr;  // token-interleaved copy of the next call's x (see DeltaLaunch::x4); set and cleared by the FFN path
     bool    base_ready = false;  // ws already holds the base terms of the next call's tokens (gate|up base launch of the FFN path)
     size_t  ws_bytes = 0;
 };
@@ -140,6 +141,9 @@ struct DeltaLaunch {
                             // is written straight into y and the residual kernel updates y in place, v == y, v_ld == ldy)
     // gated FFN, ffn_up node: the epilogue writes act(gate[t][o]) * y instead of y (the node's own guard runs first)
     const float * glu_gate = nullptr; int64_t glu_ldg = 0; int glu_act = 0; const uint16_t * glu_tab = nullptr;
+    // 2..4 tokens: a token-interleaved copy of x, x4[4 * i + t] (slots past T zero), when the producer wrote one (the FFN
+    // path's gate|up launch): a COO row entry is then one 16-byte gather for all tokens instead of one 4-byte gather per token
+    const float * x4 = nullptr;
 };
 int launch_delta(const DeviceWeight & w, const DeltaLaunch & a, hipStream_t s);
 
@@ -159,7 +163,7 @@ int launch_decode_fused(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s);
 // 1..MAX_FUSED_TOKENS tokens, gate and up tall base payloads of one shape: h[t][o] = act(gate(x_t)[o]) * up(x_t)[o] in
 // one launch. Returns SDH_OK, 1 if the pair does not qualify, <0 on error. nf_g / nf_u: the two nodes' counters.
 int launch_decode_pair(DeviceWeight & g, DeviceWeight & u, int act, const uint16_t * gelu_tab,
-                       const float * x, int64_t ldx, int n_tok, float * h, int64_t ldh,
+                       const float * x, int64_t ldx, int n_tok, float * h, int64_t ldh, float * h4,
                        int * nf_g, int * nf_u, bool zero_nonfinite, hipStream_t s);
 int launch_delta_rows_pair(const DeviceWeight & g, const DeviceWeight & u, const DeltaLaunch & ag, const DeltaLaunch & au,
                            int act, const uint16_t * gelu_tab, float * h, int64_t ldh, hipStream_t s);

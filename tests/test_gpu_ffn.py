@@ -163,6 +163,29 @@ def test_gate_up_small_batch_single_launch_is_bit_identical_to_node_by_node(hip,
     assert wg.nonfinite_count() == 0 and wu.nonfinite_count() == 0
 
 
+@pytest.mark.parametrize("scheme,K,block", [("coo", 128, 16), ("coo", 32, 16), ("block", 128, 16)])
+@pytest.mark.parametrize("dims", [(2048, 5632), (4096, 14336)])
+def test_ffn_two_to_four_tokens_keep_one_token_results(hip, scheme, K, block, dims):
+    """sdh_ffn_forward with 2..4 tokens: the gate|up launch also leaves h token-interleaved and a COO down launch gathers
+    from that copy (one 16-byte gather per entry for all tokens). Every token's output is its one-token output bit for
+    bit, call after call (the interleaved copy is rewritten per call), and equals the node-by-node path's."""
+    n_embd, n_ff = dims
+    kw = dict(scheme=scheme, K=K, block=block, base=True, d13_random=True)
+    gate, up = make_payload(n_embd, n_ff, seed=61, **kw), make_payload(n_embd, n_ff, seed=62, **kw)
+    down = make_payload(n_ff, n_embd, seed=63, **kw)
+    wg, wu, wd = hip.SeedDeltaWeight(gate), hip.SeedDeltaWeight(up), hip.SeedDeltaWeight(down)
+    xs = make_x(n_embd, 8, seed=29)
+    single = np.concatenate([hip.ffn_forward_host(wg, wu, wd, xs[t:t + 1], O.ACT_GELU) for t in range(8)], axis=0)
+    for T in (4, 2, 3, 4):
+        for t0 in (0, 4):
+            y = hip.ffn_forward_host(wg, wu, wd, xs[t0:t0 + T], O.ACT_GELU)
+            assert hip.ffn_last_fused()
+            assert np.array_equal(bits(y), bits(single[t0:t0 + T])), (T, t0)
+    yn = hip.ffn_forward_host(wg, wu, wd, xs[:3], O.ACT_GELU, hip.FWD_NO_FUSE)
+    assert np.array_equal(bits(yn), bits(single[:3]))
+    assert wg.nonfinite_count() == 0 and wu.nonfinite_count() == 0 and wd.nonfinite_count() == 0
+
+
 @pytest.mark.parametrize("scheme,K,block", [("coo", 128, 16), ("block", 128, 16)])
 def test_ffn_five_to_eight_tokens_keep_one_token_results(hip, scheme, K, block):
     """sdh_ffn_forward with 5..8 tokens goes node by node through the LDS rows kernels (base terms of gate and up from
