@@ -19,6 +19,14 @@
 //                              differs from the CPU op (tolerance-checked).
 //   delta_rows_scalar_kernel — same ownership, element-wise loads, for rows that are not 16-byte
 //                              multiples.
+//   delta_rows_{coo,block}_lds_kernel
+//                            — several tokens, the same arithmetic per token: x of up to 8 tokens in LDS,
+//                              rows walked pass by pass with the next pass's operands requested ahead,
+//                              transposing reduction (one epilogue lane per token). Block payloads with
+//                              rows of more than 256 entries from 10 tokens, otherwise from 5 tokens
+//                              when the tiled SpMM is not asked for (gated FFN node launches,
+//                              SDH_FWD_NO_SPMM). The *_pair_kernel forms do gate and up of a gated FFN
+//                              from one tile of x and write act(gate) * up.
 //   delta_exact_kernel       — verification mode: one lane per output, the reference's sequential
 //                              order with separately rounded multiply and add; bit-identical.
 #include "sdh_internal.h"

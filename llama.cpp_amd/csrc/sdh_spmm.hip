@@ -277,13 +277,13 @@ static int launch_vec(const DeltaParams & p, int64_t T, hipStream_t s) {
     if (col * 8 <= budget) return launch_tt<IDX_T, VAL_T, BLOCK, VEC, 8>(p, T, s);
     // narrower tiles re-stream the payload T/TT times: measured on MI355X (T=512, n_in=14336) the COO
     // form still wins 4x over the per-token kernels, the block form loses (0.25 vs 0.15 ms at K=128,
-    // 2.6 vs 0.8 ms at K=1536), so block payloads with long inputs keep the per-token kernels
+    // 2.6 vs 0.8 ms at K=1536), so block payloads with long inputs kept the per-token kernels
     // (re-measured with the spare-row layout: at K=128 the block form now wins as well, 0.161 -> 0.132 ms per Mistral
     // down block16 ubatch; at K=1536 it still loses, 0.81 -> 1.07 ms — the payload is re-streamed T/TT times)
-    if (BLOCK && p.Ktot > 256) return 1;
+    if (BLOCK && p.Ktot > 256) return 1;                 // -> delta_rows_block_lds_kernel (0.33 ms at K=1536)
     if (col * 4 <= budget) return launch_tt<IDX_T, VAL_T, BLOCK, VEC, 4>(p, T, s);
     if (col * 2 <= budget) return launch_tt<IDX_T, VAL_T, BLOCK, VEC, 2>(p, T, s);
-    return 1;                                           // does not fit: caller uses the per-token kernels
+    return 1;                                           // does not fit: caller uses the row kernels (sdh_delta.hip)
 }
 
 template <typename IDX_T, typename VAL_T, bool BLOCK>
