@@ -236,6 +236,7 @@ void delta_rows_block_lds_kernel(const DeltaParams p, const int64_t T, const int
 template <typename IDX_T, typename VAL_T, int STEPS, int NT>
 __global__ __launch_bounds__(1024)
 void delta_rows_coo_lds_kernel(const DeltaParams p, const int64_t T, const int rows_per_wg) {
+#pragma clang fp contract(off)                           // the products and the adds round separately, as in delta_row_partial
     extern __shared__ float xs[];                       // [4 * n4][NT]
     static_assert(NT == 2 || NT == 4 || NT == 8, "tokens per tile");
     constexpr int NS = STEPS;
@@ -290,6 +291,8 @@ void delta_rows_coo_lds_kernel(const DeltaParams p, const int64_t T, const int r
     int o = r0 + wave * rows_wave + lane / G;
     request(o);                                          // the first rows' payload travels while the tile is filled
     spmm_fill_tile<false, NT, GRP, 1024>(p, xs, t0, nt, n4, tid);
+    const int zero_row = 4 * n4;                         // one row past the tile: all zeros, what skipped entries read
+    if (tid < NT) xs[(size_t) zero_row * NT + tid] = 0.0f;
     __syncthreads();
     const int passes = (r1 - r0 + stride - 1) / stride;  // uniform over the workgroup
     for (int it = 0; it < passes; ++it, o += stride) {
@@ -303,9 +306,9 @@ void delta_rows_coo_lds_kernel(const DeltaParams p, const int64_t T, const int r
 #pragma unroll
         for (int b = 0; b < NB; ++b) vb[b] = vb_n[b];
         request(o + stride);
-        float acc[NT];
+        f32x2_t acc2[NT / 2];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = 0.0f;
+        for (int t = 0; t < NT / 2; ++t) acc2[t] = f32x2_t{0.0f, 0.0f};
 #pragma unroll
         for (int u = 0; u < NS; ++u) {
             const bool oku = row_ok & eok[u];
@@ -317,18 +320,24 @@ void delta_rows_coo_lds_kernel(const DeltaParams p, const int64_t T, const int r
                 for (int j = 0; j < 4; ++j) {
                     const int i = idx_to_i32<IDX_T>(ii[u].get(h + j));
                     okj[j] = oku & ((unsigned) i < (unsigned) p.n_in);
-                    const gvec * row = reinterpret_cast<const gvec *>(xs + (size_t) tile_row<false>(p, okj[j] ? i : 0, n4) * NT);
+                    const gvec * row = reinterpret_cast<const gvec *>(xs + (size_t) (okj[j] ? tile_row<false>(p, i, n4) : zero_row) * NT);
 #pragma unroll
                     for (int q = 0; q < NT / GRP; ++q) xv[j][q] = row[q ^ half_sw];
                 }
+                // a skipped entry contributes +0.0f * +0.0f = +0.0f (its value masked, its activations the tile's zero
+                // row): acc + (+0) is add_if's acc + (ok ? term : 0) — one select per entry instead of one per entry and token
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float v = val_to_f32<VAL_T>(vv[u].get(h + j));
+                    const float v = okj[j] ? val_to_f32<VAL_T>(vv[u].get(h + j)) : 0.0f;
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[t] = add_if(acc[t], okj[j], __fmul_rn(v, xv[j][t / GRP][t % GRP]));
+                    for (int t = 0; t < NT; t += 2)
+                        acc2[t / 2] = mul_then_add2(acc2[t / 2], v, f32x2_t{xv[j][t / GRP][t % GRP], xv[j][t / GRP][t % GRP + 1]});
                 }
             }
         }
+        float acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t += 2) { acc[t] = acc2[t / 2][0]; acc[t + 1] = acc2[t / 2][1]; }
         if constexpr (NT == 8) {                         // odd lanes accumulated tokens 4..7 in slots 0..3: put them back
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -361,6 +370,7 @@ template <int STEPS, int NT>
 __global__ __launch_bounds__(1024)
 void delta_rows_coo_lds_pair_kernel(const DeltaParams pg, const DeltaParams pu, const int64_t T, const int rows_per_wg,
                                     const int act, const uint16_t * __restrict__ tab, float * __restrict__ h, const int64_t ldh) {
+#pragma clang fp contract(off)
     extern __shared__ float xs[];                       // [4 * n4][NT]
     static_assert(NT == 2 || NT == 4 || NT == 8, "tokens per tile");
     constexpr int NS = STEPS;
@@ -421,11 +431,14 @@ void delta_rows_coo_lds_pair_kernel(const DeltaParams pg, const DeltaParams pu, 
     int o = r0 + wave * rows_wave + lane / G;
     request(pa, o);
     spmm_fill_tile<false, NT, GRP, 1024>(pg, xs, t0, nt, n4, tid);
+    const int zero_row = 4 * n4;
+    if (tid < NT) xs[(size_t) zero_row * NT + tid] = 0.0f;
     __syncthreads();
     auto row_sum = [&](const Vec8<uint16_t> (&ii)[NS], const Vec8<uint16_t> (&vv)[NS], bool row_ok) -> float {
-        float acc[NT];
+#pragma clang fp contract(off)
+        f32x2_t acc2[NT / 2];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = 0.0f;
+        for (int t = 0; t < NT / 2; ++t) acc2[t] = f32x2_t{0.0f, 0.0f};
 #pragma unroll
         for (int u = 0; u < NS; ++u) {
             const bool oku = row_ok & eok[u];
@@ -437,18 +450,22 @@ void delta_rows_coo_lds_pair_kernel(const DeltaParams pg, const DeltaParams pu, 
                 for (int j = 0; j < 4; ++j) {
                     const int i = idx_to_i32<uint16_t>(ii[u].get(hh + j));
                     okj[j] = oku & ((unsigned) i < (unsigned) pg.n_in);
-                    const gvec * row = reinterpret_cast<const gvec *>(xs + (size_t) tile_row<false>(pg, okj[j] ? i : 0, n4) * NT);
+                    const gvec * row = reinterpret_cast<const gvec *>(xs + (size_t) (okj[j] ? tile_row<false>(pg, i, n4) : zero_row) * NT);
 #pragma unroll
                     for (int q = 0; q < NT / GRP; ++q) xv[j][q] = row[q ^ half_sw];
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float v = val_to_f32<uint16_t>(vv[u].get(hh + j));
+                for (int j = 0; j < 4; ++j) {                // skipped entries: +0 * +0, see delta_rows_coo_lds_kernel
+                    const float v = okj[j] ? val_to_f32<uint16_t>(vv[u].get(hh + j)) : 0.0f;
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[t] = add_if(acc[t], okj[j], __fmul_rn(v, xv[j][t / GRP][t % GRP]));
+                    for (int t = 0; t < NT; t += 2)
+                        acc2[t / 2] = mul_then_add2(acc2[t / 2], v, f32x2_t{xv[j][t / GRP][t % GRP], xv[j][t / GRP][t % GRP + 1]});
                 }
             }
         }
+        float acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t += 2) { acc[t] = acc2[t / 2][0]; acc[t + 1] = acc2[t / 2][1]; }
         if constexpr (NT == 8) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -702,7 +719,7 @@ static int launch_typed(const DeltaLaunch & a, DeltaParams & p, hipStream_t s) {
                 kern = nt == 8 ? delta_rows_coo_lds_kernel<IDX_T, VAL_T, 2, 8> : nt == 4 ? delta_rows_coo_lds_kernel<IDX_T, VAL_T, 2, 4> : delta_rows_coo_lds_kernel<IDX_T, VAL_T, 2, 2>;
             if (kern) {
                 SDH_HIP_CHECK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                hipLaunchKernelGGL(kern, dim3((unsigned) tiles, gl), dim3(1024), col * nt, s, p, a.T, rows_per_wg);
+                hipLaunchKernelGGL(kern, dim3((unsigned) tiles, gl), dim3(1024), col * nt + (size_t) nt * 4, s, p, a.T, rows_per_wg);   // + the zero row
                 SDH_HIP_CHECK(hipGetLastError());
                 return SDH_OK;
             }
@@ -849,7 +866,7 @@ int launch_delta_rows_pair(const DeviceWeight & g, const DeviceWeight & u, const
         is_block ? (nt == 8 ? delta_rows_block_lds_pair_kernel<8> : nt == 4 ? delta_rows_block_lds_pair_kernel<4> : delta_rows_block_lds_pair_kernel<2>)
                  : (nt == 8 ? delta_rows_coo_lds_pair_kernel<1, 8> : nt == 4 ? delta_rows_coo_lds_pair_kernel<1, 4> : delta_rows_coo_lds_pair_kernel<1, 2>);
     SDH_HIP_CHECK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(kern, dim3((unsigned) tiles, gl), dim3(1024), col * nt, s, pg, pu, ag.T, rows_per_wg, act, gelu_tab, h, ldh);
+    hipLaunchKernelGGL(kern, dim3((unsigned) tiles, gl), dim3(1024), col * nt + (is_block ? 0 : (size_t) nt * 4), s, pg, pu, ag.T, rows_per_wg, act, gelu_tab, h, ldh);
     SDH_HIP_CHECK(hipGetLastError());
     return SDH_OK;
 }

@@ -114,6 +114,23 @@ __device__ __forceinline__ float dot8(const Vec8<VAL_T> & v, const float4 & a, c
     return ps;
 }
 __device__ __forceinline__ float add_if(float acc, bool ok, float term) { return __fadd_rn(acc, ok ? term : 0.0f); }
+// acc + v * x as a separately rounded product and sum. (__fadd_rn(acc, __fmul_rn(v, x)) does NOT do this: the two
+// library calls inline to a plain fmul / fadd pair that the backend fuses into v_fmac_f32 — 60 % of the outputs of a
+// row kernel written that way differed from the one-token kernel by an ulp or two. add_if's select between the product
+// and the sum is what keeps them apart there.)
+__device__ __forceinline__ float mul_then_add(float acc, float v, float x) {
+#pragma clang fp contract(off)
+    const float prod = v * x;
+    return acc + prod;
+}
+// two tokens per instruction (v_pk_mul_f32, v_pk_add_f32): each component rounds as the scalar forms do
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t mul_then_add2(f32x2_t acc, float v, f32x2_t x) {
+#pragma clang fp contract(off)
+    const f32x2_t vv = {v, v};
+    const f32x2_t prod = vv * x;
+    return acc + prod;
+}
 
 // One lane's share of one row's dot product on the vector path. STEPS = number of 8-element
 // steps each lane owns (compile time, so that every payload / index / activation load of the row
