@@ -794,14 +794,38 @@ def complete_entry(e: dict) -> dict:
     return {k: out[k] for k in _ENTRY_ORDER}
 
 
+def finalize_report_entry(e: dict) -> dict:
+    """sd_report::finalize_report_entry (sd_report.cpp:46-59): the defaults an entry takes just before it is
+    written — metric_used from the gating metric, the tau targets from the gating thresholds, reject_reason from
+    the decision. Works on an entry in this module's field names (`decision` is the builder's decision_reason,
+    written as "decision", sd_report.cpp:231)."""
+    out = dict(e)
+    if not out.get("metric_used"):
+        out["metric_used"] = out.get("gating_metric", "")
+    t = dict(out.get("targets_used") or {})
+    if not t.get("tau_mean"):
+        t["tau_mean"] = out.get("gating_min_mean", 0.0)
+    if not t.get("tau_p05"):
+        t["tau_p05"] = out.get("gating_min_p05", 0.0)
+    out["targets_used"] = t
+    if not out.get("reject_reason"):
+        out["reject_reason"] = out.get("decision", "")
+    return out
+
+
 def report_document(entries: Sequence[dict], params: ScanParams, input_name: str = "", output_name: str = "",
-                    policy_file: str = "", policy_hash: str = "") -> dict:
+                    policy_file: str = "", policy_hash: str = "", imatrix: Optional[dict] = None) -> dict:
     """The report.json document (sd_report.cpp:122-161 header + weights[]), numbers at 6 significant
-    digits as the builder's ostream prints them."""
+    digits as the builder's ostream prints them. `imatrix`: {"file", "eps", "power", "datasets"} when the run had
+    an importance matrix (the header fields of sd_report.cpp:133-143)."""
     doc = {"input": input_name, "output": output_name, "base": bool(params.base), "policy_file": policy_file,
            "policy_hash": policy_hash}
     if params.base:
         doc.update(base_kind="xor_circulant", base_max_samples=params.base_max_samples, base_perm_trials=params.base_perm_trials)
+    if imatrix is not None:
+        doc.update(imatrix_file=imatrix.get("file", ""), imatrix_eps=round_like_report(float(imatrix.get("eps", 1e-8))),
+                   imatrix_power=round_like_report(float(imatrix.get("power", 1.0))),
+                   imatrix_datasets=list(imatrix.get("datasets", [])))
     resid = {"scheme": params.scheme}
     if params.scheme == "block":
         resid["block"] = params.block

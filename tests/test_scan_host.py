@@ -80,6 +80,37 @@ def test_shard_is_a_balanced_partition():
     assert SC.shard(cands, 1, 4, cost) == SC.shard(list(reversed(cands)), 1, 4, cost)   # order-independent
 
 
+def test_shard_groups_keeps_a_k_schedule_on_one_rank():
+    """The deal bench.py's scan leg uses (SC.shard_groups): a partition of the candidates in which every K of a
+    (layer, tensor) lands on ONE rank (its dense weight is uploaded once, fit / dequant / sort shared by the
+    schedule), the same on every rank without communication, balanced to within one group, and with `counts`
+    equal to what each rank really gets. Candidate independence: scripts/seeddelta-layer-scan.py:206-262."""
+    grid = {"ffn_gate": [128, 256, 384, 512, 640, 768], "ffn_up": [128, 256, 384, 512, 640, 768],
+            "ffn_down": [256, 512, 768, 1024, 1280, 1536]}
+    cands = SC.enumerate_candidates(range(32), SC.KINDS, grid)
+    cost = lambda c: 1.0 + c.K / 1536.0        # noqa: E731
+    for world in (1, 2, 3, 4, 8):
+        deals = [SC.shard_groups(cands, r, world, cost) for r in range(world)]
+        parts = [d[0] for d in deals]
+        assert all(d[1] == deals[0][1] for d in deals)                       # every rank computes the same counts
+        assert [len(p) for p in parts] == deals[0][1]
+        keys = sorted(c.key() for p in parts for c in p)
+        assert keys == sorted(c.key() for c in cands)                        # nothing lost, nothing doubled
+        owner = {}
+        for r, p in enumerate(parts):
+            for c in p:
+                assert owner.setdefault((c.layer, c.kind), r) == r           # one rank per (layer, tensor)
+            assert p == [c for c in cands if owner.get((c.layer, c.kind)) == r]   # serial visiting order kept
+        loads = [sum(cost(c) for c in p) for p in parts]
+        heaviest = max(sum(cost(c) for c in cands if (c.layer, c.kind) == g) for g in owner)
+        assert max(loads) - min(loads) <= heaviest + 1e-9
+    a = SC.shard_groups(cands, 1, 4, cost)
+    assert a == SC.shard_groups(list(cands), 1, 4, cost)
+    # a variant tag in the group key (bench.py deals the two parameter sets of a tensor to one rank as well)
+    mine, counts = SC.shard_groups(cands, 0, 2, cost, group_key=lambda c: (c.layer,))
+    assert sum(counts) == len(cands) and len({c.layer for c in mine}) == 16
+
+
 def test_record_round_trip():
     c = SC.Candidate(17, "ffn_down", 1536)
     res = fake_result(proxy=True)
@@ -102,14 +133,20 @@ rank, world = dist.get_rank(), dist.get_world_size()
 grid = {"ffn_gate": [128, 256], "ffn_up": [128], "ffn_down": [256, 512]}
 cands = SC.enumerate_candidates(range(3), SC.KINDS, grid)
 cost = lambda c: 1.0 + c.K / 512.0
-mine = SC.shard(cands, rank, world, cost)
+mine, counts = SC.shard_groups(cands, rank, world, cost)          # the deal bench.py's scan leg uses
+assert counts == SC.shard_groups(cands, 1 - rank, world, cost)[1] and counts[rank] == len(mine)
+owners = {}
+for r in range(world):
+    for c in SC.shard_groups(cands, r, world, cost)[0]:
+        assert owners.setdefault((c.layer, c.kind), r) == r       # all K of a (layer, tensor) on one rank
+assert len(owners) == 9 and sum(counts) == len(cands)
 def fake(c):
     v = float(c.layer * 1000 + SC.KIND_ID[c.kind] * 100) + c.K / 1000.0
     return {"K_eff": c.K, "n_blocks": 1, "L": 0, "B": 0, "has_x": True, "proxy_available": False,
             "em": np.full(5, v), "em_x": np.full(5, v + 0.5), "cost": np.zeros(8), "proxy": np.zeros(8), "gpu_ms": 1.0}
 local = np.stack([SC.to_record(c, fake(c)) for c in mine]) if mine else np.zeros((0, SC.RECORD_LEN))
-counts = [len(SC.shard(cands, r, world, cost)) for r in range(world)]
 allr = SC.gather_records(local, counts)
+assert sorted(tuple(r[:3]) for r in allr) == sorted(tuple(float(v) for v in c.key()) for c in cands)   # gathered set == serial set
 got = {SC.from_record(r)[0].key(): SC.from_record(r)[1]["em"][0] for r in allr}
 want = {c.key(): fake(c)["em"][0] for c in cands}
 assert got == want, (rank, len(got), len(want))
@@ -149,6 +186,35 @@ def test_report_document_has_the_builder_fields(script_golden):
         assert m["S_mean"] == 0.8 and m["ffn_proxy_available"] == (e["kind"] != "ffn_down")
     assert json.loads(SC.dumps(doc))["resid"]["K_down"] == 12
     assert SC.report_document(entries, SC.ScanParams(base=True))["base_kind"] == "xor_circulant"
+
+
+def test_report_serialization_as_the_reference_selftest():
+    """The reference's own expectations for the report writer: test_report_serialization
+    (tools/seeddelta-build/selftest/sd_selftest.cpp:52-118) builds ONE entry (layer 3, ffn_gate, has_w, gating
+    metric cos_x 0.7 / 0.4, decision pass_gating, emit, metric_used cleared), finalises it, writes it with a
+    base + imatrix + COO K=32 header and looks for three substrings in the file. Same entry, same header, same
+    substrings here — plus what finalize_report_entry (sd_report.cpp:46-59) must have filled in."""
+    entry = {"layer": 3, "kind": "ffn_gate", "has_w": True, "gating_metric": "cos_x", "gating_value": 0.7, "gating_p05": 0.4,
+             "decision": "pass_gating", "emit": True, "metric_used": ""}       # sd_constants.h:10
+    entry = SC.finalize_report_entry(entry)
+    assert entry["metric_used"] == "cos_x" and entry["reject_reason"] == "pass_gating"
+    assert entry["targets_used"] == {"tau_mean": 0.0, "tau_p05": 0.0}
+    cfg = SC.ScanParams(scheme="coo", K=32, base=True, row_scale=True, base_max_samples=1, base_perm_trials=1, eval_cols=1, eval_x=1)
+    doc = SC.report_document([entry], cfg, input_name="in.gguf", output_name="out.gguf", policy_file="policy.json",
+                             policy_hash="hash", imatrix={"file": "matrix.gguf", "eps": 1e-8, "power": 1.0, "datasets": ["dataset"]})
+    contents = SC.dumps(doc)
+    assert '"layer": 3' in contents                     # sd_selftest.cpp:107
+    assert '"kind": "ffn_gate"' in contents             # :111
+    assert "pass_gating" in contents                    # :115
+    # the header the writer emits for that config, in the writer's order (sd_report.cpp:122-160)
+    assert list(doc)[:15] == ["input", "output", "base", "policy_file", "policy_hash", "base_kind", "base_max_samples",
+                              "base_perm_trials", "imatrix_file", "imatrix_eps", "imatrix_power", "imatrix_datasets", "resid",
+                              "eval_cols", "eval_x"]
+    back = json.loads(contents)
+    assert back["imatrix_datasets"] == ["dataset"] and back["imatrix_eps"] == 1e-8 and back["resid"]["K_gate"] == 32
+    w = back["weights"][0]
+    assert w["decision"] == "pass_gating" and w["emit"] is True and w["has_w"] is True and w["gating_value"] == 0.7
+    assert w["n_in"] == 0 and w["K"] == 0 and w["autotune_attempts"] == []     # zero-initialised fields of an entry that ran no trial
 
 
 @pytest.mark.parametrize("seed,skip,n", [(1234, 0, 1), (1234, 3, 2), (7, 11, 7), (1234, 0, 32 * 4096), (99, 623, 100001), (5, 624, 32 * 14336)])
