@@ -138,15 +138,32 @@ def scan_variants(metrics_only=True):
                           metrics_only=metrics_only)}
 
 
+def scan_host_threads(args, world):
+    """Host threads preparing candidates per rank: the flag, capped at this process's share of the host's cores."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    return max(2, min(args.scan_threads, cores // max(1, world)))
+
+
 def run_scan(args, rank, world, dev):
     """The sweep of config 5, scaled to --scan-layers layers: (layer, tensor, K) candidates in two
-    variants (COO without base + FFN proxy; COO with base + row scale), dealt to ranks, evaluated on
-    each rank's GPU, one all_gather of the records (RCCL). Strong scaling: the job is fixed."""
+    variants (COO without base + FFN proxy; COO with base + row scale), dealt to ranks as whole (layer, tensor)
+    groups, evaluated on each rank's GPU, one all_gather of the records (RCCL). Strong scaling: the job is fixed.
+    Three timed passes over the SAME candidates:
+      upload_inclusive  each rank materialises and uploads only its own layers' weights inside the clock, then runs
+                        the sweep with every output row selected (payload emission: the reference's only form);
+      value             the same payload-emission sweep with the weights already resident;
+      metrics_only      report entries only (rows the metric passes sample), weights resident."""
     import torch
     from llama_cpp_amd import scan as SC
-    variants = scan_variants()
+    from llama_cpp_amd import seeddelta as _sd
+    one_dev = os.environ.get("SDH_BENCH_ONE_DEVICE") == "1"
+    threads = scan_host_threads(args, world)
+    lite, full = scan_variants(True), scan_variants(False)
     cands = []
-    for v in variants:
+    for v in lite:
         for c in SC.enumerate_candidates(range(args.scan_layers), SC.KINDS, SCAN_K):
             c.variant = v
             cands.append(c)
@@ -154,94 +171,106 @@ def run_scan(args, rank, world, dev):
     # all trials of one (layer, tensor) stay on one rank: its dense weight is uploaded once;
     # the same deal the world-size-2 gloo test exercises (tests/test_scan_host.py)
     mine, counts = SC.shard_groups(cands, rank, world, cost)
-    ev = SC.Evaluator(scan_model, variants[0], max_resident=3 * max(1, args.scan_layers), dims_of=scan_dims)
-    for c in mine:                                                    # weights resident before the clock starts
-        for k in (SC.KINDS if c.kind != "ffn_down" else (c.kind,)):
-            ev.dense(c.layer, k)
+    ev = SC.Evaluator(scan_model, lite[0], max_resident=3 * max(1, args.scan_layers) + 3, dims_of=scan_dims)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    def max_over_ranks(el):
+        if world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([el], dtype=torch.float64, device="cpu" if one_dev else dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
+        return el
+
+    def sweep(variants, upload_first=False):
+        """barrier, clock, [this rank's weights], the sweep, the gather, barrier, clock; max over ranks."""
+        _sd.load_library().sdh_scan_memo_clear()          # every timed sweep makes every distinct draw itself
+        barrier()
+        t0 = time.perf_counter()
+        if upload_first:
+            for c in mine:
+                for k in (SC.KINDS if c.kind != "ffn_down" else (c.kind,)):
+                    ev.dense(c.layer, k)
+        res = ev.run_many(mine, threads=threads, params_of=lambda c: variants[c.variant])
+        local = np.stack([SC.to_record(c, r) for c, r in zip(mine, res)]) if mine else np.zeros((0, SC.RECORD_LEN))
+        allr = SC.gather_records(local, counts, device=None if one_dev else dev)
+        barrier()
+        el = max_over_ranks(time.perf_counter() - t0)
+        assert len(allr) == len(cands)
+        return el
+
+    # warm-up on the worker pool the timed runs use, on a layer outside the sweep: every worker creates its scan
+    # handle (stream, events, device buffers at the largest K), as in a scan that has been running for a while
+    wl = args.scan_layers + rank
+    warm = []
+    for v in lite:
+        for c in SC.enumerate_candidates([wl], SC.KINDS, SCAN_K):
+            c.variant = v
+            warm.append(c)
+    for _ in range(max(1, -(-threads // 6))):
+        ev.run_many(warm, threads=threads, params_of=lambda c: full[c.variant])
+        ev.run_many(warm, threads=threads, params_of=lambda c: lite[c.variant])
+    for key in [k for k in list(ev._cache) if k[0] == wl]:             # the warm-up layer leaves the device
+        ev._cache.pop(key).close()
+        ev._order.remove(key)
+
+    el_up = sweep(full, upload_first=True)
     dense_bytes = sum(w.stored_bytes for w in ev._cache.values())
-    # warm-up on the worker pool the timed run uses: every worker creates its scan handle (stream, events,
-    # device buffers) and the Gaussian-draw memo is filled, as in a sweep that has been running for a while
-    warm_n = min(len(mine), 8 * args.scan_threads)
-    ev.run_many(mine[:: max(1, len(mine) // max(1, warm_n))][:warm_n], threads=args.scan_threads, params_of=lambda c: variants[c.variant])
-    from llama_cpp_amd import seeddelta as _sd
-    _sd.load_library().sdh_scan_memo_clear()          # the timed sweep makes every distinct draw itself
-    torch.cuda.synchronize()
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-    t0 = time.perf_counter()
-    res = ev.run_many(mine, threads=args.scan_threads, params_of=lambda c: variants[c.variant])
-    local = np.stack([SC.to_record(c, r) for c, r in zip(mine, res)]) if mine else np.zeros((0, SC.RECORD_LEN))
-    allr = SC.gather_records(local, counts, device=None if os.environ.get("SDH_BENCH_ONE_DEVICE") == "1" else dev)
-    torch.cuda.synchronize()
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if os.environ.get("SDH_BENCH_ONE_DEVICE") == "1" else dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    # the same pipeline with every output row selected (what build_run needs to write a GGUF), on a sample
-    payload = None
-    if rank == 0 and args.scan_payload_sample > 0 and mine:
-        full = scan_variants(metrics_only=False)
-        # whole K schedules (every K of a sampled (layer, tensor, variant)): the unit the builder works in
-        groups = {}
-        for c in mine:
-            groups.setdefault((c.variant, c.layer, c.kind), []).append(c)
-        keys = sorted(groups)
-        n_groups = max(1, args.scan_payload_sample // max(1, len(SCAN_K["ffn_gate"])))
-        keys = keys[:: max(1, len(keys) // n_groups)][:n_groups]
-        sample = [c for k in keys for c in groups[k]]
-        ev.run_many(groups[keys[0]], threads=args.scan_threads, params_of=lambda c: full[c.variant])
-        t1 = time.perf_counter()
-        ev.run_many(sample, threads=args.scan_threads, params_of=lambda c: full[c.variant])
-        payload = {"value": len(sample) / (time.perf_counter() - t1), "unit": "candidates/s", "candidates": len(sample),
-                   "schedules": len(keys),
-                   "note": "every output row selected and kept on the device (payload emission), whole K schedules of "
-                           "sampled (layer, tensor, variant) groups, rank 0 only"}
+    el_full = sweep(full)
+    el_lite = sweep(lite)
     ev.close()
-    assert len(allr) == len(cands)
     # bytes actually read: HBM traffic per candidate from the committed counter passes (tools/gpu/gpu_scan_pmc.sh:
-    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this sweep at 8 layers, FETCH_SIZE doubled as the guide prescribes)
-    traffic = None
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_scan_traffic.json")
-    if os.path.exists(tpath):
-        traffic = json.load(open(tpath))
-    per_c = traffic["sweep"]["hbm_bytes_per_candidate"] if traffic else None
-    # algorithmic bytes of the unit measured (a report entry from the rows the metric passes sample, SURVEY 8d per-unit
-    # figure restricted to what this path reads): per K schedule the fit's sampled row blocks once + the sampled rows
-    # of the selection and of each pass; per candidate that is the schedule's bytes over its K count
+    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over the sweep, FETCH_SIZE doubled as the guide prescribes)
+    traffic, tsrc = None, None
+    for name in ("r03_scan_traffic.json", "r02_scan_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(tpath):
+            with open(tpath) as fh:
+                traffic, tsrc = json.load(fh), "profiles/" + name
+            break
+    # algorithmic bytes per candidate, SURVEY §8d: the quantised tensor read once per K schedule (work shared across a
+    # K grid is never counted twice) + the idx / val / row_scale emitted per candidate (int32 / fp32 staging)
     q8_row = lambda n_in: n_in // 32 * 34                                                    # noqa: E731
-    def alg_bytes(c):
+    def alg_full(c):
+        n_in, n_out = scan_dims(c.layer, c.kind)
+        return n_out * q8_row(n_in) / len(SCAN_K[c.kind]) + n_out * (8 * c.K + 4)
+    # metrics-only: per K schedule the fit's sampled row blocks once + the rows the metric passes sample
+    def alg_lite(c):
         n_in, n_out = scan_dims(c.layer, c.kind)
         L = 1 << (min(n_in, n_out) - 1).bit_length()
         fit = (min(2048, L) * -(-max(n_in, n_out) // L) * q8_row(min(n_in, L))) if c.variant else 0
-        rows = 64 * (2 + 2) * q8_row(n_in)                      # selection (2 passes' rows) + eval_w + eval_x dense rows
+        rows = 64 * (2 + 2) * q8_row(n_in)
         return (fit + rows) / len(SCAN_K[c.kind])
-    alg = sum(alg_bytes(c) for c in cands)
-    out = {"metric": "scan candidates/s", "value": len(cands) / elapsed, "unit": "candidates/s", "n_gpus": world,
-           "scaling": "strong", "candidates": len(cands), "seconds": elapsed,
-           "roofline": {"bound": "hbm", "achieved": alg / elapsed / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
-                        "frac": alg / elapsed / 1e9 / (HBM_PEAK_GBS * world),
-                        "traffic": per_c * len(cands) if per_c else None,
-                        "traffic_rate_gbs": per_c * len(cands) / elapsed / 1e9 if per_c else None,
-                        "traffic_source": "profiles/r02_scan_traffic.json" if per_c else None,
-                        "note": "achieved = bytes this path has to read (fit sample blocks once per K schedule + the rows "
-                                "the metric passes sample) / sweep time; traffic = measured HBM bytes per candidate "
-                                "(counter passes over the same sweep at 8 layers) x candidates. The sweep is bound by the "
-                                "fit kernel's per-sample arithmetic (fp64 sums in sample order, ~0.77 ms per fit on 64 "
-                                "CUs) and by launch latency, not by the weight stream; measured traffic exceeds the "
-                                "algorithmic bytes because the 4 workgroups of a fit job each re-read the job's rows"},
-           "with_payload_emission": payload,
-           "config": {"workload": f"cfg5: {args.scan_layers} synthetic Mistral-7B layers x gate/up/down x "
-                                  f"K {SCAN_K} x {{coo no-base + proxy, coo base + row_scale}}, eval_cols=64 eval_x=32, Q8_0; "
-                                  "report entries only (metrics_only: rows the metric passes sample)",
-                      "host_threads_per_rank": args.scan_threads, "dense_bytes_resident_per_rank": dense_bytes,
-                      "collective": "one all_gather of %d-double records" % SC.RECORD_LEN}}
-    return out
+    a_full, a_lite = sum(map(alg_full, cands)), sum(map(alg_lite, cands))
+    peak = HBM_PEAK_GBS * world
+    roof = lambda a, el: {"bound": "hbm", "achieved": a / el / 1e9, "peak": peak, "unit": "GB/s", "frac": a / el / 1e9 / peak}  # noqa: E731
+    r_full = roof(a_full, el_full)
+    per_c = traffic["sweep"].get("hbm_bytes_per_candidate_payload_emission") if traffic else None
+    r_full.update({"traffic": per_c, "traffic_source": tsrc if per_c else None,
+                   "algorithmic_bytes_per_candidate": a_full / len(cands),
+                   "note": "achieved = (quantised tensor once per K schedule + emitted idx/val/row_scale per candidate) / "
+                           "sweep time; traffic = measured HBM bytes per candidate from the committed counter passes"})
+    r_lite = roof(a_lite, el_lite)
+    r_lite.update({"traffic": traffic["sweep"].get("hbm_bytes_per_candidate") if traffic else None,
+                   "traffic_source": tsrc, "algorithmic_bytes_per_candidate": a_lite / len(cands)})
+    return {"metric": "scan candidates/s", "value": len(cands) / el_full, "unit": "candidates/s", "n_gpus": world,
+            "scaling": "strong", "candidates": len(cands), "seconds": el_full, "roofline": r_full,
+            "upload_inclusive": {"value": len(cands) / el_up, "unit": "candidates/s", "seconds": el_up,
+                                 "dense_bytes_uploaded_per_rank": dense_bytes,
+                                 "note": "each rank materialises and uploads only its own layers' Q8_0 weights inside "
+                                         "the clock (a real scan's dominant cost; it shards with the candidates)"},
+            "metrics_only": {"value": len(cands) / el_lite, "unit": "candidates/s", "seconds": el_lite, "roofline": r_lite,
+                             "note": "report entries only: rows the metric passes sample (layer-scan / autogate use)"},
+            "config": {"workload": f"cfg5: {args.scan_layers} synthetic Mistral-7B layers x gate/up/down x "
+                                   f"K {SCAN_K} x {{coo no-base + proxy, coo base + row_scale}}, eval_cols=64 eval_x=32, Q8_0; "
+                                   "every output row selected per K (payload emission)",
+                       "host_threads_per_rank": threads, "dense_bytes_resident_per_rank": dense_bytes,
+                       "collective": "one all_gather of %d-double records" % SC.RECORD_LEN}}
 
 
 def timed_on_stream(fn, reps, stream, seeddelta, warm=None):
@@ -438,11 +467,6 @@ def run_prefill(args, dev):
     T = 512
     st = torch.cuda.Stream(device=dev)
     sp = st.cuda_stream
-    pmc = None
-    ppath = os.path.join(ROOT, "profiles", "r02_prefill_pmc.json")
-    if os.path.exists(ppath):
-        with open(ppath) as fh:
-            pmc = json.load(fh)
     legs = {}
     for name in PREFILL_WORKLOADS:
         p = config_payload(name)
@@ -473,8 +497,6 @@ def run_prefill(args, dev):
                              "frac": fl / ms / 1e9 / MFMA_F16_PEAK_TFLOPS,
                              "note": "whole call (W0 contraction + residual epilogue) against the dense f16 MFMA peak"}
             leg[tag] = d
-        if pmc and name in pmc:
-            leg["pmc"] = pmc[name]
         legs[name] = leg
         w.close()
         del x, y
@@ -509,8 +531,8 @@ def scan_cpu_baseline(budget_s):
         if el >= budget_s or n >= 60:
             break
     return {"value": n / el, "unit": "candidates/s", "cores": cores, "kind": "port",
-            "compare_with": "with_payload_emission (every output row selected: the only form the reference has); "
-                            "the metrics-only `value` has no CPU counterpart",
+            "compare_with": "scan.value (every output row selected: the only form the reference has); "
+                            "metrics_only has no CPU counterpart",
             "sample": f"{n} candidates = K schedule {SCAN_K['ffn_gate']} of ffn_gate 4096->14336 Q8_0 (COO, base fitted once: "
                       f"2048 samples x 4 perms, row_scale, eval_cols=64, eval_x=32) in {el:.1f}s; base fit and evals "
                       f"single-threaded as in the reference, row loop on {cores} threads"}
@@ -730,17 +752,54 @@ def main():
                        "parallelism": "replicas only" if world > 1 else "single GPU"},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        detail = dict(line)
+        for key, leg in (("pcie_inclusive", host_io), ("ffn_block", ffn), ("ffn_stack", stack), ("prefill", prefill), ("scan", scan)):
+            if leg is not None:
+                detail[key] = leg
+        # The long form goes to a file; the printed line stays small (a few KB) so that whoever captures the tail of
+        # stdout gets ALL of it: headline fields, roofline, cpu_baseline, and one compact object per leg.
+        dpath = os.environ.get("SDH_BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json"))
+        try:
+            with open(dpath, "w") as fh:
+                json.dump(detail, fh, indent=1)
+            line["detail_file"] = os.path.relpath(dpath, ROOT)
+        except OSError:
+            line["detail_file"] = None
+        r3 = lambda v: None if v is None else float("%.4g" % v)         # noqa: E731
+        if roof is not None:
+            line["roofline"] = {k: (r3(v) if isinstance(v, float) else v) for k, v in roof.items() if k not in ("timing",)}
+        if cpu is not None:
+            line["cpu_baseline"] = dict(cpu, value=r3(cpu["value"]), sample=cpu["sample"][:120])
         if host_io is not None:
-            line["pcie_inclusive"] = host_io
+            line["pcie_inclusive"] = {"value": r3(host_io["value"]), "unit": "tok/s"}
         if ffn is not None:
-            line["ffn_block"] = ffn
+            line["ffn_block"] = {"value": r3(ffn["value"]), "unit": ffn["unit"], "us_per_layer": r3(ffn["us_per_layer"]),
+                                 "bound": "hbm", "frac": r3(ffn["roofline"]["frac"]), "timing_consistent": ffn["timing_consistent"]}
         if stack is not None:
-            line["ffn_stack"] = stack
+            line["ffn_stack"] = {"value": r3(stack["value"]), "unit": stack["unit"], "us_per_layer": r3(stack["us_per_layer"]),
+                                 "bound": "hbm", "frac": r3(stack["roofline"]["frac"]), "handoff_timeouts": stack["handoff_timeouts"]}
         if prefill is not None:
-            line["prefill"] = prefill
+            legs = {}
+            for name, leg in prefill["workloads"].items():
+                best = min(("default", "w0_mfma", "rows_lds"), key=lambda t: leg[t]["ms"] if t in leg else 1e30)
+                legs[name] = {"ms": r3(leg["default"]["ms"]), "hbm_frac": r3(leg["default"]["hbm"]["frac"]),
+                              "mfma_ms": r3(leg["w0_mfma"]["ms"]), "mfma_frac": r3(leg["w0_mfma"]["mfma"]["frac"]),
+                              "rows_ms": r3(leg["rows_lds"]["ms"]), "best": best}
+            line["prefill"] = {"tokens": 512, "unit": "ms per ubatch and tensor", "workloads": legs}
         if scan is not None:
-            line["scan"] = scan
-        print(json.dumps(line), flush=True)
+            sc = {"value": r3(scan["value"]), "unit": scan["unit"], "n_gpus": scan["n_gpus"], "scaling": scan["scaling"],
+                  "candidates": scan["candidates"], "seconds": r3(scan["seconds"]), "bound": "hbm",
+                  "frac": r3(scan["roofline"]["frac"]), "traffic_per_candidate": scan["roofline"]["traffic"],
+                  "upload_inclusive": r3(scan["upload_inclusive"]["value"]), "metrics_only": r3(scan["metrics_only"]["value"]),
+                  "host_threads_per_rank": scan["config"]["host_threads_per_rank"]}
+            if scan.get("cpu_baseline"):
+                cb = scan["cpu_baseline"]
+                sc["cpu_baseline"] = {"value": r3(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"]}
+            line["scan"] = sc
+        out = json.dumps(line)
+        assert len(out) < 6000, len(out)
+        sys.stdout.flush()
+        print(out, flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

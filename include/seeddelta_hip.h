@@ -28,7 +28,10 @@
 extern "C" {
 #endif
 
-#define SDH_ABI_VERSION 1
+/* 2: stream == NULL on device-I/O calls is HIP's legacy default stream (version 1: the library's private stream);
+ *    SDH_FWD_NO_SPMM selects the row kernels' arithmetic; sdh_scan_params.reserved0 became kgrid_draws;
+ *    sdh_debug_alloc_calls added. INTEGRATION.md "Migration notes". */
+#define SDH_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------------------ */
 typedef enum sdh_status {
@@ -177,6 +180,9 @@ int     sdh_forward_noalloc(sdh_weight * w,
                             float * y, int64_t ldy,
                             int flags, void * stream);
 int64_t sdh_noalloc_scratch_bytes(void);   /* SDH_NOALLOC_SCRATCH_BYTES of the loaded library */
+/* Test hook (no counterpart in the reference): hipMalloc + hipHostMalloc + hipFree calls the library has made in this
+ * process so far. tests/test_zz_no_alloc.py reads it around sdh_forward_noalloc calls and asserts a difference of 0. */
+int64_t sdh_debug_alloc_calls(void);
 
 /* Number of non-finite outputs produced by the most recent sdh_forward on this handle
  * (the reference's llama_seeddelta_nan_count, src/llama-seeddelta.cpp:77,382, per call).
@@ -237,9 +243,16 @@ int sdh_glu(int act, const float * g, const float * u, float * y, int64_t n, voi
  * 4096} and at most 4 blocks, I16/F16 payload with K (or nb*block) a multiple of 8 up to 1024, one scheme;
  * otherwise create returns SDH_ERR_UNSUPPORTED and the caller evaluates layer by layer. x, y: device pointers,
  * n_embd floats. The handles must outlive the stack. One call at a time per stack (it owns its hand-off buffers);
- * not capturable into a HIP graph (SDH_ERR_UNSUPPORTED on a capturing stream). sdh_ffn_stack_status waits for the
- * last call and returns the number of non-finite node outputs (counted and, with SDH_FWD_ZERO_NONFINITE, zeroed per
- * node as in sdh_ffn_forward) and of hand-off waits that timed out (0 unless the grid could not run concurrently). */
+ * not capturable into a HIP graph (SDH_ERR_UNSUPPORTED on a capturing stream).
+ * ONE TENANT: the launch is a persistent grid of one workgroup per CU whose phases wait for one another, so it is
+ * only correct while all its workgroups are resident at once. That is checked once per stack (occupancy query + a
+ * census launch on the first call), not per call: while a stack call runs, nothing else may occupy the GPU — no
+ * kernel on another stream, no second stack in flight, no other process on the device. If co-residency is lost
+ * anyway, every hand-off wait is bounded (500 us), NaN is published in place of the missing value, the call still
+ * returns SDH_OK (it is asynchronous) and y is not valid. sdh_ffn_stack_status waits for the last call and returns
+ * the number of non-finite node outputs (counted and, with SDH_FWD_ZERO_NONFINITE, zeroed per node as in
+ * sdh_ffn_forward) and the number of hand-off waits of THAT call that timed out: a caller that cannot guarantee the
+ * single tenant checks it (non-zero: discard y and evaluate the layers with sdh_ffn_forward). */
 typedef struct sdh_ffn_stack sdh_ffn_stack;
 int     sdh_ffn_stack_create(sdh_weight * const * gate, sdh_weight * const * up, sdh_weight * const * down, int n_layers,
                              sdh_ffn_stack ** out);

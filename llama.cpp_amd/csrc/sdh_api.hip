@@ -27,6 +27,8 @@ LibState & lib() {
     return s;
 }
 
+std::atomic<long long> g_alloc_calls{0};
+
 static std::mutex g_mu;
 
 // ---- sdh_forward_noalloc: the scratch its kernels use instead of a hipMalloc'ed workspace --------------
@@ -723,6 +725,9 @@ static int ffn_gate_up(sdh_weight * hg, sdh_weight * hu, int act, const float * 
     DeviceWeight * g = reinterpret_cast<DeviceWeight *>(hg);
     DeviceWeight * u = reinterpret_cast<DeviceWeight *>(hu);
     const int64_t n_ff = g->n_out;
+    // base_ready ("the workspace already holds this call's base terms") lives only inside this function: whatever
+    // way it is left, both handles have it cleared, so an unrelated sdh_forward can never see a stale claim
+    struct ClearBaseReady { DeviceWeight * a, * b; ~ClearBaseReady() { a->base_ready = b->base_ready = false; } } clear_ready{g, u};
     if (act == SDH_ACT_GELU) { int rc = ensure_gelu_table(ls); if (rc != SDH_OK) return rc; }
     ls.ffn_last_fused = 0;
     int rc = 1;
@@ -1035,6 +1040,7 @@ int sdh_forward_noalloc(sdh_weight * h, const float * x, int64_t ldx, int64_t n_
 }
 
 int64_t sdh_noalloc_scratch_bytes(void) { return (int64_t) NOALLOC_SCRATCH_BYTES; }
+int64_t sdh_debug_alloc_calls(void) { return (int64_t) sdh::g_alloc_calls.load(); }
 
 int sdh_ffn_gate_up(sdh_weight * hg, sdh_weight * hu, int act, const float * x, int64_t ldx, int64_t n_tokens,
                     float * h, int64_t ldh, int flags, void * stream) {

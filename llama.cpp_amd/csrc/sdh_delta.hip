@@ -30,6 +30,8 @@
 //   delta_exact_kernel       — verification mode: one lane per output, the reference's sequential
 //                              order with separately rounded multiply and add; bit-identical.
 #include "sdh_internal.h"
+#include <mutex>
+#include <unordered_map>
 #include <algorithm>
 #include <type_traits>
 #include "sdh_delta_dev.h"
@@ -674,6 +676,20 @@ bool delta_vector_shape(const DeltaParams & p, bool is_block, int * G_out, int *
     return vec_ok;
 }
 
+// Raise a kernel's dynamic-LDS limit to the 160 KiB of a gfx950 CU, once per kernel. false = this device does not
+// grant it (a 64 KiB LDS part): the LDS rows forms "do not fit" and the caller takes the per-token kernels.
+static bool lds_tile_ok(const void * kern) {
+    static std::mutex mu;
+    static std::unordered_map<const void *, bool> seen;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = seen.find(kern);
+    if (it != seen.end()) return it->second;
+    const bool ok = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    if (!ok) (void) hipGetLastError();
+    seen[kern] = ok;
+    return ok;
+}
+
 template <typename IDX_T, typename VAL_T, bool BLOCK>
 static int launch_typed(const DeltaLaunch & a, DeltaParams & p, hipStream_t s) {
     if (a.exact_order) {
@@ -717,8 +733,8 @@ static int launch_typed(const DeltaLaunch & a, DeltaParams & p, hipStream_t s) {
             if (steps == 1) kern = nt == 8 ? delta_rows_coo_lds_kernel<IDX_T, VAL_T, 1, 8> : nt == 4 ? delta_rows_coo_lds_kernel<IDX_T, VAL_T, 1, 4> : delta_rows_coo_lds_kernel<IDX_T, VAL_T, 1, 2>;
             else if constexpr (sizeof(VAL_T) == 2 && sizeof(IDX_T) == 2)
                 kern = nt == 8 ? delta_rows_coo_lds_kernel<IDX_T, VAL_T, 2, 8> : nt == 4 ? delta_rows_coo_lds_kernel<IDX_T, VAL_T, 2, 4> : delta_rows_coo_lds_kernel<IDX_T, VAL_T, 2, 2>;
-            if (kern) {
-                SDH_HIP_CHECK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            // a device whose LDS cannot be raised to the tile size ("does not fit"): the per-token kernels below
+            if (kern && lds_tile_ok((const void *) kern)) {
                 hipLaunchKernelGGL(kern, dim3((unsigned) tiles, gl), dim3(1024), col * nt + (size_t) nt * 4, s, p, a.T, rows_per_wg);   // + the zero row
                 SDH_HIP_CHECK(hipGetLastError());
                 return SDH_OK;
@@ -764,10 +780,11 @@ static int launch_typed(const DeltaLaunch & a, DeltaParams & p, hipStream_t s) {
             } else {                                        // G < 64: one step per lane
                 kern = nt == 8 ? delta_rows_block_lds_kernel<IDX_T, VAL_T, 1, 8, 0> : nt == 4 ? delta_rows_block_lds_kernel<IDX_T, VAL_T, 1, 4, 0> : delta_rows_block_lds_kernel<IDX_T, VAL_T, 1, 2, 0>;
             }
-            SDH_HIP_CHECK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            hipLaunchKernelGGL(kern, dim3((unsigned) tiles, gl), dim3(1024), col * nt, s, p, a.T, rows_per_wg);
-            SDH_HIP_CHECK(hipGetLastError());
-            return SDH_OK;
+            if (kern && lds_tile_ok((const void *) kern)) {
+                hipLaunchKernelGGL(kern, dim3((unsigned) tiles, gl), dim3(1024), col * nt, s, p, a.T, rows_per_wg);
+                SDH_HIP_CHECK(hipGetLastError());
+                return SDH_OK;
+            }
         }
     }
     if (vec_ok) {
@@ -865,7 +882,7 @@ int launch_delta_rows_pair(const DeviceWeight & g, const DeviceWeight & u, const
     void (*kern)(const DeltaParams, const DeltaParams, int64_t, int, int, const uint16_t *, float *, int64_t) =
         is_block ? (nt == 8 ? delta_rows_block_lds_pair_kernel<8> : nt == 4 ? delta_rows_block_lds_pair_kernel<4> : delta_rows_block_lds_pair_kernel<2>)
                  : (nt == 8 ? delta_rows_coo_lds_pair_kernel<1, 8> : nt == 4 ? delta_rows_coo_lds_pair_kernel<1, 4> : delta_rows_coo_lds_pair_kernel<1, 2>);
-    SDH_HIP_CHECK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (!lds_tile_ok((const void *) kern)) return 1;           // does not fit this device's LDS: the caller goes node by node
     hipLaunchKernelGGL(kern, dim3((unsigned) tiles, gl), dim3(1024), col * nt + (is_block ? 0 : (size_t) nt * 4), s, pg, pu, ag.T, rows_per_wg, act, gelu_tab, h, ldh);
     SDH_HIP_CHECK(hipGetLastError());
     return SDH_OK;

@@ -1,6 +1,7 @@
 // sdh_internal.h — private declarations shared by the translation units of libseeddelta_hip.so.
 // gfx950 (MI355X) only. Nothing here crosses the C ABI.
 #pragma once
+#include <atomic>
 #include <cstring>
 #include <exception>
 #include <new>
@@ -12,6 +13,16 @@
 #include "../../include/seeddelta_hip.h"
 
 namespace sdh {
+
+// ---- allocation census: every hipMalloc / hipHostMalloc / hipFree of the library goes through these, so that
+// sdh_debug_alloc_calls() can state how many a call sequence made (tests/test_zz_no_alloc.py asserts zero)
+extern std::atomic<long long> g_alloc_calls;
+inline hipError_t counted_malloc(void ** p, size_t n) { g_alloc_calls.fetch_add(1, std::memory_order_relaxed); return hipMalloc(p, n); }
+inline hipError_t counted_host_malloc(void ** p, size_t n, unsigned f) { g_alloc_calls.fetch_add(1, std::memory_order_relaxed); return hipHostMalloc(p, n, f); }
+inline hipError_t counted_free(void * p) { if (p) g_alloc_calls.fetch_add(1, std::memory_order_relaxed); return hipFree(p); }
+#define hipMalloc(p, n) ::sdh::counted_malloc((void **) (p), (n))
+#define hipHostMalloc(p, n, f) ::sdh::counted_host_malloc((void **) (p), (n), (f))
+#define hipFree(p) ::sdh::counted_free((void *) (p))
 
 // ---- error plumbing ----------------------------------------------------------------------
 void set_error(const char * fmt, ...);

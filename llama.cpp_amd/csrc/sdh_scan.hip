@@ -1466,6 +1466,13 @@ static int scan_grid_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * 
     std::memset(outs, 0, sizeof(*outs) * (size_t) nK);
     if (p.scheme != 0 && p.scheme != 1) { set_error("scan: scheme must be 0 (coo) or 1 (block)"); return SDH_ERR_INVALID; }
     if (p.scheme == 1 && p.block <= 0) { set_error("scan: block must be > 0"); return SDH_ERR_INVALID; }
+    // rejected before any draw or state write: a caller that falls back to one call per budget starts from the
+    // generator state and the handle contents it had before this call
+    const bool clamp_applies = p.delta_norm_clamp_down > 0.0 && p.kind == 2 && p.scheme == 0;   // ffn_down, d_val non-empty
+    if (clamp_applies && nK > 1) {
+        set_error("scan: delta_norm_clamp_down rescales the residual values of each K: evaluate such budgets one by one");
+        return SDH_ERR_UNSUPPORTED;
+    }
 
     int64_t K_eff = 0, keep = 0;                             // of the largest budget: what is selected and stored
     int64_t K_eff_j[SDH_SCAN_MAX_K], keep_j[SDH_SCAN_MAX_K];
@@ -1568,11 +1575,6 @@ static int scan_grid_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * 
     // ---- selection ------------------------------------------------------------------------------------
     // select(rows_dev, n_sel): rows_dev == null selects every output row into [n_out] slots (the payload);
     // otherwise only the listed rows, into compact slots [n_sel] in list order (metrics_only)
-    const bool clamp_applies = p.delta_norm_clamp_down > 0.0 && p.kind == 2 && p.scheme == 0;   // ffn_down, d_val non-empty
-    if (clamp_applies && nK > 1) {
-        set_error("scan: delta_norm_clamp_down rescales the residual values of each K: evaluate such budgets one by one");
-        return SDH_ERR_UNSUPPORTED;
-    }
     const bool metrics_only = p.metrics_only != 0 && !clamp_applies;
     const int compact = metrics_only ? 1 : 0;
     const size_t r_bytes = ((size_t) n_in * 4 + 15) & ~(size_t) 15;

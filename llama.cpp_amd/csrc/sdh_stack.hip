@@ -84,7 +84,8 @@ struct StackArgs {
     const uint16_t * gelu_tab;
     int zero_nf;
     int * nf;                                       // [n_layers][3] non-finite counters
-    unsigned * ctr;                                 // [0] census arrivals, [1] census failures, [2] timeouts
+    unsigned * ctr;                                 // [0] census arrivals, [1] census failures
+    unsigned * tmo;                                 // hand-off waits of THIS call that timed out (cleared with nf before every launch)
     int n_dwg;                                      // workgroups that own down rows (the rest of the row workgroups own gate/up rows)
     int census;
     unsigned long long * stamps;                    // diagnostic build (-DSDH_STK_STAMPS): [7 samples][n_layers][8] real-time ticks
@@ -318,7 +319,7 @@ void ffn_stack_kernel(const StackArgs a) {
                 for (int r = 0; r < E; ++r) y[r] = used[r] ? a.x[gi[r]] : 0.0f;
             } else {
                 if (!stk_poll<E>(src, gi, used, tag, y)) {     // 3B workgroups: they poll directly
-                    atomicAdd(&a.ctr[2], 1u);
+                    atomicAdd(a.tmo, 1u);
 #pragma unroll
                     for (int r = 0; r < E; ++r) y[r] = qnan;
                 }
@@ -396,7 +397,7 @@ void ffn_stack_kernel(const StackArgs a) {
             } else {
                 float xv[STK_MAXX] = {};
                 if (!stk_wait<STK_MAXX>(a.XG, xi, xu, tag, xv)) {
-                    atomicAdd(&a.ctr[2], 1u);
+                    atomicAdd(a.tmo, 1u);
 #pragma unroll
                     for (int k = 0; k < STK_MAXX; ++k) xv[k] = qnan;
                 }
@@ -425,7 +426,7 @@ void ffn_stack_kernel(const StackArgs a) {
             }
             const bool ok = stk_wait<2 * STK_MAXP_GU>(a.VGU, vi, vu, tag, vv);
             STK_STAMP(smp, l, 3);
-            if (!ok) atomicAdd(&a.ctr[2], 1u);
+            if (!ok) atomicAdd(a.tmo, 1u);
 #pragma unroll
             for (int p = 0; p < STK_MAXP_GU; ++p) {
                 if (rok[p] && l_in == 0) {
@@ -490,7 +491,7 @@ void ffn_stack_kernel(const StackArgs a) {
             {
                 float hv[STK_MAXH] = {};
                 if (!stk_wait<STK_MAXH>(a.HG, hi, hu, tag, hv)) {
-                    atomicAdd(&a.ctr[2], 1u);
+                    atomicAdd(a.tmo, 1u);
 #pragma unroll
                     for (int k = 0; k < STK_MAXH; ++k) hv[k] = qnan;
                 }
@@ -519,7 +520,7 @@ void ffn_stack_kernel(const StackArgs a) {
             }
             const bool okv = stk_wait<STK_MAXP_D * STK_MAXB>(a.VD, vi, vu, tag, vv);
             STK_STAMP(smp, l, 3);
-            if (!okv) atomicAdd(&a.ctr[2], 1u);
+            if (!okv) atomicAdd(a.tmo, 1u);
             const bool last = l + 1 == a.n_layers;
 #pragma unroll
             for (int p = 0; p < STK_MAXP_D; ++p) {
@@ -680,7 +681,7 @@ int stack_create(const sdh_weight * const * gate, const sdh_weight * const * up,
     const size_t BL = (size_t) st->B * st->L;
     if ((rc = dmalloc((void **) &st->XG, (size_t) st->n_embd * 8)) || (rc = dmalloc((void **) &st->HG, (size_t) st->n_ff * 8)) ||
         (rc = dmalloc((void **) &st->VGU, 2 * BL * 8)) || (rc = dmalloc((void **) &st->VD, BL * 8)) ||
-        (rc = dmalloc((void **) &st->nf, (size_t) n_layers * 3 * sizeof(int))) || (rc = dmalloc((void **) &st->ctr, 16)) ||
+        (rc = dmalloc((void **) &st->nf, ((size_t) n_layers * 3 + 1) * sizeof(int))) || (rc = dmalloc((void **) &st->ctr, 16)) ||
         (rc = dmalloc((void **) &st->stamps, (size_t) 7 * n_layers * 8 * sizeof(unsigned long long))) ||
         (rc = dmalloc((void **) &st->dev_layers, (size_t) n_layers * sizeof(StackLayer)))) { stack_free(st); return rc; }
     std::vector<StackLayer> hl((size_t) n_layers);
@@ -712,6 +713,7 @@ int stack_forward(FfnStack * st, int act, const uint16_t * gelu_tab, const float
     for (int t = 0; t < 3; ++t) a.pd[t] = st->w[t][0]->pack;
     a.act = act; a.gelu_tab = gelu_tab; a.zero_nf = zero_nf ? 1 : 0;
     a.nf = st->nf; a.ctr = st->ctr; a.n_dwg = st->n_dwg; a.stamps = st->stamps;
+    a.tmo = (unsigned *) (st->nf + (size_t) st->n_layers * 3);      // behind the per-node counters: one memset clears both
     if (!st->census_ok) {
         int occ = 0;
         SDH_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, STK_WAVES * 64, st->lds));
@@ -731,7 +733,7 @@ int stack_forward(FfnStack * st, int act, const uint16_t * gelu_tab, const float
     if (st->tag > 0xFFFFFFFFu - 2u * (unsigned) st->n_layers - 2u) st->tag = 0;
     a.tag0 = st->tag + 1;
     st->tag += (unsigned) st->n_layers;
-    SDH_HIP_CHECK(hipMemsetAsync(st->nf, 0, (size_t) st->n_layers * 3 * sizeof(int), s));
+    SDH_HIP_CHECK(hipMemsetAsync(st->nf, 0, ((size_t) st->n_layers * 3 + 1) * sizeof(int), s));       // per-node counters and this call's timeouts
     hipLaunchKernelGGL(kern, dim3(st->grid), dim3(STK_WAVES * 64), st->lds, s, a);
     SDH_HIP_CHECK(hipGetLastError());
     st->last_stream = s;
@@ -740,14 +742,12 @@ int stack_forward(FfnStack * st, int act, const uint16_t * gelu_tab, const float
 
 int stack_status(FfnStack * st, int64_t * nonfinite, int64_t * timeouts) {
     SDH_HIP_CHECK(hipStreamSynchronize(st->last_stream));
-    std::vector<int> nf((size_t) st->n_layers * 3);
-    unsigned ctr[4] = {0, 0, 0, 0};
+    std::vector<int> nf((size_t) st->n_layers * 3 + 1);
     SDH_HIP_CHECK(hipMemcpy(nf.data(), st->nf, nf.size() * sizeof(int), hipMemcpyDeviceToHost));
-    SDH_HIP_CHECK(hipMemcpy(ctr, st->ctr, sizeof(ctr), hipMemcpyDeviceToHost));
     int64_t n = 0;
-    for (int v : nf) n += v;
+    for (size_t i = 0; i + 1 < nf.size(); ++i) n += nf[i];
     if (nonfinite) *nonfinite = n;
-    if (timeouts) *timeouts = ctr[2];
+    if (timeouts) *timeouts = (unsigned) nf.back();           // of the last call only
     return SDH_OK;
 }
 

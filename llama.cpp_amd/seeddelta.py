@@ -32,7 +32,7 @@ FWD_DEVICE_IO, FWD_HOST_IO, FWD_ZERO_NONFINITE, FWD_EXACT_ORDER, FWD_W0_MFMA, FW
 ABI_SYMBOLS = [
     "sdh_init", "sdh_abi_version", "sdh_last_error", "sdh_device_synchronize", "sdh_library_stream",
     "sdh_weight_create", "sdh_weight_destroy", "sdh_weight_op_kind", "sdh_weight_payload_bytes",
-    "sdh_forward", "sdh_forward_noalloc", "sdh_noalloc_scratch_bytes", "sdh_nonfinite_count", "sdh_w0_tile", "sdh_ffn_forward", "sdh_ffn_gate_up", "sdh_ffn_last_fused", "sdh_glu",
+    "sdh_forward", "sdh_forward_noalloc", "sdh_noalloc_scratch_bytes", "sdh_debug_alloc_calls", "sdh_nonfinite_count", "sdh_w0_tile", "sdh_ffn_forward", "sdh_ffn_gate_up", "sdh_ffn_last_fused", "sdh_glu",
     "sdh_ffn_stack_create", "sdh_ffn_stack_destroy", "sdh_ffn_stack_forward", "sdh_ffn_stack_status", "sdh_ffn_stack_payload_bytes",
     "sdh_profile_enable", "sdh_profile_read", "sdh_profile_span_begin", "sdh_profile_span_end",
     "sdh_dense_create", "sdh_dense_destroy", "sdh_dense_bytes",
@@ -123,6 +123,7 @@ def load_library(path: str = LIB_PATH):
                                 C.c_int, C.c_void_p]
     lib.sdh_forward_noalloc.argtypes = lib.sdh_forward.argtypes
     lib.sdh_noalloc_scratch_bytes.restype = C.c_int64
+    lib.sdh_debug_alloc_calls.restype = C.c_int64
     lib.sdh_ffn_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64,
                                     C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
     lib.sdh_ffn_gate_up.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64,

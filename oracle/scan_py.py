@@ -122,6 +122,13 @@ class Engine:
         return f
 
     # ---- RNG ----
+    def fork(self) -> "Engine":
+        """A second oracle engine at the same stream position (peek at draws without consuming them)."""
+        assert self.which == "oracle"
+        e = Engine("oracle", 0)
+        C.memmove(C.byref(e._state), C.byref(self._state), C.sizeof(SdsoRng))
+        return e
+
     def u32(self) -> int:
         return int(self._fn("rng_u32", C.c_uint32)(self.rng))
 
@@ -249,6 +256,26 @@ def select_rows(W, fit: Optional[Fit], scheme: int, K_or_keep: int, block: int, 
     a = fit.arrays() if fit is not None else None
     lib.sdso_select_rows(C.byref(t), C.byref(a) if a is not None else None, _p(_f32(w_scale)), C.c_int(scheme),
                          C.c_int64(K_or_keep), C.c_int64(block), _p(idx), _p(val), _p(rs), C.c_int(nth))
+    return idx, val, rs
+
+
+def select_rows_list(W, fit: Optional[Fit], scheme: int, K_or_keep: int, block: int, row_scale: bool, rows, w_scale=None,
+                     out=None):
+    """The run_trial column loop for the listed rows only; the [n_out] arrays (zero elsewhere, or `out` from an
+    earlier call) receive them in the rows' own slots. For full-size tests: the evaluators read nothing else."""
+    n_in, n_out = w_dims(W)
+    lib = oracle_lib()
+    if out is None:
+        idx = np.zeros((n_out, K_or_keep), dtype=np.int32)
+        val = np.zeros((n_out, K_or_keep, block) if scheme == 1 else (n_out, K_or_keep), dtype=np.float32)
+        rs = np.ones(n_out, dtype=np.float32) if row_scale else None
+    else:
+        idx, val, rs = out
+    rows = np.ascontiguousarray(rows, dtype=np.int64)
+    t = w_tensor(W)
+    a = fit.arrays() if fit is not None else None
+    lib.sdso_select_rows_list(C.byref(t), C.byref(a) if a is not None else None, _p(_f32(w_scale)), C.c_int(scheme),
+                              C.c_int64(K_or_keep), C.c_int64(block), _p(idx), _p(val), _p(rs), _p(rows), C.c_int64(len(rows)))
     return idx, val, rs
 
 

@@ -329,6 +329,7 @@ static inline float base_weight(const sdso_base * a, int tall, int64_t row, int6
 typedef struct {
     const sdo_tensor * W; const sdso_base * base; const float * ws; int scheme; int64_t K, block;
     int32_t * idx; float * val; float * rs; int64_t r0, r1;
+    const int64_t * rows;          /* NULL: rows r0..r1-1; else rows[r0..r1-1] (outputs still stored at the row's own slot) */
 } select_job;
 
 static void * select_worker(void * arg) {
@@ -338,7 +339,8 @@ static void * select_worker(void * arg) {
     float * w = (float *) malloc((size_t) n_in * sizeof(float));
     float * r = (float *) malloc((size_t) n_in * sizeof(float));
     int32_t * top = (int32_t *) malloc((size_t) (j->K > 0 ? j->K : 1) * sizeof(int32_t));
-    for (int64_t row = j->r0; row < j->r1; ++row) {
+    for (int64_t rr0 = j->r0; rr0 < j->r1; ++rr0) {
+        const int64_t row = j->rows ? j->rows[rr0] : rr0;
         sdso_read_row(j->W, row, w);
         double dot = 0.0, nn = 0.0;
         const float * src = w;
@@ -406,12 +408,22 @@ void sdso_select_rows(const sdo_tensor * W, const sdso_base * base, const float 
     pthread_t th[64];
     for (int t = 0; t < nth; ++t) {
         select_job j = { W, base, w_scale, scheme, K_or_keep, block, idx, val, row_scale,
-                         n_out * t / nth, n_out * (t + 1) / nth };
+                         n_out * t / nth, n_out * (t + 1) / nth, NULL };
         jobs[t] = j;
         if (nth == 1) select_worker(&jobs[0]);
         else pthread_create(&th[t], NULL, select_worker, &jobs[t]);
     }
     if (nth > 1) for (int t = 0; t < nth; ++t) pthread_join(th[t], NULL);
+}
+
+/* The same column loop for a LIST of rows (each one independent of the others in run_trial): outputs go to the
+ * rows' own slots of the [n_out] arrays, other slots are left untouched. Lets a full-size parity test restate only
+ * the rows the metric passes sample (sd_eval.cpp:138, :1052). */
+void sdso_select_rows_list(const sdo_tensor * W, const sdso_base * base, const float * w_scale, int scheme,
+                           int64_t K_or_keep, int64_t block, int32_t * idx, float * val, float * row_scale,
+                           const int64_t * rows, int64_t n_rows) {
+    select_job j = { W, base, w_scale, scheme, K_or_keep, block, idx, val, row_scale, 0, n_rows, rows };
+    select_worker(&j);
 }
 
 /* ===== metrics ============================================================================= */

@@ -48,6 +48,10 @@ void    sdso_apply_base_block(const sdso_base * a, int64_t b, const float * x, f
 void    sdso_select_rows(const sdo_tensor * W, const sdso_base * base, const float * w_scale, int scheme,
                          int64_t K_or_keep, int64_t block, int32_t * idx, float * val, float * row_scale /* or NULL */,
                          int nth);
+/* the same loop for a list of rows; outputs land in the rows' own slots of the [n_out] arrays */
+void    sdso_select_rows_list(const sdo_tensor * W, const sdso_base * base, const float * w_scale, int scheme,
+                              int64_t K_or_keep, int64_t block, int32_t * idx, float * val, float * row_scale /* or NULL */,
+                              const int64_t * rows, int64_t n_rows);
 /* weight-space metrics on the given rows; per_row (optional) receives w_norm2, wh_norm2, dot per row;
  * out5 = rel_l2_mean, rel_l2_p95, cos_mean, cos_p05, norm_ratio_mean */
 void    sdso_eval_w_rows(const sdo_tensor * W, const sdso_base * base, int scheme, const int32_t * idx, const float * val,

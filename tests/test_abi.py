@@ -31,7 +31,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for sym in declared_symbols():
         assert hasattr(lib, sym), f"{sym} declared in include/seeddelta_hip.h but not exported"
     lib.sdh_abi_version.restype = C.c_int
-    assert lib.sdh_abi_version() == 1
+    assert lib.sdh_abi_version() == 2
 
 
 def test_struct_layouts_match_header():

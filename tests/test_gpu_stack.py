@@ -115,3 +115,41 @@ def test_stack_declines_shapes_it_is_not_built_for(hip):
     odd = hip.SeedDeltaWeight(make_payload(1024, 2304, scheme="coo", K=20, base=True, seed=2))   # K not a multiple of 8
     with pytest.raises(hip.SeedDeltaError, match=r"\(-4\)"):
         hip.FfnStack([(odd, odd, ws[0][2])])
+
+
+def test_stack_call_under_contention_reports_its_own_timeouts(hip):
+    """The stack kernel is only correct while all its workgroups are resident at once (header: one tenant per GPU while
+    a stack call runs). A call made while another stream saturates the GPU either still finds its workgroups co-resident
+    (timeouts == 0: the output must be right) or has hand-off waits time out (bounded at 500 us each): then
+    sdh_ffn_stack_status says so FOR THAT CALL — and the next call, on an idle GPU, reports 0 again and is right."""
+    torch = pytest.importorskip("torch")
+    n_embd, n_ff = 4096, 14336
+    ps, ws = make_layers(hip, 3, n_embd, n_ff, "coo", 128, seed=1300)
+    st = hip.FfnStack(ws)
+    x = make_x(n_embd, 1, seed=9)
+    want = chain_node_by_node(hip, torch, ws, x, 0)[-1]
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.full((1, n_embd), float("nan"), dtype=torch.float32, device="cuda")
+    s, side = torch.cuda.Stream(), torch.cuda.Stream()
+    st.forward_device(0, xd.data_ptr(), yd.data_ptr(), stream=s.cuda_stream)        # census + a clean call
+    assert st.status() == (0, 0)
+    a = torch.randn((8192, 8192), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(12):
+            b = a @ a                                                               # ~10 ms each: the GPU is full for the call below
+    yd.fill_(float("nan"))
+    st.forward_device(0, xd.data_ptr(), yd.data_ptr(), stream=s.cuda_stream)
+    nf, timeouts = st.status()
+    y = yd.cpu().numpy()
+    if timeouts == 0:
+        assert np.array_equal(bits(y), bits(want))
+    else:
+        print(f"\ncontended stack call: {timeouts} hand-off waits timed out, {nf} non-finite node outputs")
+    side.synchronize()
+    del b
+    yd.fill_(float("nan"))
+    st.forward_device(0, xd.data_ptr(), yd.data_ptr(), stream=s.cuda_stream)
+    assert st.status() == (0, 0)                                                    # per call, not cumulative
+    assert np.array_equal(bits(yd.cpu().numpy()), bits(want))
+    st.close()

@@ -23,29 +23,45 @@ def run_noalloc(torch, w, x, flags=0, stream=0):
 
 @pytest.mark.parametrize("cfg", ["cfg4_mistral_down_coo_k128", "cfg4_mistral_gate_block16_k128", "cfg1_gemma1b_down_block16_k128"])
 def test_noalloc_matches_forward_two_calls_in_a_row(hip, cfg):
+    """Calls of different sizes in a row on the scratch the previous one left behind, against sdh_forward on a
+    handle of its own. "Allocates nothing" is asserted two ways around the no-alloc calls alone (x / y allocated
+    beforehand, the reference results computed beforehand): the library's own census of hipMalloc / hipHostMalloc /
+    hipFree calls (sdh_debug_alloc_calls) must not move, and the device's free memory must not move by more than
+    2 MiB — the workspace sdh_forward grows for the 700-token call is 44.8 MiB (700 x B*L*4 = 64 KiB), and a control
+    at the end shows both detectors see exactly that growth. All calls are issued on ONE stream: calls that overlap
+    on one GPU race on the static scratch (header)."""
     torch = pytest.importorskip("torch")
+    lib = hip.load_library()
     p = config_payload(cfg)
     w = hip.SeedDeltaWeight(p)
     ref = hip.SeedDeltaWeight(p)                     # the existing entry point runs on a handle of its own
-    assert hip.load_library().sdh_noalloc_scratch_bytes() == 8 * 1024 * 1024
+    assert lib.sdh_noalloc_scratch_bytes() == 8 * 1024 * 1024
     # first call: 700 tokens = more than one scratch-sized chunk (B*L*4 = 64 KiB per token -> 128 tokens per chunk)
     # second call: smaller (3 tokens), on the scratch the first call left behind
-    free0 = None
-    for T, seed in ((700, 1), (3, 2), (1, 3), (130, 4)):
-        x = make_x(p.n_in, T, seed=seed)
-        want = ref.forward_host(x, hip.FWD_NO_FUSE)
-        if free0 is None:
-            torch.cuda.synchronize()
-            free0 = torch.cuda.mem_get_info()[0]
-        rc, y = run_noalloc(torch, w, x)
-        assert rc == 0, hip.load_library().sdh_last_error()
-        assert np.array_equal(bits(y), bits(want)), (cfg, T, float(np.abs(y - want).max()))
-        assert np.array_equal(bits(y), bits(ref.forward_host(x)))          # and the default path (fused launch at T <= 4)
-        assert w.nonfinite_count() == 0
-    # the handle never grew a workspace: free device memory is what it was before the first call
-    # (torch's own allocations for xd / yd come from its cache or are returned to it; allow its block granularity)
+    cases = [(700, 1), (3, 2), (1, 3), (130, 4)]
+    xs = [make_x(p.n_in, T, seed=seed) for T, seed in cases]
+    wants = [(ref.forward_host(x, hip.FWD_NO_FUSE), ref.forward_host(x)) for x in xs]
+    xd = [torch.from_numpy(x).cuda() for x in xs]
+    yd = [torch.full((x.shape[0], w.n_out), float("nan"), dtype=torch.float32, device="cuda") for x in xs]
     torch.cuda.synchronize()
-    assert abs(torch.cuda.mem_get_info()[0] - free0) <= 64 << 20
+    free0, calls0 = torch.cuda.mem_get_info()[0], lib.sdh_debug_alloc_calls()
+    for (T, _), x_d, y_d in zip(cases, xd, yd):
+        rc = w.forward_device_noalloc(x_d.data_ptr(), w.n_in, T, y_d.data_ptr(), w.n_out, 0, 0)
+        assert rc == 0, lib.sdh_last_error()
+    torch.cuda.synchronize()
+    assert lib.sdh_debug_alloc_calls() == calls0, "sdh_forward_noalloc called hipMalloc / hipFree"
+    assert abs(torch.cuda.mem_get_info()[0] - free0) <= 2 << 20
+    for (T, _), y_d, (want_nofuse, want_default) in zip(cases, yd, wants):
+        y = y_d.cpu().numpy()
+        assert np.array_equal(bits(y), bits(want_nofuse)), (cfg, T, float(np.abs(y - want_nofuse).max()))
+        assert np.array_equal(bits(y), bits(want_default))          # and the default path (fused launch at T <= 4)
+    assert w.nonfinite_count() == 0
+    # control: the same 700-token call through sdh_forward on the same (workspace-free) handle DOES allocate, and
+    # both detectors see it — so the zero above is a measurement, not a blind spot
+    rc = w.forward_device(xd[0].data_ptr(), w.n_in, 700, yd[0].data_ptr(), w.n_out, hip.FWD_NO_FUSE, 0)
+    torch.cuda.synchronize()
+    assert lib.sdh_debug_alloc_calls() > calls0
+    assert free0 - torch.cuda.mem_get_info()[0] >= 40 << 20
     # explicit stream and the verification order
     st = torch.cuda.Stream()
     x = make_x(p.n_in, 9, seed=8)
