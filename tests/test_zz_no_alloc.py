@@ -27,7 +27,7 @@ def test_noalloc_matches_forward_two_calls_in_a_row(hip, cfg):
     handle of its own. "Allocates nothing" is asserted two ways around the no-alloc calls alone (x / y allocated
     beforehand, the reference results computed beforehand): the library's own census of hipMalloc / hipHostMalloc /
     hipFree calls (sdh_debug_alloc_calls) must not move, and the device's free memory must not move by more than
-    2 MiB — the workspace sdh_forward grows for the 700-token call is 44.8 MiB (700 x B*L*4 = 64 KiB), and a control
+    2 MiB — the workspace sdh_forward grows for the 700-token call is 700 x B*L*4 bytes (44.8 MiB at Mistral dims), and a control
     at the end shows both detectors see exactly that growth. All calls are issued on ONE stream: calls that overlap
     on one GPU race on the static scratch (header)."""
     torch = pytest.importorskip("torch")
@@ -61,7 +61,8 @@ def test_noalloc_matches_forward_two_calls_in_a_row(hip, cfg):
     rc = w.forward_device(xd[0].data_ptr(), w.n_in, 700, yd[0].data_ptr(), w.n_out, hip.FWD_NO_FUSE, 0)
     torch.cuda.synchronize()
     assert lib.sdh_debug_alloc_calls() > calls0
-    assert free0 - torch.cuda.mem_get_info()[0] >= 40 << 20
+    grown = 700 * p.base_d1.shape[0] * p.base_d1.shape[1] * 4           # v[T][B][L] f32: 44.8 MiB at Mistral dims
+    assert free0 - torch.cuda.mem_get_info()[0] >= grown - (2 << 20)
     # explicit stream and the verification order
     st = torch.cuda.Stream()
     x = make_x(p.n_in, 9, seed=8)
