@@ -483,7 +483,9 @@ def run_prefill(args, dev):
         # rows_lds: SDH_FWD_NO_SPMM, the residual through the LDS rows kernels (the fast path's arithmetic: within the
         # tolerance of tests/test_gpu_forward.py, each token bit-identical to its one-token result) instead of the tiled
         # SpMM, whose rows are bit-identical to the CPU op; the gated FFN entry points use it for COO payloads
-        for tag, flags in (("default", 0), ("w0_mfma", seeddelta.FWD_W0_MFMA), ("rows_lds", seeddelta.FWD_NO_SPMM)):
+        # mfma_fold: SDH_FWD_MFMA_FOLD, the whole op as one dense contraction (residual added to the W0 tile in LDS)
+        for tag, flags in (("default", 0), ("w0_mfma", seeddelta.FWD_W0_MFMA), ("rows_lds", seeddelta.FWD_NO_SPMM),
+                           ("mfma_fold", seeddelta.FWD_MFMA_FOLD)):
             fn = lambda: w.forward_device(x.data_ptr(), n_in, T, y.data_ptr(), n_out, flags=flags, stream=sp)   # noqa: E731
             ev_ms, host_ms = timed_on_stream(fn, args.prefill_reps, st, seeddelta, warm=3)
             ms = ev_ms / args.prefill_reps
@@ -491,7 +493,7 @@ def run_prefill(args, dev):
                  "hbm": {"achieved": alg / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / ms / 1e6 / HBM_PEAK_GBS},
                  "residual_valu": {"achieved": 2.0 * K * n_out * T / ms / 1e9, "peak": VALU_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                    "frac": 2.0 * K * n_out * T / ms / 1e9 / VALU_F32_PEAK_TFLOPS}}
-            if tag == "w0_mfma":
+            if tag in ("w0_mfma", "mfma_fold"):
                 fl = 2.0 * n_in * n_out * T
                 d["mfma"] = {"achieved": fl / ms / 1e9, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": fl / ms / 1e9 / MFMA_F16_PEAK_TFLOPS,
@@ -781,10 +783,11 @@ def main():
         if prefill is not None:
             legs = {}
             for name, leg in prefill["workloads"].items():
-                best = min(("default", "w0_mfma", "rows_lds"), key=lambda t: leg[t]["ms"] if t in leg else 1e30)
+                best = min(("default", "w0_mfma", "rows_lds", "mfma_fold"), key=lambda t: leg[t]["ms"] if t in leg else 1e30)
                 legs[name] = {"ms": r3(leg["default"]["ms"]), "hbm_frac": r3(leg["default"]["hbm"]["frac"]),
                               "mfma_ms": r3(leg["w0_mfma"]["ms"]), "mfma_frac": r3(leg["w0_mfma"]["mfma"]["frac"]),
-                              "rows_ms": r3(leg["rows_lds"]["ms"]), "best": best}
+                              "rows_ms": r3(leg["rows_lds"]["ms"]), "fold_ms": r3(leg["mfma_fold"]["ms"]),
+                              "fold_mfma_frac": r3(leg["mfma_fold"]["mfma"]["frac"]), "best": best}
             line["prefill"] = {"tokens": 512, "unit": "ms per ubatch and tensor", "workloads": legs}
         if scan is not None:
             sc = {"value": r3(scan["value"]), "unit": scan["unit"], "n_gpus": scan["n_gpus"], "scaling": scan["scaling"],

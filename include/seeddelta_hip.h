@@ -112,6 +112,14 @@ typedef enum sdh_op_kind {
                                       points make this choice per tensor themselves.                          */
 #define SDH_FWD_W0_MFMA       0x8  /* prefill: evaluate the base as W0 tiles regenerated in LDS
                                       and contracted on MFMA instead of the FWHT form          */
+#define SDH_FWD_MFMA_FOLD    0x40  /* prefill (5 tokens and more, payloads with a base): the whole op as ONE dense
+                                      contraction on the matrix cores — the W0 tile of every k-slab is regenerated in
+                                      LDS and the residual entries of that slab are added to it there, so the residual
+                                      costs one LDS add per entry and workgroup instead of a gather-multiply per entry
+                                      and token. f16 operands (x, W0 + delta), fp32 accumulation, row_scale in fp32:
+                                      results within 2e-3 * sum|terms| of the CPU op (tests state it), not bit-identical
+                                      to it. The first call on a handle re-lays the residual out by (row tile, k-slab)
+                                      on the device (once; it doubles the payload's footprint in HBM).          */
 
 /* ---- library / device ----------------------------------------------------------------
  * sdh_init: bind the calling process to HIP device `device` and create the library's

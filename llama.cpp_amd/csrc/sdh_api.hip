@@ -156,6 +156,7 @@ static void free_weight(DeviceWeight * w) {
     (void) hipFree(w->d1); (void) hipFree(w->d2); (void) hipFree(w->d3); (void) hipFree(w->p1); (void) hipFree(w->p2);
     (void) hipFree(w->pack_dev); (void) hipFree(w->handoff);
     (void) hipFree(w->G); (void) hipFree(w->inv); (void) hipFree(w->nf_ring); (void) hipFree(w->ws);
+    fold_free(*w);
     delete w;
 }
 
@@ -568,6 +569,35 @@ static int sdh_forward_impl(sdh_weight * h, const float * x, int64_t ldx, int64_
         if (chunk < 1) chunk = 1;
     }
     LibState & ls = lib();
+    // Many tokens, one dense contraction per tensor: the residual folded into the W0 tile in LDS (SDH_FWD_MFMA_FOLD;
+    // f16 operands, fp32 accumulation). The call is complete after it: row scale, non-finite census, everything.
+    if ((flags & SDH_FWD_MFMA_FOLD) && has_base && !(flags & SDH_FWD_EXACT_ORDER) && !noalloc && !glu &&
+        w->w0_closed_form && w->L >= 128 && n_tokens > MAX_FUSED_TOKENS) {
+        const int64_t fchunk = std::min<int64_t>(n_tokens, 2048);
+        int rc = ensure_ws(w, w0_fold_ws_bytes(*w, fchunk));
+        if (rc != SDH_OK) return rc;
+        int pair = -1;
+        if (ls.prof_on) {
+            if (ls.prof_used == LibState::PROF_PAIRS) { rc = prof_flush(ls); if (rc != SDH_OK) return rc; }
+            pair = ls.prof_used;
+            SDH_HIP_CHECK(hipEventRecord(ls.prof_ev[2 * pair], s));
+        }
+        for (int64_t t0 = 0; t0 < n_tokens && rc == SDH_OK; t0 += fchunk) {
+            const int64_t tc = std::min<int64_t>(fchunk, n_tokens - t0);
+            rc = launch_w0_fold(*w, dx + t0 * dldx, dldx, tc, w->ws, dy + t0 * dldy, dldy, w->nf_ring + slot,
+                                (flags & SDH_FWD_ZERO_NONFINITE) != 0, s);
+        }
+        if (rc < 0) return rc;
+        if (rc == SDH_OK) {
+            if (pair >= 0) { SDH_HIP_CHECK(hipEventRecord(ls.prof_ev[2 * pair + 1], s)); ls.prof_used = pair + 1; }
+            w->seq++;
+            w->last_stream = s;
+            ls.span_forwards++;
+            if (host_io) return device_to_host_sync(ls, y, ldy, dy, w->n_out, n_tokens, s);
+            return SDH_OK;
+        }
+        // rc == 1: the payload does not fit the scheme (only possible before anything was launched)
+    }
     for (int64_t t0 = 0; t0 < n_tokens; t0 += chunk) {
         const int64_t tc = (n_tokens - t0 < chunk) ? (n_tokens - t0) : chunk;
         const float * xc = dx + t0 * dldx;

@@ -93,6 +93,9 @@ struct DeviceWeight {
     const float * x4_hint = nullptr;  // token-interleaved copy of the next call's x (see DeltaLaunch::x4); set and cleared by the FFN path
     bool    base_ready = false;  // ws already holds the base terms of the next call's tokens (gate|up base launch of the FFN path)
     size_t  ws_bytes = 0;
+    // the residual re-laid out for the folded MFMA contraction (sdh_w0fold.hip), built on first use: entries bucketed by
+    // (128-row tile, 64-wide k-slab), fold_off [tiles][fold_ng + 1]
+    unsigned * fold_ent = nullptr; int * fold_off = nullptr; int fold_ng = 0, fold_spb = 0;
 };
 
 struct LibState {
@@ -164,6 +167,14 @@ int launch_w0_mfma(const DeviceWeight & w, const float * x, int64_t ldx, int64_t
 size_t w0_mfma_x16_bytes(const DeviceWeight & w, int64_t T);
 int launch_w0_mfma_tiled(const DeviceWeight & w, const float * x, int64_t ldx, int64_t T, _Float16 * x16_ws,
                          float * out, int64_t ldo, hipStream_t s);
+
+int launch_w0_x16(const float * x, int64_t ldx, int64_t T, int n_in, _Float16 * x16, int64_t ld16, int64_t T_pad, hipStream_t s);
+// Prefill as one dense contraction: residual entries added to the W0 tile in LDS (sdh_w0fold.hip). ws: w0_fold_ws_bytes.
+// Returns SDH_OK if launched (y complete: row scale applied, non-finite outputs counted), 1 if the payload does not fit.
+size_t w0_fold_ws_bytes(const DeviceWeight & w, int64_t T);
+int  launch_w0_fold(DeviceWeight & w, const float * x, int64_t ldx, int64_t T, void * ws, float * y, int64_t ldy,
+                    int * nf_counter, bool zero_nf, hipStream_t s);
+void fold_free(DeviceWeight & w);
 
 // Prefill: token-tiled SpMM (sdh_spmm.hip). Returns SDH_OK if launched, 1 if the shape does not fit.
 int launch_delta_spmm(const DeviceWeight & w, const DeltaLaunch & a, hipStream_t s);

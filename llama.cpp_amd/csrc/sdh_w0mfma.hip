@@ -126,6 +126,14 @@ void w0_x16_kernel(const float * __restrict__ x, int64_t ldx, int64_t T, int n_i
     *reinterpret_cast<half8 *>(x16 + e) = h;
 }
 
+// f16 image of x, zero-padded to whole tiles (also the pre-pass of the folded contraction, sdh_w0fold.hip)
+int launch_w0_x16(const float * x, int64_t ldx, int64_t T, int n_in, _Float16 * x16, int64_t ld16, int64_t T_pad, hipStream_t s) {
+    const int64_t n8 = T_pad * ld16 / 8;
+    hipLaunchKernelGGL(w0_x16_kernel, dim3((unsigned) ((n8 + 255) / 256)), dim3(256), 0, s, x, ldx, T, n_in, x16, ld16, T_pad);
+    SDH_HIP_CHECK(hipGetLastError());
+    return SDH_OK;
+}
+
 template <bool TALL, bool SCALED /* d1 or d3 present and not all ones */>
 __global__ __launch_bounds__(512)
 void w0_mfma_tile_kernel(const _Float16 * __restrict__ x16, int64_t ld16, int64_t T, int n_in, int n_out, int L,

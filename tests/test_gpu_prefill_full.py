@@ -119,3 +119,86 @@ def test_prefill_T512_w0_mfma(hip, cfg):
         worst = max(worst, float(np.max(err / bound)))
     assert worst > 1e-4          # the MFMA path really ran (it is not bit-exact)
     w.close()
+
+
+def fold_bound(p, x, y_ref, rows, sel):
+    """per sampled (token, row): 1.5e-3 * |rs| * sum_i (|W0[o,i]| + |D[o,i]|) * |x[i]| — f16 rounding of x, of W0 and of
+    the sum W0 + D (each <= 2^-11 relative) — plus the fast path's fp32 ordering tolerance"""
+    xs = np.abs(x[sel].astype(np.float64))
+    tol = fast_tolerance(p, x[sel], y_ref[sel])                  # 2e-5 * |rs| * (sum |val x| + |W0 x|)
+    out = {}
+    for o in rows:
+        W0 = np.abs(O.w0_tile(p, int(o), int(o) + 1, 0, p.n_in).astype(np.float64))[0]
+        rs = abs(float(p.row_scale[o])) if p.row_scale is not None else 1.0
+        out[int(o)] = 1.5e-3 * rs * (xs @ W0) + 75.0 * tol[:, o]
+    return out
+
+
+@pytest.mark.parametrize("cfg", list(SPMM_EXACT))
+def test_prefill_T512_mfma_fold(hip, cfg):
+    """SDH_FWD_MFMA_FOLD at the real dims: ONE dense contraction per tensor, the residual added to the W0 tile in LDS
+    (src/llama-seeddelta.cpp:1088-1175 evaluated as (W0 + D) x). f16 operands, fp32 accumulation."""
+    p, x, y_ref = case(cfg)
+    w = hip.SeedDeltaWeight(p)
+    y = w.forward_host(x, hip.FWD_MFMA_FOLD)
+    assert w.nonfinite_count() == 0 and np.isfinite(y).all()
+    assert np.abs(y - y_ref).max() <= 2e-2 * np.abs(y_ref).max()
+    rows = np.unique(np.concatenate([[0, p.n_out - 1], np.random.default_rng(3).integers(0, p.n_out, 96)]))
+    sel = token_sample(4)
+    bound = fold_bound(p, x, y_ref, rows, sel)
+    worst = 0.0
+    for o in rows:
+        err = np.abs(y[sel, o].astype(np.float64) - y_ref[sel, o].astype(np.float64))
+        assert np.all(err <= bound[int(o)]), (cfg, int(o), float(np.max(err / bound[int(o)])))
+        worst = max(worst, float(np.max(err / bound[int(o)])))
+    assert worst > 1e-4          # the folded path really ran (it is not bit-exact)
+    # a second call reuses the re-laid-out payload; ragged token counts (a partly filled last tile, fewer than a tile)
+    for t in (300, 7):
+        yt = w.forward_host(x[:t], hip.FWD_MFMA_FOLD)
+        assert np.array_equal(bits(yt), bits(y[:t])), t          # a token's result does not depend on its batch
+    w.close()
+
+
+@pytest.mark.parametrize("dims", [(256, 640), (640, 256), (200, 1000), (1000, 200), (1024, 1024)])
+@pytest.mark.parametrize("scheme,K,block", [("coo", 24, 16), ("block", 64, 16), ("block", 96, 32)])
+def test_mfma_fold_small_shapes(hip, dims, scheme, K, block):
+    """Odd dims (n_in not a multiple of the 64-wide slab, n_out not a multiple of the 128-row tile, a partly filled last
+    base block), d1 / d3 present, bad indices, duplicates: every element against the oracle with the stated f16 bound."""
+    n_in, n_out = dims
+    p = make_payload(n_in, n_out, scheme=scheme, K=K, block=block, base=True, seed=n_in + K, d13_random=True)
+    rng = np.random.default_rng(4)
+    if scheme == "coo":
+        p.d_idx[::7, 0] = -1
+        p.d_idx[1::9, 1] = n_in + 3                         # out of range: skipped (:693)
+        p.d_idx[2::5, 3] = p.d_idx[2::5, 2]                 # duplicates sum
+    else:
+        p.b_idx[::6, 0] = -1
+        p.b_idx[1::8, 1] = (n_in + block - 1) // block - 1  # the ragged last block (clipped to n_in) where n_in % block != 0
+    T = 37
+    x = make_x(n_in, T, seed=3)
+    y_ref = O.forward(p, x, nth=4)
+    w = hip.SeedDeltaWeight(p)
+    y = w.forward_host(x, hip.FWD_MFMA_FOLD)
+    rows = np.arange(n_out)
+    sel = np.arange(T)
+    bound = fold_bound(p, x, y_ref, rows, sel)
+    for o in rows:
+        err = np.abs(y[:, o].astype(np.float64) - y_ref[:, o].astype(np.float64))
+        assert np.all(err <= bound[int(o)]), (dims, scheme, int(o), float(np.max(err / bound[int(o)])))
+    assert w.nonfinite_count() == 0
+    w.close()
+
+
+def test_mfma_fold_counts_nonfinite_outputs(hip):
+    p = make_payload(512, 768, scheme="coo", K=16, base=True, seed=5)
+    x = make_x(512, 12, seed=1)
+    x[3, 10] = np.inf
+    w = hip.SeedDeltaWeight(p)
+    y = w.forward_host(x, hip.FWD_MFMA_FOLD | hip.FWD_ZERO_NONFINITE)
+    y_ref = O.forward(p, x, nth=4)                          # the reference guard writes 0 without a dense weight (:373-380)
+    # an infinite input reaches every output of its token through the dense base: the whole row is non-finite
+    assert w.nonfinite_count() == p.n_out
+    assert np.all(y[3] == 0.0) and np.all(y_ref[3] == 0.0) and np.isfinite(y).all()
+    ok = np.arange(12) != 3
+    assert np.abs(y[ok] - y_ref[ok]).max() <= 2e-2 * np.abs(y_ref[ok]).max()
+    w.close()
