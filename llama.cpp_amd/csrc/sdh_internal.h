@@ -94,8 +94,9 @@ struct DeviceWeight {
     bool    base_ready = false;  // ws already holds the base terms of the next call's tokens (gate|up base launch of the FFN path)
     size_t  ws_bytes = 0;
     // the residual re-laid out for the folded MFMA contraction (sdh_w0fold.hip), built on first use: entries bucketed by
-    // (128-row tile, 64-wide k-slab), fold_off [tiles][fold_ng + 1]
-    unsigned * fold_ent = nullptr; int * fold_off = nullptr; int fold_ng = 0, fold_spb = 0;
+    // (128-row tile, 64-wide k-slab), fold_off [tiles][fold_ng] = {begin, end} of a bucket in fold_ent
+    unsigned * fold_ent = nullptr; int2 * fold_off = nullptr; int fold_ng = 0, fold_spb = 0;
+    bool fold_dup = false;       // some (row, input) pair occurs twice: the adds must be atomic
 };
 
 struct LibState {

@@ -33,7 +33,6 @@ typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int FD_R = 128, FD_N = 256, FD_K = 64, FD_LD = 72;
-constexpr int FD_EPT = 3;          // residual entries per thread prefetched per slab (512 x 3; more are loaded in the scatter step)
 
 // ---- payload re-layout: entries bucketed by (row tile, k-slab) ------------------------------------------------
 struct FoldArgs {
@@ -87,16 +86,17 @@ void fold_bucket_kernel(const FoldArgs a, int * __restrict__ counts, int * __res
     }
 }
 
-// counts [tiles][n_g + 1] -> exclusive offsets in place (entry n_g of a row = the row's end), and a copy in cursor
+// counts [tiles][n_g + 1] -> bucket bounds: every bucket starts at a multiple of 4 entries (16-byte loads) and is padded
+// to one with null entries (value +0: skipped by the kernel); cursor = the bucket starts, bounds[tile * n_g + g] = {begin, end}
 __global__ __launch_bounds__(1024)
-void fold_scan_kernel(int * __restrict__ counts, int * __restrict__ cursor, int tiles, int n_g) {
+void fold_scan_kernel(const int * __restrict__ counts, int * __restrict__ cursor, int2 * __restrict__ bounds, int tiles, int n_g) {
     __shared__ int tile_base[1];
     __shared__ int totals[1024];
     int carry = 0;
     for (int t0 = 0; t0 < tiles; t0 += 1024) {
         const int t = t0 + (int) threadIdx.x;
         int tot = 0;
-        if (t < tiles) for (int g = 0; g < n_g; ++g) tot += counts[(size_t) t * (n_g + 1) + g];
+        if (t < tiles) for (int g = 0; g < n_g; ++g) tot += (counts[(size_t) t * (n_g + 1) + g] + 3) & ~3;
         totals[threadIdx.x] = tot;
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -109,15 +109,32 @@ void fold_scan_kernel(int * __restrict__ counts, int * __restrict__ cursor, int 
             int run = totals[threadIdx.x];
             for (int g = 0; g < n_g; ++g) {
                 const size_t at = (size_t) t * (n_g + 1) + g;
-                const int v = counts[at];
-                counts[at] = run; cursor[at] = run;
+                const int v = (counts[at] + 3) & ~3;
+                cursor[at] = run;
+                bounds[(size_t) t * n_g + g] = make_int2(run, run + v);
                 run += v;
             }
-            counts[(size_t) t * (n_g + 1) + n_g] = run;
         }
         carry = tile_base[0];
         __syncthreads();
     }
+}
+
+// does any bucket hold the same (row, column) twice? one workgroup per bucket, a bitmap of the 8192 positions of a tile
+__global__ __launch_bounds__(256)
+void fold_dup_kernel(const unsigned * __restrict__ ent, const int2 * __restrict__ bounds, int * __restrict__ dup) {
+    __shared__ unsigned bm[256];
+    bm[threadIdx.x] = 0u;
+    __syncthreads();
+    const int2 o = bounds[blockIdx.x];
+    bool hit = false;
+    for (int e = o.x + (int) threadIdx.x; e < o.y; e += 256) {
+        const unsigned wd = ent[e];
+        if ((wd & 0x7FFF0000u) == 0u) continue;                                  // padding, or a value of zero
+        const unsigned key = wd & 0x1FFFu, bit = 1u << (key & 31u);
+        hit |= (atomicOr(&bm[key >> 5], bit) & bit) != 0u;
+    }
+    if (hit) atomicOr(dup, 1);
 }
 
 int fold_ensure(DeviceWeight & w, hipStream_t s) {
@@ -135,18 +152,30 @@ int fold_ensure(DeviceWeight & w, hipStream_t s) {
     const int64_t cap = (int64_t) w.n_out * (is_block ? w.nb * w.block : w.K);
     if (cap <= 0 || cap > 0x7fffffff) return 1;
     const size_t off_bytes = (size_t) tiles * (a.n_g + 1) * sizeof(int);
-    int * off = nullptr, * cursor = nullptr; unsigned * ent = nullptr;
-    SDH_HIP_CHECK(hipMalloc((void **) &off, off_bytes));
+    const size_t ent_words = (size_t) cap + (size_t) 4 * tiles * a.n_g + 4;       // every bucket padded to a multiple of 4
+    int * counts = nullptr, * cursor = nullptr; unsigned * ent = nullptr; int2 * bounds = nullptr;
+    SDH_HIP_CHECK(hipMalloc((void **) &counts, off_bytes));
     SDH_HIP_CHECK(hipMalloc((void **) &cursor, off_bytes));
-    SDH_HIP_CHECK(hipMalloc((void **) &ent, (size_t) cap * sizeof(unsigned) + 16));
-    SDH_HIP_CHECK(hipMemsetAsync(off, 0, off_bytes, s));
+    SDH_HIP_CHECK(hipMalloc((void **) &bounds, (size_t) tiles * a.n_g * sizeof(int2)));
+    SDH_HIP_CHECK(hipMalloc((void **) &ent, ent_words * sizeof(unsigned)));
+    SDH_HIP_CHECK(hipMemsetAsync(counts, 0, off_bytes, s));
+    SDH_HIP_CHECK(hipMemsetAsync(ent, 0, ent_words * sizeof(unsigned), s));       // padding = null entries
     const unsigned grid = (unsigned) ((w.n_out * per_row + 255) / 256);
-    hipLaunchKernelGGL(fold_bucket_kernel<0>, dim3(grid), dim3(256), 0, s, a, off, cursor, ent);
-    hipLaunchKernelGGL(fold_scan_kernel, dim3(1), dim3(1024), 0, s, off, cursor, tiles, a.n_g);
-    hipLaunchKernelGGL(fold_bucket_kernel<1>, dim3(grid), dim3(256), 0, s, a, off, cursor, ent);
+    hipLaunchKernelGGL(fold_bucket_kernel<0>, dim3(grid), dim3(256), 0, s, a, counts, cursor, ent);
+    hipLaunchKernelGGL(fold_scan_kernel, dim3(1), dim3(1024), 0, s, counts, cursor, bounds, tiles, a.n_g);
+    hipLaunchKernelGGL(fold_bucket_kernel<1>, dim3(grid), dim3(256), 0, s, a, counts, cursor, ent);
     SDH_HIP_CHECK(hipGetLastError());
+    // counts is free again: its first word receives the "a (row, input) pair repeats" flag
+    SDH_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(int), s));
+    hipLaunchKernelGGL(fold_dup_kernel, dim3((unsigned) (tiles * a.n_g)), dim3(256), 0, s, ent, bounds, counts);
+    SDH_HIP_CHECK(hipGetLastError());
+    int dup = 0;
+    SDH_HIP_CHECK(hipMemcpyAsync(&dup, counts, sizeof(int), hipMemcpyDeviceToHost, s));
     SDH_HIP_CHECK(hipStreamSynchronize(s));
     SDH_HIP_CHECK(hipFree(cursor));
+    SDH_HIP_CHECK(hipFree(counts));
+    int2 * off = bounds;
+    w.fold_dup = dup != 0;
     w.fold_ent = ent; w.fold_off = off; w.fold_ng = a.n_g; w.fold_spb = a.spb;
     return SDH_OK;
 }
@@ -157,12 +186,12 @@ void fold_free(DeviceWeight & w) {
 }
 
 // ---- the contraction ---------------------------------------------------------------------------------------------
-template <bool TALL, bool SCALED /* d1 or d3 present and not all ones */>
+template <bool TALL, bool SCALED /* d1 or d3 present and not all ones */, bool ATOMIC /* the payload repeats a (row, input) pair */>
 __global__ __launch_bounds__(512)
 void w0d_mfma_kernel(const _Float16 * __restrict__ x16, int64_t ld16, int64_t T, int n_in, int n_out, int L,
                      const float * __restrict__ d1, const float * __restrict__ d3,
                      const float * __restrict__ G, const int * __restrict__ inv,
-                     const unsigned * __restrict__ ent, const int * __restrict__ off, int n_g, int spb,
+                     const unsigned * __restrict__ ent, const int2 * __restrict__ off, int n_g, int spb,
                      const float * __restrict__ rs, float * __restrict__ out, int64_t ldo,
                      int * __restrict__ nf_counter, int zero_nf) {
     extern __shared__ __align__(16) unsigned char fd_smem[];
@@ -179,7 +208,7 @@ void w0d_mfma_kernel(const _Float16 * __restrict__ x16, int64_t ld16, int64_t T,
     const int k_begin = TALL ? 0 : b * L;                         // first input of this workgroup's K range
     const int q_len = TALL ? n_in : min(L, n_in - b * L);
     const int n_slab = (q_len + FD_K - 1) / FD_K;
-    const int * offr = off + (size_t) blockIdx.x * (n_g + 1) + (TALL ? 0 : b * spb);       // bucket s of this workgroup: [offr[s], offr[s+1])
+    const int2 * offr = off + (size_t) blockIdx.x * n_g + (TALL ? 0 : b * spb);             // bounds of bucket s of this workgroup: offr[s]
 
     float d3r[2];
     bool rok[2];
@@ -200,10 +229,10 @@ void w0d_mfma_kernel(const _Float16 * __restrict__ x16, int64_t ld16, int64_t T,
     float d1q[2][8];
     unsigned ivq[8];
     half8 xq[2][4];
-    unsigned eq[2][FD_EPT];     // residual entries of the slab after next / the next slab
+    uint4 eq[2];                // residual entries (four per thread) of the slab after next / the next slab
     int ebeg[2], eend[2];       // their bucket bounds
     int ivl = 0;
-    int ob = 0, oe = 0;         // bucket bounds loaded a slab ahead of the entry loads that use them
+    int2 obe = make_int2(0, 0); // bucket bounds loaded a slab ahead of the entry loads that use them
     auto fetch_idx = [&](int s) {
         const int q0 = max(min(s, n_slab - 1), 0) * FD_K + wave * 8;
         ivl = inv[pb + q0 + (lane & 7)];
@@ -212,7 +241,7 @@ void w0d_mfma_kernel(const _Float16 * __restrict__ x16, int64_t ld16, int64_t T,
     asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));                 // a zero the compiler cannot see: keeps the loads below vector loads
     auto fetch_off = [&](int s) {                                  // (a scalar load in flight turns every LDS wait into lgkmcnt(0))
         const int sc = max(min(s, n_slab - 1), 0);
-        ob = offr[sc + vzero]; oe = offr[sc + 1 + vzero];
+        obe = offr[sc + vzero];
     };
     auto fetchW = [&](auto set_c, int s) {
         constexpr int S = decltype(set_c)::value;
@@ -236,12 +265,9 @@ void w0d_mfma_kernel(const _Float16 * __restrict__ x16, int64_t ld16, int64_t T,
     };
     auto fetchE = [&](auto set_c) {                                // entries of the bucket [ob, oe)
         constexpr int S = decltype(set_c)::value;
-        ebeg[S] = __builtin_amdgcn_readfirstlane(ob); eend[S] = __builtin_amdgcn_readfirstlane(oe);
-#pragma unroll
-        for (int i = 0; i < FD_EPT; ++i) {
-            const int e = ebeg[S] + i * 512 + tid;
-            eq[S][i] = ent[min(e, max(eend[S] - 1, 0))];           // clamped: read unconditionally, used if e < end
-        }
+        ebeg[S] = __builtin_amdgcn_readfirstlane(obe.x); eend[S] = __builtin_amdgcn_readfirstlane(obe.y);
+        const int e = ebeg[S] + 4 * tid;                           // buckets start and end at multiples of 4: one 16-byte load
+        eq[S] = *reinterpret_cast<const uint4 *>(ent + (e < eend[S] ? e : max(eend[S] - 4, 0)));      // clamped: read unconditionally
     };
     auto commitW = [&](auto set_c, unsigned wbuf, int rr) {
         _Float16 * Wb = Ws + wbuf;
@@ -260,20 +286,47 @@ void w0d_mfma_kernel(const _Float16 * __restrict__ x16, int64_t ld16, int64_t T,
         for (int i = 0; i < 2; ++i)
             *reinterpret_cast<half8 *>(Xs + (size_t) buf * FD_N * FD_LD + xs_w + (2 * half + i) * 64 * FD_LD) = xq[S][2 * half + i];
     };
-    auto add_entry = [&](unsigned wbuf, unsigned wd) {
-        _Float16 * Wb = Ws + wbuf;
-        const unsigned pos = ((wd >> 6) & 127u) * FD_LD + (wd & 63u);
-        const unsigned short vb = (unsigned short) (wd >> 16);
-        _Float16 v; __builtin_memcpy(&v, &vb, 2);
+    // Adding the entries of a bucket to a W tile. Entries of a payload without repeated (row, input) pairs touch distinct
+    // elements, so each is a plain 16-bit read, add, 16-bit write — the reads of a slab's entries are issued at the first
+    // multiply step and the writes two steps later, so no wave waits out an LDS round trip between its MFMAs (a read-add-
+    // write per entry in one place cost 0.3 us per slab: three dependent round trips with the matrix pipe idle). Payloads
+    // that do repeat a pair (hand-made ones; the builder's top-K never does) take ds_pk_add_f16, which sums them as the
+    // reference does.
+    auto entry_pos = [&](unsigned wd) { return ((wd >> 6) & 127u) * FD_LD + (wd & 63u); };
+    auto entry_val = [&](unsigned wd) { const unsigned short vb = (unsigned short) (wd >> 16); _Float16 v; __builtin_memcpy(&v, &vb, 2); return v; };
+    auto add_atomic = [&](unsigned wbuf, unsigned wd) {
+        const unsigned pos = entry_pos(wd);
+        const _Float16 v = entry_val(wd);
         const half2v add = (pos & 1u) ? half2v{(_Float16) 0.0f, v} : half2v{v, (_Float16) 0.0f};
-        __builtin_amdgcn_ds_atomic_fadd_v2f16((__attribute__((address_space(3))) half2v *) (Wb + (pos & ~1u)), add);
+        __builtin_amdgcn_ds_atomic_fadd_v2f16((__attribute__((address_space(3))) half2v *) (Ws + wbuf + (pos & ~1u)), add);
+    };
+    _Float16 eold[4];
+    auto live = [&](unsigned wd) { return (wd & 0x7FFF0000u) != 0u; };          // not padding (and not a value of zero)
+    auto scatter_read = [&](auto set_c, unsigned Wb) {
+        constexpr int S = decltype(set_c)::value;
+        if constexpr (!ATOMIC) {
+            const unsigned wd[4] = {eq[S].x, eq[S].y, eq[S].z, eq[S].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) eold[i] = Ws[Wb + entry_pos(wd[i])];      // unconditional: a clamped or null entry reads a valid element
+        }
     };
     auto scatter = [&](auto set_c, unsigned Wb) {
         constexpr int S = decltype(set_c)::value;
+        if (ebeg[S] + 4 * tid < eend[S]) {
+            const unsigned wd[4] = {eq[S].x, eq[S].y, eq[S].z, eq[S].w};
 #pragma unroll
-        for (int i = 0; i < FD_EPT; ++i)
-            if (ebeg[S] + i * 512 + tid < eend[S]) add_entry(Wb, eq[S][i]);
-        for (int e = ebeg[S] + FD_EPT * 512 + tid; e < eend[S]; e += 512) add_entry(Wb, ent[e]);     // a bucket beyond the prefetch
+            for (int i = 0; i < 4; ++i)
+                if (live(wd[i])) {
+                    if constexpr (ATOMIC) add_atomic(Wb, wd[i]);
+                    else Ws[Wb + entry_pos(wd[i])] = eold[i] + entry_val(wd[i]);
+                }
+        }
+        for (int e = ebeg[S] + 2048 + tid; e < eend[S]; e += 512) {                       // a bucket beyond the prefetch
+            const unsigned wd = ent[e];
+            if (!live(wd)) continue;
+            if constexpr (ATOMIC) add_atomic(Wb, wd);
+            else { const unsigned pos = Wb + entry_pos(wd); Ws[pos] = Ws[pos] + entry_val(wd); }
+        }
     };
 
     const int wr = wave & 1, wt = wave >> 1;                      // wave tile: rows wr*64.., tokens wt*64..
@@ -294,9 +347,14 @@ void w0d_mfma_kernel(const _Float16 * __restrict__ x16, int64_t ld16, int64_t T,
     auto slab = [&](auto p_c, auto q_c, int s) {
         constexpr int P = decltype(p_c)::value;
         if (s + 3 < n_slab) fetchW(q_c, s + 3);
+#ifndef FD_ABL_NOFETCHE
         if (s + 2 < n_slab) { fetchX(p_c, s + 2); fetchE(p_c); }
         fetch_idx(s + 4);
         fetch_off(s + 3);
+#else
+        if (s + 2 < n_slab) { fetchX(p_c, s + 2); }
+        fetch_idx(s + 4);
+#endif
         const _Float16 * Wb = Ws + Wcur + wfrag;
         const _Float16 * Xb = Xs + (size_t) P * FD_N * FD_LD + xfrag;
         half8 xf[2][2], wf[2][2];
@@ -315,9 +373,14 @@ void w0d_mfma_kernel(const _Float16 * __restrict__ x16, int64_t ld16, int64_t T,
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
                     acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[ks & 1][a], wf[ks & 1][c], acc[a][c], 0, 0, 0);
+            if (ks == 0 && s + 1 < n_slab) scatter_read(q_c, Wnxt);
             if (ks == 0 && s + 2 < n_slab) commitW(p_c, Wnx2, 0);
             if (ks == 1 && s + 2 < n_slab) commitW(p_c, Wnx2, 1);
+#ifndef FD_ABL_NOSCATTER
             if (ks == 2 && s + 1 < n_slab) { commitX(q_c, P ^ 1, 0); scatter(q_c, Wnxt); }
+#else
+            if (ks == 2 && s + 1 < n_slab) { commitX(q_c, P ^ 1, 0); }
+#endif
             if (ks == 3 && s + 1 < n_slab) commitX(q_c, P ^ 1, 1);
         }
         __syncthreads();
@@ -338,6 +401,7 @@ void w0d_mfma_kernel(const _Float16 * __restrict__ x16, int64_t ld16, int64_t T,
         commitW(set1{}, Wnxt, 0); commitW(set1{}, Wnxt, 1);
     }
     __syncthreads();
+    scatter_read(set0{}, Wcur);
     scatter(set0{}, Wcur);
     fetch_idx(2);
     fetch_off(1);
@@ -415,22 +479,28 @@ int launch_w0_fold(DeviceWeight & w, const float * x, int64_t ldx, int64_t T, vo
     _Float16 * x16 = (_Float16 *) ((unsigned char *) ws + part_bytes);
     if ((rc = launch_w0_x16(x, ldx, T, (int) w.n_in, x16, ld16, T_pad, s)) != SDH_OK) return rc;
     const size_t lds = (size_t) (3 * FD_R + 2 * FD_N) * FD_LD * 2;
-    static const bool attr_ok =
-        hipFuncSetAttribute((const void *) w0d_mfma_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
-        hipFuncSetAttribute((const void *) w0d_mfma_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
-        hipFuncSetAttribute((const void *) w0d_mfma_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
-        hipFuncSetAttribute((const void *) w0d_mfma_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    static const bool attr_ok = [] {
+        bool ok = true;
+        const void * ks[8] = {(const void *) w0d_mfma_kernel<true, true, true>, (const void *) w0d_mfma_kernel<true, true, false>,
+                              (const void *) w0d_mfma_kernel<true, false, true>, (const void *) w0d_mfma_kernel<true, false, false>,
+                              (const void *) w0d_mfma_kernel<false, true, true>, (const void *) w0d_mfma_kernel<false, true, false>,
+                              (const void *) w0d_mfma_kernel<false, false, true>, (const void *) w0d_mfma_kernel<false, false, false>};
+        for (const void * k : ks) ok &= hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        return ok;
+    }();
     if (!attr_ok) return 1;                                     // a device without the LDS for it: the caller's other forms
     const dim3 grid((unsigned) ((w.n_out + FD_R - 1) / FD_R), (unsigned) (T_pad / FD_N), (unsigned) (w.tall ? 1 : w.B));
     if (grid.y > 65535 || grid.z > 65535) { set_error("w0 fold: token chunk too large"); return SDH_ERR_UNSUPPORTED; }
     const bool scaled = w.pack.off_d1 >= 0 || w.pack.off_d3 >= 0;          // else d1 = d3 = 1 (what the builder writes)
     float * out = w.tall ? y : part;
     const int64_t ldo = w.tall ? ldy : (int64_t) w.B * w.L;
-#define SDH_FD_LAUNCH(TALL_, SC_) hipLaunchKernelGGL((w0d_mfma_kernel<TALL_, SC_>), grid, dim3(512), lds, s, x16, ld16, T, \
+#define SDH_FD_LAUNCH(TALL_, SC_, AT_) hipLaunchKernelGGL((w0d_mfma_kernel<TALL_, SC_, AT_>), grid, dim3(512), lds, s, x16, ld16, T, \
         (int) w.n_in, (int) w.n_out, (int) w.L, w.d1, w.d3, w.G, w.inv, w.fold_ent, w.fold_off, w.fold_ng, w.fold_spb, w.rs, out, ldo, \
         nf_counter, zero_nf ? 1 : 0)
-    if (w.tall) { if (scaled) SDH_FD_LAUNCH(true, true); else SDH_FD_LAUNCH(true, false); }
-    else        { if (scaled) SDH_FD_LAUNCH(false, true); else SDH_FD_LAUNCH(false, false); }
+#define SDH_FD_LAUNCH2(TALL_, SC_) do { if (w.fold_dup) SDH_FD_LAUNCH(TALL_, SC_, true); else SDH_FD_LAUNCH(TALL_, SC_, false); } while (0)
+    if (w.tall) { if (scaled) SDH_FD_LAUNCH2(true, true); else SDH_FD_LAUNCH2(true, false); }
+    else        { if (scaled) SDH_FD_LAUNCH2(false, true); else SDH_FD_LAUNCH2(false, false); }
+#undef SDH_FD_LAUNCH2
 #undef SDH_FD_LAUNCH
     SDH_HIP_CHECK(hipGetLastError());
     if (!w.tall) {

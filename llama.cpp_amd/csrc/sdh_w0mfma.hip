@@ -116,20 +116,27 @@ constexpr int MT_R = 128, MT_N = 256, MT_K = 64, MT_LD = 72;
 
 __global__ __launch_bounds__(256)
 void w0_x16_kernel(const float * __restrict__ x, int64_t ldx, int64_t T, int n_in, _Float16 * __restrict__ x16, int64_t ld16, int64_t T_pad) {
-    const int64_t e = ((int64_t) blockIdx.x * 256 + threadIdx.x) * 8;            // 8 consecutive k of one token
-    if (e >= T_pad * ld16) return;
-    const int64_t t = e / ld16;
-    const int k = (int) (e - t * ld16);
+    // blockIdx.y = token, threads over k in runs of 8 (no 64-bit division per thread; rows of x are 16-byte aligned when ldx % 4 == 0)
+    const int64_t t = blockIdx.y;
+    const int k = ((int) blockIdx.x * 256 + (int) threadIdx.x) * 8;
+    if (k >= ld16) return;
     half8 h;
+    const float * xr = x + t * ldx + k;
+    if (t < T && k + 8 <= n_in && (((uintptr_t) xr) & 15) == 0) {
+        const float4 a = *reinterpret_cast<const float4 *>(xr), c = *reinterpret_cast<const float4 *>(xr + 4);
+        h[0] = (_Float16) a.x; h[1] = (_Float16) a.y; h[2] = (_Float16) a.z; h[3] = (_Float16) a.w;
+        h[4] = (_Float16) c.x; h[5] = (_Float16) c.y; h[6] = (_Float16) c.z; h[7] = (_Float16) c.w;
+    } else {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) h[j] = (_Float16) ((t < T && k + j < n_in) ? x[t * ldx + k + j] : 0.0f);
-    *reinterpret_cast<half8 *>(x16 + e) = h;
+        for (int j = 0; j < 8; ++j) h[j] = (_Float16) ((t < T && k + j < n_in) ? xr[j] : 0.0f);
+    }
+    *reinterpret_cast<half8 *>(x16 + t * ld16 + k) = h;
 }
 
 // f16 image of x, zero-padded to whole tiles (also the pre-pass of the folded contraction, sdh_w0fold.hip)
 int launch_w0_x16(const float * x, int64_t ldx, int64_t T, int n_in, _Float16 * x16, int64_t ld16, int64_t T_pad, hipStream_t s) {
-    const int64_t n8 = T_pad * ld16 / 8;
-    hipLaunchKernelGGL(w0_x16_kernel, dim3((unsigned) ((n8 + 255) / 256)), dim3(256), 0, s, x, ldx, T, n_in, x16, ld16, T_pad);
+    if (T_pad > 65535) { set_error("w0 x16: token chunk too large"); return SDH_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(w0_x16_kernel, dim3((unsigned) ((ld16 / 8 + 255) / 256), (unsigned) T_pad), dim3(256), 0, s, x, ldx, T, n_in, x16, ld16, T_pad);
     SDH_HIP_CHECK(hipGetLastError());
     return SDH_OK;
 }
@@ -320,8 +327,7 @@ int launch_w0_mfma_tiled(const DeviceWeight & w, const float * x, int64_t ldx, i
     if (T <= 0) return SDH_OK;
     const int64_t T_pad = (T + MT_N - 1) / MT_N * MT_N;
     const int64_t ld16 = (w.n_in + MT_K - 1) / MT_K * MT_K + MT_K;
-    const int64_t n8 = T_pad * ld16 / 8;
-    hipLaunchKernelGGL(w0_x16_kernel, dim3((unsigned) ((n8 + 255) / 256)), dim3(256), 0, s, x, ldx, T, (int) w.n_in, x16_ws, ld16, T_pad);
+    { int rc = launch_w0_x16(x, ldx, T, (int) w.n_in, x16_ws, ld16, T_pad, s); if (rc != SDH_OK) return rc; }
     const size_t lds = (size_t) 2 * (MT_R + MT_N) * MT_LD * 2;
     static const bool attr_ok =
         hipFuncSetAttribute((const void *) w0_mfma_tile_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
