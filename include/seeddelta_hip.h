@@ -119,7 +119,11 @@ typedef enum sdh_op_kind {
                                       and token. f16 operands (x, W0 + delta), fp32 accumulation, row_scale in fp32:
                                       results within 2e-3 * sum|terms| of the CPU op (tests state it), not bit-identical
                                       to it. The first call on a handle re-lays the residual out by (row tile, k-slab)
-                                      on the device (once; it doubles the payload's footprint in HBM).          */
+                                      on the device (once; it doubles the payload's footprint in HBM). Without any
+                                      flag sdh_forward takes this form by itself where it wins by a wide margin: rows
+                                      of 512 entries and more from 160 tokens on (Mistral down, block 32, K = 1536:
+                                      0.15 against 0.32 ms per ubatch of 512).                                   */
+#define SDH_FWD_NO_MFMA      0x80  /* never choose SDH_FWD_MFMA_FOLD by default: keep the fp32 forms            */
 
 /* ---- library / device ----------------------------------------------------------------
  * sdh_init: bind the calling process to HIP device `device` and create the library's

@@ -571,7 +571,12 @@ static int sdh_forward_impl(sdh_weight * h, const float * x, int64_t ldx, int64_
     LibState & ls = lib();
     // Many tokens, one dense contraction per tensor: the residual folded into the W0 tile in LDS (SDH_FWD_MFMA_FOLD;
     // f16 operands, fp32 accumulation). The call is complete after it: row scale, non-finite census, everything.
-    if ((flags & SDH_FWD_MFMA_FOLD) && has_base && !(flags & SDH_FWD_EXACT_ORDER) && !noalloc && !glu &&
+    // Taken on request, and by default where it wins by a wide margin: rows with 512 entries and more (config 3: block 32,
+    // K = 1536) from 160 tokens on — 0.15 ms per ubatch of 512 against 0.32 ms for the LDS rows kernel (T=128: 0.12 / 0.10,
+    // T=192: 0.13 / 0.15). SDH_FWD_NO_MFMA keeps the fp32 forms.
+    const int64_t row_entries = (w->kind == SDH_OP_BASE_BLOCK) ? w->nb * w->block : w->K;
+    const bool fold_default = row_entries >= 512 && n_tokens >= 160 && !(flags & (SDH_FWD_NO_MFMA | SDH_FWD_W0_MFMA | SDH_FWD_NO_SPMM | SDH_FWD_INTERNAL_ROWS));
+    if (((flags & SDH_FWD_MFMA_FOLD) || fold_default) && has_base && !(flags & SDH_FWD_EXACT_ORDER) && !noalloc && !glu &&
         w->w0_closed_form && w->L >= 128 && n_tokens > MAX_FUSED_TOKENS) {
         const int64_t fchunk = std::min<int64_t>(n_tokens, 2048);
         int rc = ensure_ws(w, w0_fold_ws_bytes(*w, fchunk));

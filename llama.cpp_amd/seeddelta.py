@@ -27,6 +27,7 @@ LIB_PATH = os.environ.get("SEEDDELTA_HIP_LIB") or os.path.join(HERE, "csrc", "li
 SDH_TYPE = {np.dtype(np.float32): 0, np.dtype(np.float16): 1, np.dtype(np.int16): 25, np.dtype(np.int32): 26}
 
 FWD_DEVICE_IO, FWD_HOST_IO, FWD_ZERO_NONFINITE, FWD_EXACT_ORDER, FWD_W0_MFMA, FWD_NO_FUSE, FWD_NO_SPMM = 0x0, 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
+FWD_NO_MFMA = 0x80            # keep the fp32 forms where sdh_forward would choose the folded contraction by itself
 FWD_MFMA_FOLD = 0x40          # prefill as one dense contraction, residual folded into the W0 tile (f16 operands)
 
 # every symbol include/seeddelta_hip.h declares (tests check the library exports all of them)

@@ -57,6 +57,11 @@ def test_prefill_T512_default_path(hip, cfg):
     if SPMM_EXACT[cfg]:
         assert np.array_equal(bits(y), bits(y_ref)), f"{cfg}: max abs diff {np.abs(y - y_ref).max()}"
     else:
+        # rows of 512 entries and more: sdh_forward chooses the folded MFMA contraction from 160 tokens on (f16 bound,
+        # test_prefill_T512_mfma_fold); SDH_FWD_NO_MFMA keeps the fp32 row kernels, checked here
+        assert np.array_equal(bits(y), bits(w.forward_host(x, hip.FWD_MFMA_FOLD)))
+        y = w.forward_host(x, hip.FWD_NO_MFMA)
+        assert not np.array_equal(bits(y), bits(w.forward_host(x, hip.FWD_MFMA_FOLD)))
         assert np.abs(y - y_ref).max() <= 1e-4 * np.abs(y_ref).max()          # every element, coarse
         sel = token_sample()
         check_fast(p, x[sel], y[sel], y_ref[sel])                             # sampled tokens, the stated bound
