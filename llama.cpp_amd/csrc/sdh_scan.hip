@@ -525,6 +525,82 @@ __device__ __forceinline__ void bitonic_desc(int n, CMP swap_if_needed) {
     }
 }
 
+// lane ^ m partner of a 32-bit value (m a power of two, uniform) without the LDS crossbar: half-register swaps for
+// m = 32 / 16, DPP moves inside a 16-lane row below (a ds_bpermute per value made the register sort LDS-bound)
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_u32(uint32_t a) {
+    return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) a, CTRL, 0xF, 0xF, true);
+}
+__device__ __forceinline__ uint32_t lane_xor_u32(uint32_t v, int m, int lane) {
+    switch (m) {
+        case 32: { const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); return (lane & 32) ? r[0] : r[1]; }
+        case 16: { const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); return (lane & 16) ? r[0] : r[1]; }
+        case 8:  return dpp_u32<0x128>(v);                                       // row_ror:8
+        case 4:  { const uint32_t a = dpp_u32<0x104>(v), b = dpp_u32<0x114>(v);  // row_shl:4 (i <- i+4), row_shr:4 (i <- i-4)
+                   return (lane & 4) ? b : a; }
+        case 2:  return dpp_u32<0x4E>(v);                                        // quad_perm [2,3,0,1]
+        default: return dpp_u32<0xB1>(v);                                        // quad_perm [1,0,3,2]
+    }
+}
+
+// Bitonic sort (descending) of n = 256 * E 64-bit keys held E per thread, element i = tid * E + e. The network and
+// its result are those of the LDS form below (the keys are distinct, so any correct sorting network gives the same
+// order); what changes is where a compare-exchange finds its partner: strides below E in the thread's own registers,
+// strides below 64 * E in another lane of the wave (two DPP moves or half-register swaps per key), and only the strides that cross waves —
+// three stages for 1024 or 2048 keys instead of 55 or 66 — go through LDS with a barrier.
+template <int E, int K2, int J>
+__device__ __forceinline__ void bitonic_stage(uint64_t (&v)[E], uint64_t * sbuf, int tid) {
+    if constexpr (J >= 64 * E) {                              // partner in another wave
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; ++e) sbuf[tid * E + e] = v[e];
+        __syncthreads();
+        const int pt = tid ^ (J / E);
+        const bool keep_max = (((tid * E) & K2) == 0) == (((tid * E) & J) == 0);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const uint64_t y = sbuf[pt * E + e];
+            v[e] = keep_max ? (v[e] > y ? v[e] : y) : (v[e] < y ? v[e] : y);
+        }
+    } else if constexpr (J >= E) {                            // partner in this wave
+        const bool keep_max = (((tid * E) & K2) == 0) == (((tid * E) & J) == 0);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const uint32_t lo = lane_xor_u32((uint32_t) v[e], J / E, tid & 63);
+            const uint32_t hi = lane_xor_u32((uint32_t) (v[e] >> 32), J / E, tid & 63);
+            const uint64_t y = ((uint64_t) hi << 32) | lo;
+            v[e] = keep_max ? (v[e] > y ? v[e] : y) : (v[e] < y ? v[e] : y);
+        }
+    } else {                                                  // partner in this thread
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if ((e & J) == 0) {
+                const bool desc = (((tid * E + e) & K2) == 0);
+                const uint64_t a = v[e], b = v[e | J];
+                const bool sw = desc ? (a < b) : (a > b);
+                v[e] = sw ? b : a; v[e | J] = sw ? a : b;
+            }
+        }
+    }
+    if constexpr (J > 1) bitonic_stage<E, K2, J / 2>(v, sbuf, tid);
+}
+template <int E, int K2>
+__device__ __forceinline__ void bitonic_merge_levels(uint64_t (&v)[E], uint64_t * sbuf, int tid) {
+    bitonic_stage<E, K2, K2 / 2>(v, sbuf, tid);
+    if constexpr (K2 < 256 * E) bitonic_merge_levels<E, K2 * 2>(v, sbuf, tid);
+}
+template <int E>
+__device__ __forceinline__ void bitonic_desc_regs(uint64_t * sbuf) {
+    const int tid = threadIdx.x;
+    uint64_t v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = sbuf[tid * E + e];
+    bitonic_merge_levels<E, 2>(v, sbuf, tid);                 // every stride a compile-time constant: the lane exchanges fold to one DPP move or swap
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e) sbuf[tid * E + e] = v[e];
+    __syncthreads();
+}
+
 // A K schedule evaluated from ONE selection (the builder fits once per tensor and runs a trial per K,
 // sd_build.cpp:444-451, :843-913): rows are selected and sorted at the largest K; descending order with
 // ties by ascending index makes the top-K of every smaller K a prefix of that row. k[j] counts idx entries
@@ -624,7 +700,16 @@ void scan_select_coo_kernel(DenseView W, BaseView base, int has_base, int K /* t
 
     // bitonic sort, descending; a thread's pairs of one stage are disjoint, so their loads are issued
     // together (four LDS round trips per stage become one)
-    for (int k = 2; k <= Kpad; k <<= 1) {
+    // 512 keys and more: E per thread in registers (bitonic_desc_regs); fewer: the LDS form
+    int k_first = 2;
+    switch (Kpad) {
+        case 512:  bitonic_desc_regs<2>(sbuf);  k_first = Kpad + 1; break;
+        case 1024: bitonic_desc_regs<4>(sbuf);  k_first = Kpad + 1; break;
+        case 2048: bitonic_desc_regs<8>(sbuf);  k_first = Kpad + 1; break;
+        case 4096: bitonic_desc_regs<16>(sbuf); k_first = Kpad + 1; break;
+        default: break;
+    }
+    for (int k = k_first; k <= Kpad; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int t0 = 0; t0 < (Kpad >> 1); t0 += 256 * 4) {
                 uint64_t x[4], y[4];
