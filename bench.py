@@ -250,7 +250,7 @@ def run_scan(args, rank, world, dev):
     peak = HBM_PEAK_GBS * world
     roof = lambda a, el: {"bound": "hbm", "achieved": a / el / 1e9, "peak": peak, "unit": "GB/s", "frac": a / el / 1e9 / peak}  # noqa: E731
     r_full = roof(a_full, el_full)
-    per_c = traffic["sweep"].get("hbm_bytes_per_candidate_payload_emission") if traffic else None
+    per_c = traffic.get("payload", {}).get("hbm_bytes_per_candidate") if traffic else None
     r_full.update({"traffic": per_c, "traffic_source": tsrc if per_c else None,
                    "algorithmic_bytes_per_candidate": a_full / len(cands),
                    "note": "achieved = (quantised tensor once per K schedule + emitted idx/val/row_scale per candidate) / "

@@ -246,10 +246,24 @@ constexpr int FIT_ROWS_PER_STAGE = 8;
 template <int FT, bool FAST>
 __global__ __launch_bounds__(FT)
 void scan_fit_lds_q8_kernel(DenseView W, int L, int tall, const FitJob * __restrict__ jobs, const int * __restrict__ rows,
-                            const int * __restrict__ perms, const float * __restrict__ ws, double * __restrict__ out /* [n_jobs][3][L] */) {
+                            const int * __restrict__ perms, const float * __restrict__ ws, double * __restrict__ out /* [n_jobs][3][L] */,
+                            int xcd_per, int jobs_per_block) {
     extern __shared__ __align__(16) unsigned char fit_smem[];
     constexpr int R = FIT_ROWS_PER_STAGE;
-    const FitJob job = jobs[blockIdx.y];
+    // Which (job, bin chunk) this workgroup takes. The jobs of one base block (its permutation trials) and their bin
+    // chunks all stage the SAME sampled row segments; workgroups are dealt to the 8 XCDs round-robin in launch order,
+    // so with the plain (chunk, job) = blockIdx mapping the 16 workgroups of a block sat on all 8 XCDs and every row
+    // segment was fetched into 8 L2s (measured: 8.5x the algorithmic bytes). xcd_per > 0: the workgroups of a block
+    // go to xcd_per neighbouring XCDs (Mistral: 4 blocks x 2 XCDs), so a segment crosses the fabric xcd_per times.
+    int job_id = (int) blockIdx.y, chunk_id = (int) blockIdx.x;
+    if (xcd_per > 0) {
+        const int lin = (int) (blockIdx.x + gridDim.x * blockIdx.y), chunks = (int) gridDim.x;
+        const int xcd = lin & 7, slot = lin >> 3, M = jobs_per_block * chunks;
+        const int item = (xcd % xcd_per) * (M / xcd_per) + slot;
+        job_id = (xcd / xcd_per) * jobs_per_block + item / chunks;
+        chunk_id = item % chunks;
+    }
+    const FitJob job = jobs[job_id];
     const int n_rows_pad = (job.n_rows + 3) & ~3;
     int *     perm_s = (int *) fit_smem;                               // [L]
     int *     rows_s = perm_s + L;                                     // [n_rows]: the job's sampled rows
@@ -267,7 +281,7 @@ void scan_fit_lds_q8_kernel(DenseView W, int L, int tall, const FitJob * __restr
     }
     for (int i = tid; i < job.n_rows; i += FT) rows_s[i] = rows[job.rows_off + i];
     __syncthreads();
-    const int u = blockIdx.x * FT + tid;
+    const int u = chunk_id * FT + tid;
     const int nd = L >> 5;
 
     // a stage = R rows of the job: R*L/16 16-byte pieces and R*L/32 scales, fetched into registers
@@ -409,7 +423,7 @@ void scan_fit_lds_q8_kernel(DenseView W, int L, int tall, const FitJob * __restr
             if (s0 + R < job.n_rows) stage(set1{}, set0{}, std::false_type{}, s0 + R);
         }
     }
-    double * o = out + (size_t) blockIdx.y * 3 * L;
+    double * o = out + (size_t) job_id * 3 * L;
     o[u] = s; o[L + u] = s2; o[2 * L + u] = n;
 }
 
@@ -542,6 +556,18 @@ __device__ __forceinline__ uint32_t lane_xor_u32(uint32_t v, int m, int lane) {
     }
 }
 
+// all lanes of the wave receive the sum / the maximum (strides written out: each exchange folds to one DPP move or swap)
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t c, int lane) {
+    c += lane_xor_u32(c, 32, lane); c += lane_xor_u32(c, 16, lane); c += lane_xor_u32(c, 8, lane);
+    c += lane_xor_u32(c, 4, lane);  c += lane_xor_u32(c, 2, lane);  c += lane_xor_u32(c, 1, lane);
+    return c;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t c, int lane) {
+    c = max(c, lane_xor_u32(c, 32, lane)); c = max(c, lane_xor_u32(c, 16, lane)); c = max(c, lane_xor_u32(c, 8, lane));
+    c = max(c, lane_xor_u32(c, 4, lane));  c = max(c, lane_xor_u32(c, 2, lane));  c = max(c, lane_xor_u32(c, 1, lane));
+    return c;
+}
+
 // Bitonic sort (descending) of n = 256 * E 64-bit keys held E per thread, element i = tid * E + e. The network and
 // its result are those of the LDS form below (the keys are distinct, so any correct sorting network gives the same
 // order); what changes is where a compare-exchange finds its partner: strides below E in the thread's own registers,
@@ -641,10 +667,45 @@ void scan_select_coo_kernel(DenseView W, BaseView base, int has_base, int K /* t
         hist[tid] = 0;
         __syncthreads();
         if (pass == 0) {
-            for (int i0 = 0; i0 < n_in; i0 += 256) {      // whole waves stay in the loop: the ballots need them
-                const int i = i0 + tid;
-                const bool act = i < n_in;
-                hist_add_aggregated(hist, act ? (key_of(i) >> 24) : 0u, act);
+            // The top byte (sign + 7 exponent bits) of a weight row's scores takes a handful of values just below the
+            // row's largest. Each thread counts its elements into eight 8-bit fields of one register pair — the eight
+            // bins from the row maximum's down — the waves add their fields up with lane exchanges and four lanes
+            // per bin touch the LDS histogram: no ballot loop and no LDS atomic per element (0.10 of 0.43 ms per
+            // selection of a Mistral gate went there, 0.27 of 0.70 for down). If the K-th key lies below the window,
+            // or a thread owns more elements than a field counts, the general form runs instead.
+            uint32_t tmax = 0;
+            for (int i = tid; i < n_in; i += 256) tmax = max(tmax, key_of(i) >> 24);
+            tmax = wave_max_u32(tmax, tid & 63);
+            if ((tid & 63) == 0) isc[2 + (tid >> 6)] = (int) tmax;
+            __syncthreads();
+            const uint32_t bmax = (uint32_t) max(max(isc[2], isc[3]), max(isc[4], isc[5]));
+            __syncthreads();
+            bool windowed = n_in <= 255 * 256;
+            if (windowed) {
+                uint64_t packed = 0;
+                for (int i = tid; i < n_in; i += 256) {
+                    const uint32_t d = bmax - (key_of(i) >> 24);
+                    packed += d < 8u ? (1ull << (8u * d)) : 0ull;
+                }
+                int in_window = 0;
+#pragma unroll
+                for (int d = 0; d < 8; ++d) {
+                    const uint32_t c = wave_sum_u32((uint32_t) (packed >> (8 * d)) & 255u, tid & 63);
+                    if ((tid & 63) == 0 && c && bmax >= (uint32_t) d) atomicAdd(&hist[bmax - d], c);
+                    in_window += (int) c;
+                }
+                if ((tid & 63) == 0) isc[2 + (tid >> 6)] = in_window;
+                __syncthreads();
+                windowed = isc[2] + isc[3] + isc[4] + isc[5] >= need;      // uniform: every thread reads the same four words
+                __syncthreads();
+                if (!windowed) { hist[tid] = 0; __syncthreads(); }
+            }
+            if (!windowed) {
+                for (int i0 = 0; i0 < n_in; i0 += 256) {      // whole waves stay in the loop: the ballots need them
+                    const int i = i0 + tid;
+                    const bool act = i < n_in;
+                    hist_add_aggregated(hist, act ? (key_of(i) >> 24) : 0u, act);
+                }
             }
         } else {
             for (int i = tid; i < n_in; i += 256) {
@@ -733,6 +794,9 @@ void scan_select_coo_kernel(DenseView W, BaseView base, int has_base, int K /* t
         }
     }
 
+#ifdef SEL_ABL_NOWRITE
+    if (K < 0)
+#endif
     for (int rr = tid; rr < K; rr += 256) {
         const int i = (int) (0xffffffffu - (uint32_t) sbuf[rr]);
         idx_out[orow * K + rr] = i;
@@ -1618,17 +1682,30 @@ static int scan_grid_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * 
                 hipFuncSetAttribute((const void *) scan_fit_lds_q8_kernel<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
                 hipFuncSetAttribute((const void *) scan_fit_lds_q8_kernel<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
             if (!attr_ok) { set_error("scan: raising the dynamic LDS limit failed"); return SDH_ERR_HIP; }
+            // XCD-aware deal (see the kernel): the jobs of a base block are consecutive in the plan
+            int xcd_per = 0, jobs_per_block = 1;
+            {
+                int G = 0, last_b = -1;
+                for (const FitJob & j : pl.jobs) if (j.b != last_b) { ++G; last_b = j.b; }
+                static const bool no_remap = getenv("SDH_SCAN_FIT_NO_XCD") != nullptr;       // A/B
+                if (G > 0 && n_jobs % G == 0 && 8 % G == 0 && !no_remap) {
+                    const int tr = n_jobs / G, per = 8 / G, M = tr * (int) (L / 1024);
+                    bool grouped = true;
+                    for (int j = 0; j < n_jobs; ++j) grouped &= pl.jobs[j].b == pl.jobs[j / tr * tr].b;
+                    if (grouped && M % per == 0) { xcd_per = per; jobs_per_block = tr; }
+                }
+            }
             static const bool fit_slow = getenv("SDH_SCAN_FIT_GENERAL") != nullptr;          // A/B: the general body
             const bool fast = !ws_dev && !fit_slow;                  // per job: blocks wholly inside the inputs take the short body
             if (fit_256)
                 hipLaunchKernelGGL((scan_fit_lds_q8_kernel<256, false>), dim3((unsigned) (L / 256), (unsigned) n_jobs), dim3(256), fit_lds, st,
-                                   W, (int) L, tall ? 1 : 0, pl.jobs_dev, pl.rows_dev, pl.perms_dev, ws_dev, s.dbl.p);
+                                   W, (int) L, tall ? 1 : 0, pl.jobs_dev, pl.rows_dev, pl.perms_dev, ws_dev, s.dbl.p, 0, 1);
             else if (fast)
                 hipLaunchKernelGGL((scan_fit_lds_q8_kernel<1024, true>), dim3((unsigned) (L / 1024), (unsigned) n_jobs), dim3(1024), fit_lds, st,
-                                   W, (int) L, tall ? 1 : 0, pl.jobs_dev, pl.rows_dev, pl.perms_dev, ws_dev, s.dbl.p);
+                                   W, (int) L, tall ? 1 : 0, pl.jobs_dev, pl.rows_dev, pl.perms_dev, ws_dev, s.dbl.p, xcd_per, jobs_per_block);
             else
                 hipLaunchKernelGGL((scan_fit_lds_q8_kernel<1024, false>), dim3((unsigned) (L / 1024), (unsigned) n_jobs), dim3(1024), fit_lds, st,
-                                   W, (int) L, tall ? 1 : 0, pl.jobs_dev, pl.rows_dev, pl.perms_dev, ws_dev, s.dbl.p);
+                                   W, (int) L, tall ? 1 : 0, pl.jobs_dev, pl.rows_dev, pl.perms_dev, ws_dev, s.dbl.p, xcd_per, jobs_per_block);
         } else {
             SDH_LAUNCH_DT(W, scan_fit_kernel, dim3((unsigned) (L / threads), (unsigned) n_jobs), dim3(threads),
                           (size_t) L * sizeof(int), st, W, (int) L, tall ? 1 : 0, pl.jobs_dev, pl.rows_dev, pl.perms_dev, ws_dev, s.dbl.p);
