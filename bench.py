@@ -193,9 +193,7 @@ def run_scan(args, rank, world, dev):
         barrier()
         t0 = time.perf_counter()
         if upload_first:
-            for c in mine:
-                for k in (SC.KINDS if c.kind != "ffn_down" else (c.kind,)):
-                    ev.dense(c.layer, k)
+            ev.preload([(c.layer, k) for c in mine for k in (SC.KINDS if c.kind != "ffn_down" else (c.kind,))], threads=threads)
         res = ev.run_many(mine, threads=threads, params_of=lambda c: variants[c.variant])
         local = np.stack([SC.to_record(c, r) for c, r in zip(mine, res)]) if mine else np.zeros((0, SC.RECORD_LEN))
         allr = SC.gather_records(local, counts, device=None if one_dev else dev)
@@ -697,6 +695,17 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": kname, "avg_kernel_us": dur_s * 1e6, "launches": n, "timing": how,
                 "algorithmic_bytes_per_launch": alg_bytes}
+        if T == 1:
+            # the device's floor for one launch per token: a kernel that only streams the payload's bytes once, launched
+            # back to back over 32 distinct buffers (sdh_probe_stream_floor), and an empty launch of the same shape
+            try:
+                us_stream, us_empty = seeddelta.probe_stream_floor(int(alg_bytes), n_buffers=NP, reps=32, stream=sp)
+                roof["attainable"] = {"us_per_launch": us_stream, "frac": alg_bytes / (us_stream * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                      "empty_launch_us": us_empty,
+                                      "note": "a launch that only streams these bytes once (no base term, no gathers), back to back: "
+                                              "what one launch per token can reach on this device"}
+            except Exception as exc:                        # the probe is a measurement aid, never a reason to fail the bench
+                roof["attainable"] = {"error": str(exc)[:120]}
 
     host_io = None
     if args.host_io and rank == 0:
@@ -769,7 +778,9 @@ def main():
             line["detail_file"] = None
         r3 = lambda v: None if v is None else float("%.4g" % v)         # noqa: E731
         if roof is not None:
-            line["roofline"] = {k: (r3(v) if isinstance(v, float) else v) for k, v in roof.items() if k not in ("timing",)}
+            line["roofline"] = {k: (r3(v) if isinstance(v, float) else v) for k, v in roof.items() if k not in ("timing", "attainable")}
+            if isinstance(roof.get("attainable"), dict) and "frac" in roof["attainable"]:
+                line["roofline"]["attainable"] = {k: r3(v) for k, v in roof["attainable"].items() if k != "note"}
         if cpu is not None:
             line["cpu_baseline"] = dict(cpu, value=r3(cpu["value"]), sample=cpu["sample"][:120])
         if host_io is not None:

@@ -438,6 +438,12 @@ int sdh_profile_read(double * total_ms, int64_t * launches);
  * (the fused decode launch) elapsed / launches is that kernel's back-to-back launch period. */
 int sdh_profile_span_begin(void * stream);
 int sdh_profile_span_end(void * stream, double * elapsed_ms, int64_t * forwards);
+/* The device's floor for a launch that reads `bytes` once and does nothing else (a wave per 3072-byte run, 16-byte
+ * non-temporal loads, one store per wave), launched back to back on `stream` over n_buffers distinct buffers the call
+ * allocates and frees (pick n_buffers * bytes above the 256 MB Infinity Cache): microseconds per launch in *us_stream,
+ * and of an empty launch of the same shape in *us_empty (may be NULL). bench.py reports it as roofline.attainable:
+ * what a one-launch-per-token decode of that payload size could reach at best on this device. */
+int sdh_probe_stream_floor(int64_t bytes, int n_buffers, int reps, void * stream, double * us_stream, double * us_empty);
 
 #ifdef __cplusplus
 }

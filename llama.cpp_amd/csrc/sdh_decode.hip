@@ -177,6 +177,9 @@ void decode_fused_kernel(const DeltaParams p, const BasePackDesc pd, const Fused
         const int tid = threadIdx.x;
         if constexpr (RW * 64 > (1 << LOG_T)) { if (tid >= (1 << LOG_T)) return; }   // whole extra waves leave: barriers count live waves
         __builtin_amdgcn_s_setprio(SDH_BASE_PRIO);     // the base blocks are the critical path of the launch
+#ifdef SDH_DBG_NOBASE              // dev A/B: ... without the base role's work
+        return;
+#endif
         float y[E];
         base_transform<Ly, false, true>(p.x, p.n_in, p.tall ? 0 : b * L, p.x_vec_ok != 0, pd, b, lds, tid, y);
         // Publish as {value, epoch} granules, one agent-scope (sc1, write-through) 8-byte store each,
@@ -223,8 +226,12 @@ void decode_fused_kernel(const DeltaParams p, const BasePackDesc pd, const Fused
     if (leader && p.rs) scale = p.rs[o];
 
     SDH_STAMP(10);
+#ifdef SDH_DBG_NOSTREAM            // dev A/B (tools/build_variants.sh): what the launch costs without the payload stream
+    float acc = 0.0f;
+#else
     float acc = delta_row_partial<uint16_t, uint16_t, BLOCK, STEPS, true>(p, p.x, orow, row_ok, l, G);
     acc = group_reduce(acc, G);
+#endif
     SDH_STAMP(11);
 
     if (leader) {
@@ -233,9 +240,14 @@ void decode_fused_kernel(const DeltaParams p, const BasePackDesc pd, const Fused
         const int nbase = p.tall ? 1 : p.B;             // host guarantees nbase <= 8
         float vals[8];
         bool ok;
+#ifdef SDH_DBG_NOPOLL              // dev A/B: ... without waiting for the base term
+        ok = true;
+        for (int b = 0; b < 8; ++b) vals[b] = 0.0f;
+#else
         if (nbase == 1)      ok = poll_granules<1>(fa, o, L, nbase, vals);
         else if (nbase <= 4) ok = poll_granules<4>(fa, o, L, nbase, vals);
         else                 ok = poll_granules<8>(fa, o, L, nbase, vals);
+#endif
         SDH_STAMP(12);
         float yh;
         if (p.tall) yh = vals[0];

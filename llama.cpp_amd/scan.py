@@ -619,6 +619,20 @@ class Evaluator:
             self._order.append(key)
         return self._cache[key]
 
+    def preload(self, keys: Sequence[Tuple[int, str]], threads: int = 8):
+        """Materialise and upload several dense tensors concurrently (reading / dequantising a tensor and the
+        host-to-device copy both release the GIL): what a rank does with ITS layers at the start of a sharded
+        scan. Needs room for all of them (no eviction while the pool runs)."""
+        todo = [k for k in dict.fromkeys(keys) if k not in self._cache]
+        if len(self._order) + len(todo) > self.max_resident:
+            for k in todo:                                              # not enough room: one by one, evicting
+                self.dense(*k)
+            return
+        pool = self._workers(threads)
+        for k, w in zip(todo, pool.map(lambda k: DenseWeight(self.model(*k)), todo)):
+            self._cache[k] = w
+            self._order.append(k)
+
     def run(self, c: Candidate, params: Optional[ScanParams] = None) -> dict:
         """One (layer, tensor, K) trial with the RNG position a serial per-layer builder run has when
         it reaches this tensor: fresh stream, earlier tensors of the layer skipped."""

@@ -34,7 +34,7 @@ FWD_MFMA_FOLD = 0x40          # prefill as one dense contraction, residual folde
 ABI_SYMBOLS = [
     "sdh_init", "sdh_abi_version", "sdh_last_error", "sdh_device_synchronize", "sdh_library_stream",
     "sdh_weight_create", "sdh_weight_destroy", "sdh_weight_op_kind", "sdh_weight_payload_bytes",
-    "sdh_forward", "sdh_forward_noalloc", "sdh_noalloc_scratch_bytes", "sdh_debug_alloc_calls", "sdh_nonfinite_count", "sdh_w0_tile", "sdh_ffn_forward", "sdh_ffn_gate_up", "sdh_ffn_last_fused", "sdh_glu",
+    "sdh_forward", "sdh_forward_noalloc", "sdh_noalloc_scratch_bytes", "sdh_debug_alloc_calls", "sdh_probe_stream_floor", "sdh_nonfinite_count", "sdh_w0_tile", "sdh_ffn_forward", "sdh_ffn_gate_up", "sdh_ffn_last_fused", "sdh_glu",
     "sdh_ffn_stack_create", "sdh_ffn_stack_destroy", "sdh_ffn_stack_forward", "sdh_ffn_stack_status", "sdh_ffn_stack_payload_bytes",
     "sdh_profile_enable", "sdh_profile_read", "sdh_profile_span_begin", "sdh_profile_span_end",
     "sdh_dense_create", "sdh_dense_destroy", "sdh_dense_bytes",
@@ -213,6 +213,14 @@ def profile_span_end(stream: int = 0):
     _check(load_library().sdh_profile_span_end(C.c_void_p(stream) if stream else None, C.byref(ms), C.byref(n)),
            "sdh_profile_span_end")
     return ms.value, n.value
+
+
+def probe_stream_floor(nbytes: int, n_buffers: int = 32, reps: int = 64, stream: int = 0):
+    """-> (us per launch of a kernel that only streams `nbytes` once, us per empty launch of that shape)."""
+    a, b = C.c_double(0.0), C.c_double(0.0)
+    _check(load_library().sdh_probe_stream_floor(C.c_int64(nbytes), n_buffers, reps, C.c_void_p(stream) if stream else None,
+                                                 C.byref(a), C.byref(b)), "sdh_probe_stream_floor")
+    return a.value, b.value
 
 
 class SeedDeltaWeight:

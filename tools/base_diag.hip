@@ -22,8 +22,9 @@ static sdh_tensor mk(const void * d, int type, int nd, int64_t n0, int64_t n1, s
     return t;
 }
 
-int main() {
-    const int L = 4096, B = 4, NIN = 14336, NOUT = 4096, NPAY = 32, ITERS = 256;
+int main(int argc, char ** argv) {
+    const int L = argc > 1 ? atoi(argv[1]) : 4096;        // base block length: 1024 / 2048 / 4096 (how does one block's chain scale with L?)
+    const int B = 4, NIN = L * 7 / 2, NOUT = L, NPAY = 32, ITERS = 256;
     CK(hipSetDevice(0));
     if (sdh_init(0) != 0) { fprintf(stderr, "init: %s\n", sdh_last_error()); return 1; }
     hipStream_t s;
@@ -72,7 +73,7 @@ int main() {
         for (int k : ks) { double m = 0; for (int b = 0; b < B; ++b) m += (double) (hdv[b * 16 + k] - hdv[b * 16]) * 0.01; acc[k] += m / B; }
         ++n;
     }
-    printf("base_apply_kernel<4> cold, cumulative us since kernel start (mean over %d launches, %d blocks):\n", n, B);
+    printf("base_apply_kernel, L = %d, cold, cumulative us since kernel start (mean over %d launches, %d blocks):\n", L, n, B);
     printf("  x landed (and d1 applied)   %7.2f\n", acc[1] / n);
     printf("  perm1 gather                %7.2f\n", acc[2] / n);
     printf("  first FWHT                  %7.2f\n", acc[3] / n);
