@@ -585,7 +585,7 @@ __device__ __forceinline__ void bitonic_stage(uint64_t (&v)[E], uint64_t * sbuf,
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const uint64_t y = sbuf[pt * E + e];
-            v[e] = keep_max ? (v[e] > y ? v[e] : y) : (v[e] < y ? v[e] : y);
+            v[e] = ((v[e] > y) == keep_max) ? v[e] : y;            // one 64-bit compare, two selects (equal keys are padding: either is right)
         }
     } else if constexpr (J >= E) {                            // partner in this wave
         const bool keep_max = (((tid * E) & K2) == 0) == (((tid * E) & J) == 0);
@@ -594,7 +594,7 @@ __device__ __forceinline__ void bitonic_stage(uint64_t (&v)[E], uint64_t * sbuf,
             const uint32_t lo = lane_xor_u32((uint32_t) v[e], J / E, tid & 63);
             const uint32_t hi = lane_xor_u32((uint32_t) (v[e] >> 32), J / E, tid & 63);
             const uint64_t y = ((uint64_t) hi << 32) | lo;
-            v[e] = keep_max ? (v[e] > y ? v[e] : y) : (v[e] < y ? v[e] : y);
+            v[e] = ((v[e] > y) == keep_max) ? v[e] : y;            // one 64-bit compare, two selects (equal keys are padding: either is right)
         }
     } else {                                                  // partner in this thread
 #pragma unroll
@@ -602,7 +602,7 @@ __device__ __forceinline__ void bitonic_stage(uint64_t (&v)[E], uint64_t * sbuf,
             if ((e & J) == 0) {
                 const bool desc = (((tid * E + e) & K2) == 0);
                 const uint64_t a = v[e], b = v[e | J];
-                const bool sw = desc ? (a < b) : (a > b);
+                const bool sw = (a < b) == desc;
                 v[e] = sw ? b : a; v[e | J] = sw ? a : b;
             }
         }
