@@ -631,7 +631,7 @@ __device__ __forceinline__ void bitonic_desc_regs(uint64_t * sbuf) {
 // sd_build.cpp:444-451, :843-913): rows are selected and sorted at the largest K; descending order with
 // ties by ascending index makes the top-K of every smaller K a prefix of that row. k[j] counts idx entries
 // (COO: residuals; block: kept blocks). Row scales and metric results are laid out [j][slot].
-struct KGrid { int n; int k[SDH_SCAN_MAX_K]; };
+struct KGrid { int n; int k[SDH_SCAN_MAX_K]; int ord[SDH_SCAN_MAX_K]; };      // ord: the members by ascending k (ties by position)
 
 template <int DT>
 __global__ __launch_bounds__(256)
@@ -805,10 +805,15 @@ void scan_select_coo_kernel(DenseView W, BaseView base, int has_base, int K /* t
     if (want_rs) {
         // the least-squares scale of every K of the schedule: each thread adds its entries rr = tid, tid + 256, ...
         // below K_j, the order a selection at K_j alone would use
+        // ONE walk over the stored row in ascending k: a thread's running sums at the boundary k_j are exactly the sums
+        // a selection at k_j alone forms (its own entries rr = tid, tid + 256, .. below k_j, in that order), so every
+        // member's scale has the bits of a lone call and the row is read once instead of once per member
         const double d_row = block_sum(dot, dsc), n_row = block_sum(nn, dsc);
-        for (int j = 0; j < kg.n; ++j) {
-            double dot2 = 0.0, nn2 = 0.0;
-            for (int rr = tid; rr < kg.k[j]; rr += 256) {
+        double dot2 = 0.0, nn2 = 0.0;
+        int rr = tid;
+        for (int jj = 0; jj < kg.n; ++jj) {
+            const int j = kg.ord[jj];
+            for (; rr < kg.k[j]; rr += 256) {
                 const int i = (int) (0xffffffffu - (uint32_t) sbuf[rr]);
                 const double wi = (double) dense_at<DT>(W, row, i), di = (double) r[i];
                 const double s1 = ws ? (double) ws[i] : 1.0;
@@ -1633,8 +1638,10 @@ static int scan_grid_impl(sdh_scan * h, const sdh_dense * Wh, const sdh_dense * 
         clamp_budget(pj, n_in, &K_eff_j[j], &keep_j[j]);
         K_eff = std::max(K_eff, K_eff_j[j]); keep = std::max(keep, keep_j[j]);
         kg.k[j] = (int) (p.scheme == 1 ? keep_j[j] : K_eff_j[j]);
+        kg.ord[j] = j;
         outs[j].K_eff = K_eff_j[j]; outs[j].n_blocks = keep_j[j];
     }
+    std::stable_sort(kg.ord, kg.ord + nK, [&](int a, int b) { return kg.k[a] < kg.k[b]; });
     const int64_t Ksel = p.scheme == 1 ? keep : K_eff;       // entries of idx per stored row
     int rc;
     SDH_HIP_CHECK(hipEventRecord(s.ev0, st));
