@@ -950,7 +950,10 @@ static int launch_nt_steps(int steps, int n_tok, const DeltaParams & p, const Ba
         }
     }
     // 3-4 tokens: rows of up to 2 steps per lane. With 3 steps the kernel needs > 80 VGPRs or spills, and
-    // measured slower than the two-kernel path (cfg3, T=4: 22.5 vs 18.7 us), which those shapes keep.
+    // measured slower than the two-kernel path (cfg3, T=4: 22.5 vs 18.7 us), which those shapes keep. Round 3 tried
+    // two passes of two tokens inside the one launch (the second pass re-reading the row from L2, the two-token form's
+    // arithmetic): the compiler still spills 31 registers around the 16-granule poll and the launch measured 25.5 us
+    // at 3 and 25.9 us at 4 tokens against 15.5 / 17.1 us for the two kernels. Not kept.
     switch (steps) {
         case 1: return launch_nt_inst<BLOCK, 1, LOG_E, LOG_T, 4>(p, pd, fa, n_tok, grid, s);
         case 2: return launch_nt_inst<BLOCK, 2, LOG_E, LOG_T, 4>(p, pd, fa, n_tok, grid, s);
