@@ -21,6 +21,12 @@
 //              slab), Xs[2][256][72] f16. 129 KB.
 //   adds       ds_pk_add_f16 (the pair that holds the element, the other half +0): no read-modify-write sequence,
 //              and duplicate (row, column) entries of a hand-made payload sum as the reference sums them.
+//   tried      sixteen waves of 32 rows x 64 tokens per workgroup (four waves per SIMD, 128 registers) instead of eight of
+//              64 x 64: the same time within 1 % (136.7 / 135.4 us per call on a Mistral gate) — the kernel is not short
+//              of independent chains; SQ counters (profiles/r03_e_pmc_fold_and_scan.json): MFMA busy 0.22, VALU 0.29,
+//              LDS 0.22, waves waiting 0.41 of their cycles, no pipe saturated. Per slab and CU the texture path
+//              moves 64 KB, the LDS 176 KB, the matrix pipe runs 128 MFMAs: ~0.5 + 0.7 + 0.5 us if nothing overlapped,
+//              1.9 us measured.
 //   wide       K is split by base block over blockIdx.z (as the tiled W0 kernel); partial products go to [T][B][L]
 //              and fold_reduce_kernel sums them in block order, applies row_scale and the non-finite census.
 #include "sdh_internal.h"
@@ -346,15 +352,6 @@ void w0d_mfma_kernel(const _Float16 * __restrict__ x16, int64_t ld16, int64_t T,
     // s+1; LDS: Wcur = W0+D of slab s, Wnxt = W0 of slab s+1 (its entries not yet added), Xs[p] = x of slab s.
     auto slab = [&](auto p_c, auto q_c, int s) {
         constexpr int P = decltype(p_c)::value;
-        if (s + 3 < n_slab) fetchW(q_c, s + 3);
-#ifndef FD_ABL_NOFETCHE
-        if (s + 2 < n_slab) { fetchX(p_c, s + 2); fetchE(p_c); }
-        fetch_idx(s + 4);
-        fetch_off(s + 3);
-#else
-        if (s + 2 < n_slab) { fetchX(p_c, s + 2); }
-        fetch_idx(s + 4);
-#endif
         const _Float16 * Wb = Ws + Wcur + wfrag;
         const _Float16 * Xb = Xs + (size_t) P * FD_N * FD_LD + xfrag;
         half8 xf[2][2], wf[2][2];
@@ -373,14 +370,15 @@ void w0d_mfma_kernel(const _Float16 * __restrict__ x16, int64_t ld16, int64_t T,
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
                     acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[ks & 1][a], wf[ks & 1][c], acc[a][c], 0, 0, 0);
+            // the global loads of the slabs ahead, spread over the multiply steps (one burst at the top of the slab
+            // measured 135 against 127 us per call on a Mistral gate)
+            if (ks == 0 && s + 3 < n_slab) fetchW(q_c, s + 3);
+            if (ks == 1 && s + 2 < n_slab) fetchX(p_c, s + 2);
+            if (ks == 2) { if (s + 2 < n_slab) fetchE(p_c); fetch_idx(s + 4); fetch_off(s + 3); }
             if (ks == 0 && s + 1 < n_slab) scatter_read(q_c, Wnxt);
             if (ks == 0 && s + 2 < n_slab) commitW(p_c, Wnx2, 0);
             if (ks == 1 && s + 2 < n_slab) commitW(p_c, Wnx2, 1);
-#ifndef FD_ABL_NOSCATTER
             if (ks == 2 && s + 1 < n_slab) { commitX(q_c, P ^ 1, 0); scatter(q_c, Wnxt); }
-#else
-            if (ks == 2 && s + 1 < n_slab) { commitX(q_c, P ^ 1, 0); }
-#endif
             if (ks == 3 && s + 1 < n_slab) commitX(q_c, P ^ 1, 1);
         }
         __syncthreads();
@@ -494,12 +492,13 @@ int launch_w0_fold(DeviceWeight & w, const float * x, int64_t ldx, int64_t T, vo
     const bool scaled = w.pack.off_d1 >= 0 || w.pack.off_d3 >= 0;          // else d1 = d3 = 1 (what the builder writes)
     float * out = w.tall ? y : part;
     const int64_t ldo = w.tall ? ldy : (int64_t) w.B * w.L;
-#define SDH_FD_LAUNCH(TALL_, SC_, AT_) hipLaunchKernelGGL((w0d_mfma_kernel<TALL_, SC_, AT_>), grid, dim3(512), lds, s, x16, ld16, T, \
-        (int) w.n_in, (int) w.n_out, (int) w.L, w.d1, w.d3, w.G, w.inv, w.fold_ent, w.fold_off, w.fold_ng, w.fold_spb, w.rs, out, ldo, \
-        nf_counter, zero_nf ? 1 : 0)
+#define SDH_FD_ARGS x16, ld16, T, (int) w.n_in, (int) w.n_out, (int) w.L, w.d1, w.d3, w.G, w.inv, w.fold_ent, w.fold_off, w.fold_ng, w.fold_spb, \
+        w.rs, out, ldo, nf_counter, zero_nf ? 1 : 0
+#define SDH_FD_LAUNCH(TALL_, SC_, AT_) hipLaunchKernelGGL((w0d_mfma_kernel<TALL_, SC_, AT_>), grid, dim3(512), lds, s, SDH_FD_ARGS)
 #define SDH_FD_LAUNCH2(TALL_, SC_) do { if (w.fold_dup) SDH_FD_LAUNCH(TALL_, SC_, true); else SDH_FD_LAUNCH(TALL_, SC_, false); } while (0)
     if (w.tall) { if (scaled) SDH_FD_LAUNCH2(true, true); else SDH_FD_LAUNCH2(true, false); }
     else        { if (scaled) SDH_FD_LAUNCH2(false, true); else SDH_FD_LAUNCH2(false, false); }
+#undef SDH_FD_ARGS
 #undef SDH_FD_LAUNCH2
 #undef SDH_FD_LAUNCH
     SDH_HIP_CHECK(hipGetLastError());
