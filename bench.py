@@ -231,12 +231,14 @@ def run_scan(args, rank, world, dev):
             with open(tpath) as fh:
                 traffic, tsrc = json.load(fh), "profiles/" + name
             break
-    # algorithmic bytes per candidate, SURVEY §8d: the quantised tensor read once per K schedule (work shared across a
-    # K grid is never counted twice) + the idx / val / row_scale emitted per candidate (int32 / fp32 staging)
+    # algorithmic bytes per candidate, SURVEY §8d: the quantised tensor read once per K schedule and the idx / val rows
+    # stored once per schedule at its largest K (every smaller K is a prefix of the stored row: work shared across a K
+    # grid is never counted twice), int32 / fp32 staging, + the candidate's own row scales
     q8_row = lambda n_in: n_in // 32 * 34                                                    # noqa: E731
     def alg_full(c):
         n_in, n_out = scan_dims(c.layer, c.kind)
-        return n_out * q8_row(n_in) / len(SCAN_K[c.kind]) + n_out * (8 * c.K + 4)
+        ks = SCAN_K[c.kind]
+        return (n_out * q8_row(n_in) + n_out * 8 * max(ks)) / len(ks) + n_out * 4
     # metrics-only: per K schedule the fit's sampled row blocks once + the rows the metric passes sample
     def alg_lite(c):
         n_in, n_out = scan_dims(c.layer, c.kind)
@@ -251,8 +253,8 @@ def run_scan(args, rank, world, dev):
     per_c = traffic.get("payload", {}).get("hbm_bytes_per_candidate") if traffic else None
     r_full.update({"traffic": per_c, "traffic_source": tsrc if per_c else None,
                    "algorithmic_bytes_per_candidate": a_full / len(cands),
-                   "note": "achieved = (quantised tensor once per K schedule + emitted idx/val/row_scale per candidate) / "
-                           "sweep time; traffic = measured HBM bytes per candidate from the committed counter passes"})
+                   "note": "achieved = (quantised tensor + idx/val rows at the largest K, once per K schedule, + row scales per "
+                           "candidate) / sweep time; traffic = measured HBM bytes per candidate from the committed counter passes"})
     r_lite = roof(a_lite, el_lite)
     r_lite.update({"traffic": traffic["sweep"].get("hbm_bytes_per_candidate") if traffic else None,
                    "traffic_source": tsrc, "algorithmic_bytes_per_candidate": a_lite / len(cands)})
