@@ -97,6 +97,10 @@ struct DeviceWeight {
     // (128-row tile, 64-wide k-slab), fold_off [tiles][fold_ng] = {begin, end} of a bucket in fold_ent
     unsigned * fold_ent = nullptr; int2 * fold_off = nullptr; int fold_ng = 0, fold_spb = 0;
     bool fold_dup = false;       // some (row, input) pair occurs twice: the adds must be atomic
+    bool fold_over = false;      // some bucket holds more than 2048 entries
+    bool fold_perm = false;      // the buckets are in the permuted input order j = inv_b[q] (x is permuted by the pre-pass, the W0 tile is
+    short * fold_p16 = nullptr;  // [B][L] the input each permuted column multiplies (index into the row of x), -1 = none
+    _Float16 * fold_gp = nullptr;// then a plain XOR-circulant of G_b: copied from fold_gp [B][8][L], fold_gp[b][c][i] = f16(G_b[i ^ c]))
 };
 
 struct LibState {

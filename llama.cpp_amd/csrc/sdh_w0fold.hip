@@ -27,6 +27,14 @@
 //              LDS 0.22, waves waiting 0.41 of their cycles, no pipe saturated. Per slab and CU the texture path
 //              moves 64 KB, the LDS 176 KB, the matrix pipe runs 128 MFMAs: ~0.5 + 0.7 + 0.5 us if nothing overlapped,
 //              1.9 us measured.
+//   permuted   (PERM, payloads whose d1 and d3 are all ones — what the builder writes) With j = inv_b[q] as the contraction
+//              index, W0[p][j] = G_b[p ^ j]: inside a (128-row, 64-column) tile that is seg[pl ^ jl] for one aligned 128-float
+//              segment of G_b, so 8 consecutive columns of a row are an aligned group of 8 of G_b permuted by XOR with
+//              (row & 7). fold_gp holds G_b in f16 under each of those 8 permutations; a thread then builds 16 elements of
+//              the tile with two 16-byte loads and two ds_write_b128 and no arithmetic (the q-order form: 16 dword
+//              gathers, 8 readlanes, 16 multiplies and 16 conversions per thread and slab — VALU busy 0.30 against MFMA
+//              busy 0.22 in the counters above). The pre-pass writes x in j order (z[j] = x[perm1_b[j]], zero where the
+//              block has no such input; tall: one copy per base block), the buckets hold the entries' j columns.
 //   wide       K is split by base block over blockIdx.z (as the tiled W0 kernel); partial products go to [T][B][L]
 //              and fold_reduce_kernel sums them in block order, applies row_scale and the non-finite census.
 #include "sdh_internal.h"
@@ -39,18 +47,34 @@ typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int FD_R = 128, FD_N = 256, FD_K = 64, FD_LD = 72;
+constexpr int FD_GS = 8 * 128;                 // elements of one staged segment image
 
 // ---- payload re-layout: entries bucketed by (row tile, k-slab) ------------------------------------------------
 struct FoldArgs {
     const void * idx; const void * val; int idx32, val32;
     int n_in, n_out, K, nb, block, is_block;
-    int L, tall, n_g, spb;             // n_g: slabs per offsets row; spb: slabs per base block (wide)
+    int L, tall, n_g, spb;             // n_g: slabs per offsets row; spb: slabs per base block
+    const int * inv; int perm;         // perm: bucket by j = inv_b[q]
 };
 
-__device__ inline int fold_slab_of(const FoldArgs & a, int k) {
-    if (a.tall) return k / FD_K;
-    const int b = k / a.L;
-    return b * a.spb + (k - b * a.L) / FD_K;
+constexpr unsigned FD_NULL = 2u * FD_K;        // a null entry: value +0 at byte offset of (row 0, column 64) — a pad column nothing reads
+
+// bucket and column of input k in the row o
+__device__ inline void fold_place(const FoldArgs & a, int o, int k, int & g, int & col) {
+    if (a.tall) {
+        const int j = a.perm ? a.inv[(size_t) (o / a.L) * a.L + k] : k;
+        g = j / FD_K; col = j & (FD_K - 1);
+    } else {
+        const int b = k / a.L;
+        int j = k - b * a.L;
+        if (a.perm) j = a.inv[(size_t) b * a.L + j];
+        g = b * a.spb + j / FD_K; col = j & (FD_K - 1);
+    }
+}
+
+__device__ inline unsigned fold_entry(_Float16 v, int row, int col) {
+    unsigned short vb; __builtin_memcpy(&vb, &v, 2);
+    return ((unsigned) vb << 16) | (unsigned) ((row * FD_LD + col) * 2);
 }
 
 // pass 0: count, pass 1: place (cursor starts at the bucket's offset)
@@ -65,29 +89,27 @@ void fold_bucket_kernel(const FoldArgs a, int * __restrict__ counts, int * __res
     const int ii = a.idx32 ? ((const int *) a.idx)[e] : (int) ((const short *) a.idx)[e];
     if (!a.is_block) {
         if (ii < 0 || ii >= a.n_in) return;                                        // :693
-        const int g = fold_slab_of(a, ii);
+        int g, col;
+        fold_place(a, o, ii, g, col);
         int * slot = (PASS == 0 ? counts : cursor) + (size_t) tile * (a.n_g + 1) + g;
         if (PASS == 0) { atomicAdd(slot, 1); return; }
         const int pos = atomicAdd(slot, 1);
         const _Float16 v = a.val32 ? (_Float16) ((const float *) a.val)[e] : ((const _Float16 *) a.val)[e];
-        unsigned short vb; __builtin_memcpy(&vb, &v, 2);
-        const int col = a.tall ? (ii & (FD_K - 1)) : ((ii % a.L) & (FD_K - 1));
-        ent[pos] = ((unsigned) vb << 16) | (unsigned) (row << 6 | col);
+        ent[pos] = fold_entry(v, row, col);
     } else {
         if (ii < 0) return;                                                        // :929-936
         const int64_t in0 = (int64_t) ii * a.block;
         if (in0 >= a.n_in) return;
         const int in1 = (int) min((int64_t) a.n_in, in0 + a.block);
         for (int k = (int) in0; k < in1; ++k) {
-            const int g = fold_slab_of(a, k);
+            int g, col;
+            fold_place(a, o, k, g, col);
             int * slot = (PASS == 0 ? counts : cursor) + (size_t) tile * (a.n_g + 1) + g;
             if (PASS == 0) { atomicAdd(slot, 1); continue; }
             const int pos = atomicAdd(slot, 1);
             const int64_t vi = ((int64_t) o * a.nb + r) * a.block + (k - in0);
             const _Float16 v = a.val32 ? (_Float16) ((const float *) a.val)[vi] : ((const _Float16 *) a.val)[vi];
-            unsigned short vb; __builtin_memcpy(&vb, &v, 2);
-            const int col = a.tall ? (k & (FD_K - 1)) : ((k % a.L) & (FD_K - 1));
-            ent[pos] = ((unsigned) vb << 16) | (unsigned) (row << 6 | col);
+            ent[pos] = fold_entry(v, row, col);
         }
     }
 }
@@ -126,73 +148,161 @@ void fold_scan_kernel(const int * __restrict__ counts, int * __restrict__ cursor
     }
 }
 
-// does any bucket hold the same (row, column) twice? one workgroup per bucket, a bitmap of the 8192 positions of a tile
+// does any bucket hold the same (row, column) twice? one workgroup per bucket, a bitmap of the positions of a tile
 __global__ __launch_bounds__(256)
-void fold_dup_kernel(const unsigned * __restrict__ ent, const int2 * __restrict__ bounds, int * __restrict__ dup) {
-    __shared__ unsigned bm[256];
-    bm[threadIdx.x] = 0u;
+void fold_dup_kernel(const unsigned * __restrict__ ent, const int2 * __restrict__ bounds, int * __restrict__ dup /* [0] flag, [1] largest bucket */) {
+    __shared__ unsigned bm[FD_R * FD_LD / 32];
+    for (int i = threadIdx.x; i < FD_R * FD_LD / 32; i += 256) bm[i] = 0u;
     __syncthreads();
     const int2 o = bounds[blockIdx.x];
     bool hit = false;
     for (int e = o.x + (int) threadIdx.x; e < o.y; e += 256) {
         const unsigned wd = ent[e];
-        if ((wd & 0x7FFF0000u) == 0u) continue;                                  // padding, or a value of zero
-        const unsigned key = wd & 0x1FFFu, bit = 1u << (key & 31u);
+        if ((wd & 0xFFFFu) == FD_NULL) continue;                                 // padding
+        const unsigned key = (wd & 0xFFFFu) >> 1, bit = 1u << (key & 31u);
         hit |= (atomicOr(&bm[key >> 5], bit) & bit) != 0u;
     }
     if (hit) atomicOr(dup, 1);
+    if (threadIdx.x == 0) atomicMax(dup + 1, o.y - o.x);
+}
+
+// fold_gp[b][c][i] = f16(G_b[i ^ c]), c = 0..7
+__global__ __launch_bounds__(256)
+void fold_gp_kernel(const float * __restrict__ G, _Float16 * __restrict__ gp, int L, int B) {
+    const int64_t e = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t) B * 8 * L) return;
+    const int i = (int) (e % L), c = (int) ((e / L) & 7), b = (int) (e / (8 * (int64_t) L));
+    gp[e] = (_Float16) G[(size_t) b * L + (i ^ c)];
+}
+
+// The pre-pass of the permuted form: z[t][j] = f16(x[t][perm1_b[j]]) (0 where block b has no such input, and for the padding
+// tokens). One workgroup of 16 waves per pair of tokens: their rows of x go to LDS once (f16), every base block gathers from there; the
+// permutation is read as 16-bit indices (fold_p16, -1 = no input), once per pair.
+//   tall: one copy per base block (z + b * zcopy), j in [0, L);   wide: one row of B * L columns
+template <bool TALL>
+__global__ __launch_bounds__(1024)
+void fold_z16_kernel(const float * __restrict__ x, int64_t ldx, int64_t T, int n_in, int L, int B, const short * __restrict__ p16,
+                     _Float16 * __restrict__ z, int64_t ldz, int64_t zcopy) {
+    extern __shared__ __align__(16) unsigned char fz_smem[];
+    _Float16 * xr = (_Float16 *) fz_smem;                          // [2][n_in]
+    const int64_t t0 = 2 * (int64_t) blockIdx.x;
+    const bool vec = (ldx & 3) == 0 && (n_in & 3) == 0 && ((uintptr_t) x & 15) == 0;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (t0 + u >= T) continue;
+        const float * xt = x + (t0 + u) * ldx;
+        _Float16 * xu = xr + (size_t) u * n_in;
+        if (vec) {
+            for (int k = 4 * threadIdx.x; k < n_in; k += 4096) {
+                const float4 v = *reinterpret_cast<const float4 *>(xt + k);
+                typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+                *reinterpret_cast<half4 *>(xu + k) = half4{(_Float16) v.x, (_Float16) v.y, (_Float16) v.z, (_Float16) v.w};
+            }
+        } else {
+            for (int k = threadIdx.x; k < n_in; k += 1024) xu[k] = (_Float16) xt[k];
+        }
+    }
+    __syncthreads();
+    const int gpb = L / 8;
+    for (int g = threadIdx.x; g < B * gpb; g += 1024) {
+        const int b = g / gpb, j0 = (g - b * gpb) * 8;
+        typedef short short8 __attribute__((ext_vector_type(8)));
+        const short8 q = *reinterpret_cast<const short8 *>(p16 + (size_t) b * L + j0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            half8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (t0 + u < T && q[e] >= 0) ? xr[(size_t) u * n_in + q[e]] : (_Float16) 0.0f;
+            *reinterpret_cast<half8 *>(z + (TALL ? (int64_t) b * zcopy : (int64_t) b * L) + (t0 + u) * ldz + j0) = v;
+        }
+    }
+}
+
+// fold_p16[b][j] = the input (index into the row of x) that column j of block b multiplies, or -1
+__global__ __launch_bounds__(256)
+void fold_p16_kernel(const int * __restrict__ p1, short * __restrict__ p16, int L, int B, int n_in, int tall) {
+    const int64_t e = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t) B * L) return;
+    const int b = (int) (e / L), j = (int) (e - (int64_t) b * L);
+    const int q = p1 ? p1[e] : j;
+    const int q_len = tall ? n_in : max(0, min(L, n_in - b * L));
+    p16[e] = (short) ((q >= 0 && q < q_len) ? (tall ? q : b * L + q) : -1);
+}
+
+static bool fold_scaled(const DeviceWeight & w) { return w.pack.off_d1 >= 0 || w.pack.off_d3 >= 0; }   // else d1 = d3 = 1 (what the builder writes)
+
+// The permuted form multiplies over whole base blocks (tall: L columns for n_in inputs, wide: B * L): taken when that is at
+// most a third more than the inputs, and the row of x fits the pre-pass's LDS.
+static bool fold_perm_ok(const DeviceWeight & w) {
+    const int64_t kz = w.tall ? w.L : w.B * w.L;
+    static const bool off = getenv("SDH_FOLD_NO_PERM") != nullptr;               // A/B switch
+    return !off && !fold_scaled(w) && kz * 3 <= w.n_in * 4 && w.n_in <= 32767;     // 16-bit input indices; two f16 rows of x in the pre-pass's LDS
 }
 
 int fold_ensure(DeviceWeight & w, hipStream_t s) {
     if (w.fold_ent) return SDH_OK;
     if (!w.w0_closed_form || w.L < FD_R || (w.L % FD_R) != 0) return 1;
     const bool is_block = w.kind == SDH_OP_BASE_BLOCK;
+    const bool perm = fold_perm_ok(w);
     FoldArgs a{};
     a.idx = w.idx; a.val = w.val; a.idx32 = w.idx_type == SDH_TYPE_I32; a.val32 = w.val_type == SDH_TYPE_F32;
     a.n_in = (int) w.n_in; a.n_out = (int) w.n_out; a.K = (int) w.K; a.nb = (int) w.nb; a.block = (int) w.block; a.is_block = is_block;
     a.L = (int) w.L; a.tall = w.tall ? 1 : 0;
+    a.inv = w.inv; a.perm = perm ? 1 : 0;
     a.spb = (int) (w.L / FD_K);
-    a.n_g = w.tall ? (int) ((w.n_in + FD_K - 1) / FD_K) : (int) (w.B * a.spb);          // wide: a row of buckets per base block the grid has
+    a.n_g = w.tall ? (perm ? a.spb : (int) ((w.n_in + FD_K - 1) / FD_K)) : (int) (w.B * a.spb);      // wide: a row of buckets per base block the grid has
     const int tiles = (int) ((w.n_out + FD_R - 1) / FD_R);
     const int64_t per_row = is_block ? w.nb : w.K;
     const int64_t cap = (int64_t) w.n_out * (is_block ? w.nb * w.block : w.K);
     if (cap <= 0 || cap > 0x7fffffff) return 1;
     const size_t off_bytes = (size_t) tiles * (a.n_g + 1) * sizeof(int);
     const size_t ent_words = (size_t) cap + (size_t) 4 * tiles * a.n_g + 4;       // every bucket padded to a multiple of 4
-    int * counts = nullptr, * cursor = nullptr; unsigned * ent = nullptr; int2 * bounds = nullptr;
+    int * counts = nullptr, * cursor = nullptr; unsigned * ent = nullptr; int2 * bounds = nullptr; _Float16 * gp = nullptr; short * p16 = nullptr;
     SDH_HIP_CHECK(hipMalloc((void **) &counts, off_bytes));
     SDH_HIP_CHECK(hipMalloc((void **) &cursor, off_bytes));
     SDH_HIP_CHECK(hipMalloc((void **) &bounds, (size_t) tiles * a.n_g * sizeof(int2)));
     SDH_HIP_CHECK(hipMalloc((void **) &ent, ent_words * sizeof(unsigned)));
     SDH_HIP_CHECK(hipMemsetAsync(counts, 0, off_bytes, s));
-    SDH_HIP_CHECK(hipMemsetAsync(ent, 0, ent_words * sizeof(unsigned), s));       // padding = null entries
+    SDH_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t) ent, (int) FD_NULL, ent_words, s));     // padding = null entries
     const unsigned grid = (unsigned) ((w.n_out * per_row + 255) / 256);
     hipLaunchKernelGGL(fold_bucket_kernel<0>, dim3(grid), dim3(256), 0, s, a, counts, cursor, ent);
     hipLaunchKernelGGL(fold_scan_kernel, dim3(1), dim3(1024), 0, s, counts, cursor, bounds, tiles, a.n_g);
     hipLaunchKernelGGL(fold_bucket_kernel<1>, dim3(grid), dim3(256), 0, s, a, counts, cursor, ent);
     SDH_HIP_CHECK(hipGetLastError());
     // counts is free again: its first word receives the "a (row, input) pair repeats" flag
-    SDH_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(int), s));
+    SDH_HIP_CHECK(hipMemsetAsync(counts, 0, 2 * sizeof(int), s));
     hipLaunchKernelGGL(fold_dup_kernel, dim3((unsigned) (tiles * a.n_g)), dim3(256), 0, s, ent, bounds, counts);
     SDH_HIP_CHECK(hipGetLastError());
-    int dup = 0;
-    SDH_HIP_CHECK(hipMemcpyAsync(&dup, counts, sizeof(int), hipMemcpyDeviceToHost, s));
+    if (perm) {
+        const int64_t n = w.B * 8 * w.L;
+        SDH_HIP_CHECK(hipMalloc((void **) &gp, (size_t) n * sizeof(_Float16)));
+        hipLaunchKernelGGL(fold_gp_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, w.G, gp, (int) w.L, (int) w.B);
+        SDH_HIP_CHECK(hipGetLastError());
+        SDH_HIP_CHECK(hipMalloc((void **) &p16, (size_t) (w.B * w.L) * sizeof(short)));
+        hipLaunchKernelGGL(fold_p16_kernel, dim3((unsigned) ((w.B * w.L + 255) / 256)), dim3(256), 0, s, w.p1, p16, (int) w.L, (int) w.B, (int) w.n_in, w.tall ? 1 : 0);
+        SDH_HIP_CHECK(hipGetLastError());
+    }
+    int dup[2] = {0, 0};
+    SDH_HIP_CHECK(hipMemcpyAsync(dup, counts, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     SDH_HIP_CHECK(hipStreamSynchronize(s));
     SDH_HIP_CHECK(hipFree(cursor));
     SDH_HIP_CHECK(hipFree(counts));
-    int2 * off = bounds;
-    w.fold_dup = dup != 0;
-    w.fold_ent = ent; w.fold_off = off; w.fold_ng = a.n_g; w.fold_spb = a.spb;
+    w.fold_dup = dup[0] != 0;
+    w.fold_over = dup[1] > 4 * 512;                               // some bucket holds more than the four entries per thread of the prefetch
+    w.fold_perm = perm; w.fold_gp = gp; w.fold_p16 = p16;
+    w.fold_ent = ent; w.fold_off = bounds; w.fold_ng = a.n_g; w.fold_spb = a.spb;
     return SDH_OK;
 }
 
 void fold_free(DeviceWeight & w) {
-    (void) hipFree(w.fold_ent); (void) hipFree(w.fold_off);
-    w.fold_ent = nullptr; w.fold_off = nullptr;
+    (void) hipFree(w.fold_ent); (void) hipFree(w.fold_off); (void) hipFree(w.fold_gp); (void) hipFree(w.fold_p16);
+    w.fold_ent = nullptr; w.fold_off = nullptr; w.fold_gp = nullptr; w.fold_p16 = nullptr;
 }
 
 // ---- the contraction ---------------------------------------------------------------------------------------------
-template <bool TALL, bool SCALED /* d1 or d3 present and not all ones */, bool ATOMIC /* the payload repeats a (row, input) pair */>
+template <bool TALL, bool SCALED /* d1 or d3 present and not all ones */, bool ATOMIC /* the payload repeats a (row, input) pair */,
+          bool OVER /* some bucket holds more than 2048 entries: a loop over the rest in the scatter step (its loads cost the
+                       main loop its exact vmcnt bookkeeping, so it is a variant of its own) */>
 __global__ __launch_bounds__(512)
 void w0d_mfma_kernel(const _Float16 * __restrict__ x16, int64_t ld16, int64_t T, int n_in, int n_out, int L,
                      const float * __restrict__ d1, const float * __restrict__ d3,
@@ -203,6 +313,7 @@ void w0d_mfma_kernel(const _Float16 * __restrict__ x16, int64_t ld16, int64_t T,
     extern __shared__ __align__(16) unsigned char fd_smem[];
     _Float16 * Ws = (_Float16 *) fd_smem;                         // [3][FD_R][FD_LD]
     _Float16 * Xs = Ws + 3 * FD_R * FD_LD;                        // [2][FD_N][FD_LD]
+    int2 * Bn = (int2 *) (Xs + 2 * FD_N * FD_LD + 2 * FD_GS);     // [n_slab] bucket bounds of this workgroup (behind the permuted kernel's staging area)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -239,19 +350,20 @@ void w0d_mfma_kernel(const _Float16 * __restrict__ x16, int64_t ld16, int64_t T,
     int ebeg[2], eend[2];       // their bucket bounds
     int ivl = 0;
     int2 obe = make_int2(0, 0); // bucket bounds loaded a slab ahead of the entry loads that use them
+    auto clamp_slab = [&](int s) { return max(min(s, n_slab - 1), 0); };
     auto fetch_idx = [&](int s) {
-        const int q0 = max(min(s, n_slab - 1), 0) * FD_K + wave * 8;
+        const int q0 = clamp_slab(s) * FD_K + wave * 8;
         ivl = inv[pb + q0 + (lane & 7)];
     };
-    int vzero;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));                 // a zero the compiler cannot see: keeps the loads below vector loads
-    auto fetch_off = [&](int s) {                                  // (a scalar load in flight turns every LDS wait into lgkmcnt(0))
-        const int sc = max(min(s, n_slab - 1), 0);
-        obe = offr[sc + vzero];
-    };
+    // Every global load of the main loop is issued unconditionally (slab indices clamped to the last slab): a load behind a
+    // branch makes the compiler's vmcnt bookkeeping assume the path that skipped it, and every later wait then drains
+    // the queue almost completely (vmcnt(1), vmcnt(2) where ten loads could stay in flight; the bounds -> entries chain
+    // alone was a vmcnt(0) per slab that exposed the x loads issued just before it: 127 -> 9x us per call on a Mistral gate).
+    // The bucket bounds come from LDS for the same reason.
+    auto fetch_off = [&](int s) { obe = Bn[clamp_slab(s)]; };
     auto fetchW = [&](auto set_c, int s) {
         constexpr int S = decltype(set_c)::value;
-        const int q0 = s * FD_K + wave * 8;
+        const int q0 = clamp_slab(s) * FD_K + wave * 8;
         float dl = 1.0f;
         if constexpr (SCALED) dl = d1[pb + q0 + (lane & 7)];
 #pragma unroll
@@ -265,7 +377,7 @@ void w0d_mfma_kernel(const _Float16 * __restrict__ x16, int64_t ld16, int64_t T,
     };
     auto fetchX = [&](auto set_c, int s) {
         constexpr int S = decltype(set_c)::value;
-        const _Float16 * xs0 = x16 + t_tile * ld16 + k_begin + s * FD_K;         // uniform
+        const _Float16 * xs0 = x16 + t_tile * ld16 + k_begin + clamp_slab(s) * FD_K;         // uniform
 #pragma unroll
         for (int i = 0; i < 4; ++i) xq[S][i] = *reinterpret_cast<const half8 *>(xs0 + (size_t) i * 64 * ld16 + xoff);
     };
@@ -290,7 +402,11 @@ void w0d_mfma_kernel(const _Float16 * __restrict__ x16, int64_t ld16, int64_t T,
         constexpr int S = decltype(set_c)::value;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
+#ifdef SDH_FD_NOCOMMIT
+            { const half8 keep = xq[S][2 * half + i]; asm volatile("" :: "v"(keep)); }
+#else
             *reinterpret_cast<half8 *>(Xs + (size_t) buf * FD_N * FD_LD + xs_w + (2 * half + i) * 64 * FD_LD) = xq[S][2 * half + i];
+#endif
     };
     // Adding the entries of a bucket to a W tile. Entries of a payload without repeated (row, input) pairs touch distinct
     // elements, so each is a plain 16-bit read, add, 16-bit write — the reads of a slab's entries are issued at the first
@@ -298,7 +414,7 @@ void w0d_mfma_kernel(const _Float16 * __restrict__ x16, int64_t ld16, int64_t T,
     // write per entry in one place cost 0.3 us per slab: three dependent round trips with the matrix pipe idle). Payloads
     // that do repeat a pair (hand-made ones; the builder's top-K never does) take ds_pk_add_f16, which sums them as the
     // reference does.
-    auto entry_pos = [&](unsigned wd) { return ((wd >> 6) & 127u) * FD_LD + (wd & 63u); };
+    auto entry_pos = [&](unsigned wd) { return (wd & 0xFFFFu) >> 1; };             // element offset in the tile (null entries: a pad column)
     auto entry_val = [&](unsigned wd) { const unsigned short vb = (unsigned short) (wd >> 16); _Float16 v; __builtin_memcpy(&v, &vb, 2); return v; };
     auto add_atomic = [&](unsigned wbuf, unsigned wd) {
         const unsigned pos = entry_pos(wd);
@@ -307,7 +423,6 @@ void w0d_mfma_kernel(const _Float16 * __restrict__ x16, int64_t ld16, int64_t T,
         __builtin_amdgcn_ds_atomic_fadd_v2f16((__attribute__((address_space(3))) half2v *) (Ws + wbuf + (pos & ~1u)), add);
     };
     _Float16 eold[4];
-    auto live = [&](unsigned wd) { return (wd & 0x7FFF0000u) != 0u; };          // not padding (and not a value of zero)
     auto scatter_read = [&](auto set_c, unsigned Wb) {
         constexpr int S = decltype(set_c)::value;
         if constexpr (!ATOMIC) {
@@ -316,23 +431,24 @@ void w0d_mfma_kernel(const _Float16 * __restrict__ x16, int64_t ld16, int64_t T,
             for (int i = 0; i < 4; ++i) eold[i] = Ws[Wb + entry_pos(wd[i])];      // unconditional: a clamped or null entry reads a valid element
         }
     };
+    // no test per entry: a null entry adds +0 to a pad element (whatever races there is never read); the threads beyond the
+    // bucket's end hold clamped copies of its last entries and must not write
     auto scatter = [&](auto set_c, unsigned Wb) {
         constexpr int S = decltype(set_c)::value;
         if (ebeg[S] + 4 * tid < eend[S]) {
             const unsigned wd[4] = {eq[S].x, eq[S].y, eq[S].z, eq[S].w};
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (live(wd[i])) {
-                    if constexpr (ATOMIC) add_atomic(Wb, wd[i]);
-                    else Ws[Wb + entry_pos(wd[i])] = eold[i] + entry_val(wd[i]);
-                }
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (ATOMIC) add_atomic(Wb, wd[i]);
+                else Ws[Wb + entry_pos(wd[i])] = eold[i] + entry_val(wd[i]);
+            }
         }
-        for (int e = ebeg[S] + 2048 + tid; e < eend[S]; e += 512) {                       // a bucket beyond the prefetch
-            const unsigned wd = ent[e];
-            if (!live(wd)) continue;
-            if constexpr (ATOMIC) add_atomic(Wb, wd);
-            else { const unsigned pos = Wb + entry_pos(wd); Ws[pos] = Ws[pos] + entry_val(wd); }
-        }
+        if constexpr (OVER)
+            for (int e = ebeg[S] + 2048 + tid; e < eend[S]; e += 512) {                   // a bucket beyond the prefetch
+                const unsigned wd = ent[e];
+                if constexpr (ATOMIC) add_atomic(Wb, wd);
+                else { const unsigned pos = Wb + entry_pos(wd); Ws[pos] = Ws[pos] + entry_val(wd); }
+            }
     };
 
     const int wr = wave & 1, wt = wave >> 1;                      // wave tile: rows wr*64.., tokens wt*64..
@@ -350,71 +466,375 @@ void w0d_mfma_kernel(const _Float16 * __restrict__ x16, int64_t ld16, int64_t T,
     unsigned Wcur = 0, Wnxt = FD_R * FD_LD, Wnx2 = 2 * FD_R * FD_LD;      // element offsets of the three W tiles in rotation
     // slab s: p_c = parity of s. Register sets on entry: gq[p] = W0 of slab s+2, xq[!p] / eq[!p] = x tile / entries of slab
     // s+1; LDS: Wcur = W0+D of slab s, Wnxt = W0 of slab s+1 (its entries not yet added), Xs[p] = x of slab s.
+    // The fragments of a slab's first multiply step are read right after the barrier that completes its tiles, and the last
+    // multiply step of the slab before is issued behind those reads: the matrix pipe works through the LDS latency that
+    // every wave would otherwise wait out together once per slab.
+    half8 xf[2][2], wf[2][2];
+#ifdef SDH_FD_NOFRAGS
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) { asm volatile("" : "=v"(xf[q][a])); asm volatile("" : "=v"(wf[q][a])); }
+#endif
+    auto frags = [&](int q, int xbuf, unsigned wbuf, int ks) {
+#ifndef SDH_FD_NOFRAGS
+        const _Float16 * Wb = Ws + wbuf + wfrag;
+        const _Float16 * Xb = Xs + (size_t) xbuf * FD_N * FD_LD + xfrag;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) xf[q][a] = *reinterpret_cast<const half8 *>(Xb + a * 32 * FD_LD + ks * 16);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) wf[q][c] = *reinterpret_cast<const half8 *>(Wb + c * 32 * FD_LD + ks * 16);
+#endif
+    };
+    auto multiply = [&](int q) {
+#ifndef SDH_FD_NOMFMA
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[q][a], wf[q][c], acc[a][c], 0, 0, 0);
+#endif
+    };
     auto slab = [&](auto p_c, auto q_c, int s) {
         constexpr int P = decltype(p_c)::value;
-        const _Float16 * Wb = Ws + Wcur + wfrag;
-        const _Float16 * Xb = Xs + (size_t) P * FD_N * FD_LD + xfrag;
-        half8 xf[2][2], wf[2][2];
-        auto frags = [&](int q, int ks) {
 #pragma unroll
-            for (int a = 0; a < 2; ++a) xf[q][a] = *reinterpret_cast<const half8 *>(Xb + a * 32 * FD_LD + ks * 16);
-#pragma unroll
-            for (int c = 0; c < 2; ++c) wf[q][c] = *reinterpret_cast<const half8 *>(Wb + c * 32 * FD_LD + ks * 16);
-        };
-        frags(0, 0);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            if (ks + 1 < 4) frags((ks + 1) & 1, ks + 1);
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[ks & 1][a], wf[ks & 1][c], acc[a][c], 0, 0, 0);
+        for (int ks = 0; ks < 3; ++ks) {
+            frags((ks + 1) & 1, P, Wcur, ks + 1);
+            multiply(ks & 1);
             // the global loads of the slabs ahead, spread over the multiply steps (one burst at the top of the slab
             // measured 135 against 127 us per call on a Mistral gate)
-            if (ks == 0 && s + 3 < n_slab) fetchW(q_c, s + 3);
-            if (ks == 1 && s + 2 < n_slab) fetchX(p_c, s + 2);
-            if (ks == 2) { if (s + 2 < n_slab) fetchE(p_c); fetch_idx(s + 4); fetch_off(s + 3); }
-            if (ks == 0 && s + 1 < n_slab) scatter_read(q_c, Wnxt);
-            if (ks == 0 && s + 2 < n_slab) commitW(p_c, Wnx2, 0);
-            if (ks == 1 && s + 2 < n_slab) commitW(p_c, Wnx2, 1);
-            if (ks == 2 && s + 1 < n_slab) { commitX(q_c, P ^ 1, 0); scatter(q_c, Wnxt); }
-            if (ks == 3 && s + 1 < n_slab) commitX(q_c, P ^ 1, 1);
+            // (the work for slabs past the end lands in tiles nothing reads any more)
+#ifndef SDH_FD_NOSCATTER
+            if (ks == 0) fetchE(p_c);                               // bucket s + 2 (its bounds: fetch_off of the slab before)
+#endif
+#ifndef SDH_FD_NOW
+            if (ks == 0) fetchW(q_c, s + 3);
+#endif
+#ifndef SDH_FD_NOX
+            if (ks == 1) fetchX(p_c, s + 2);
+#endif
+#ifndef SDH_FD_NOSCATTER
+            if (ks == 2) { fetch_idx(s + 4); fetch_off(s + 3); }
+            if (ks == 0) scatter_read(q_c, Wnxt);
+#endif
+#ifndef SDH_FD_NOW
+            if (ks == 0) commitW(p_c, Wnx2, 0);
+            if (ks == 1) commitW(p_c, Wnx2, 1);
+#endif
+#ifndef SDH_FD_NOX
+            if (ks == 1) commitX(q_c, P ^ 1, 0);
+            if (ks == 2) commitX(q_c, P ^ 1, 1);
+#endif
+#ifndef SDH_FD_NOSCATTER
+            if (ks == 2) scatter(q_c, Wnxt);
+#endif
         }
+#ifndef SDH_FD_NOBARRIER
         __syncthreads();
+#endif
         const unsigned t = Wcur; Wcur = Wnxt; Wnxt = Wnx2; Wnx2 = t;
+        frags(0, P ^ 1, Wcur, 0);                                   // the next slab's first step
+        multiply(1);                                                // this slab's last
     };
 
-    // prologue: Wcur = W0(0), Wnxt = W0(1), Xs[0] = x(0); then the entries of slab 0 once W0(0) is complete
+    // prologue: Wcur = W0(0), Wnxt = W0(1), Xs[0] = x(0); then the entries of slab 0 once W0(0) is complete. The last loads
+    // are issued in the order a slab of the main loop issues them (entries, W0 source, x): the loop's first waits count the
+    // loads behind the one they need, and the count they may assume is the smaller of this path's and the loop's.
+    for (int i = tid; i < n_slab; i += 512) Bn[i] = offr[i];
     fetch_idx(0);
-    fetch_off(0);
     fetchW(set0{}, 0);
     fetchX(set0{}, 0);
-    fetchE(set0{});
     fetch_idx(1);
+    __syncthreads();
+    fetch_off(0);
+    fetchE(set0{});
     commitW(set0{}, Wcur, 0); commitW(set0{}, Wcur, 1);
     commitX(set0{}, 0, 0); commitX(set0{}, 0, 1);
-    if (1 < n_slab) {
-        fetchW(set1{}, 1);
-        commitW(set1{}, Wnxt, 0); commitW(set1{}, Wnxt, 1);
-    }
+    fetchW(set1{}, 1);
+    commitW(set1{}, Wnxt, 0); commitW(set1{}, Wnxt, 1);
     __syncthreads();
     scatter_read(set0{}, Wcur);
     scatter(set0{}, Wcur);
     fetch_idx(2);
     fetch_off(1);
-    if (2 < n_slab) fetchW(set0{}, 2);          // -> gq[0] = W0 of slab 2
-    if (1 < n_slab) { fetchX(set1{}, 1); fetchE(set1{}); }      // -> xq[1], eq[1] = slab 1
+    fetchE(set1{});                             // -> eq[1] = entries of slab 1
+    fetchW(set0{}, 2);                          // -> gq[0] = W0 of slab 2
+    fetchX(set1{}, 1);                          // -> xq[1] = x of slab 1
     fetch_idx(3);
     fetch_off(2);
     __syncthreads();
-    for (int s = 0; s < n_slab; s += 2) {
+    frags(0, 0, Wcur, 0);
+    for (int s = 0; s + 1 < n_slab; s += 2) {           // no branch inside the pair (see the note on vmcnt above)
         slab(set0{}, set1{}, s);
-        if (s + 1 < n_slab) slab(set1{}, set0{}, s + 1);
+        slab(set1{}, set0{}, s + 1);
     }
+    if (n_slab & 1) slab(set0{}, set1{}, n_slab - 1);
 
     // C[row = token][col = o]: row = (e & 3) + 8 * (e >> 2) + 4 * h, col = r
     const size_t col_off = TALL ? 0 : pb;
+    int bad = 0;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int orow = o_tile + wr * 64 + c * 32 + r;
+        if (orow >= n_out) continue;
+        const float sc = (TALL && rs) ? rs[orow] : 1.0f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t t = t_tile + wt * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (t >= T) continue;
+                float v = acc[a][c][e];
+                if (TALL) {
+                    if (sc != 1.0f) v *= sc;                                           // :645
+                    if (!__builtin_isfinite(v)) { ++bad; if (zero_nf) v = 0.0f; }
+                }
+                out[t * ldo + col_off + orow] = v;
+            }
+    }
+    if (TALL && bad) atomicAdd(nf_counter, bad);
+}
+
+// ---- the contraction in the permuted order --------------------------------------------------------------------------
+// Same tiles, same LDS image, same scatter step as above; what differs:
+//   W0 tile   The 128 x 64 tile of slab s is seg[pl ^ jl] for ONE aligned 128-element segment of G_b (at (p0 ^ 64 s) & ~127): 256
+//             bytes, 2 KB under the 8 permutations of fold_gp. Each thread brings one dword of that image per slab (global ->
+//             register -> Gs, laid out [group of 8][copy][8] so that the 16 lanes of a read pass fall on 16 distinct bank quads),
+//             and the tile is built LDS -> LDS: thread (pl, gsel) copies the groups (pl >> 3) ^ g ^ 8 hi of copy pl & 7 to row pl,
+//             columns 8 g .. 8 g + 7, g = gsel and gsel + 4. No arithmetic, 2 KB of L2 traffic per slab instead of 32 KB.
+//   depth     x tiles and entries are loaded THREE slabs ahead into three register sets in rotation (the loop is unrolled by
+//             three; which LDS buffer a slab reads is a runtime offset): a CU gets 60-70 GB/s from L2 with ~70 KB in flight
+//             (loads alone, no multiplies: 58 GB/s measured here), and one slab ahead (32 KB) left the waves waiting on vmcnt
+//             with the matrix pipe idle — the multiply-only build of this kernel ran 54 us, the load-only build 58 us, both
+//             together 88 us.
+//   vmcnt     every global load of the loop is issued unconditionally (indices clamped; work for slabs past the end lands in
+//             tiles nothing reads) and the prologue issues its last loads in the loop's order: a load behind a branch, or a
+//             different order on the way into the loop, makes the compiler's counted waits assume the shortest queue and
+//             drain it (vmcnt(0..2) where ten loads may stay in flight). The bucket bounds sit in LDS for the same reason.
+template <bool TALL, bool ATOMIC /* the payload repeats a (row, input) pair */, bool OVER /* some bucket holds more than 2048 entries */>
+__global__ __launch_bounds__(512)
+void w0p_mfma_kernel(const _Float16 * __restrict__ z16, int64_t ldz, int64_t zcopy, int64_t T, int n_out, int L,
+                     const _Float16 * __restrict__ gp, const unsigned * __restrict__ ent, const int2 * __restrict__ off, int n_g, int spb,
+                     const float * __restrict__ rs, float * __restrict__ out, int64_t ldo, int * __restrict__ nf_counter, int zero_nf) {
+    extern __shared__ __align__(16) unsigned char fd_smem[];
+    _Float16 * Ws = (_Float16 *) fd_smem;                         // [3][FD_R][FD_LD]
+    _Float16 * Xs = Ws + 3 * FD_R * FD_LD;                        // [2][FD_N][FD_LD]
+    _Float16 * Gs = Xs + 2 * FD_N * FD_LD;                        // [2][16 groups][8 copies][8]
+    int2 * Bn = (int2 *) (Gs + 2 * FD_GS);                        // [n_slab] bucket bounds of this workgroup
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int o_tile = (int) blockIdx.x * FD_R;
+    const int64_t t_tile = (int64_t) blockIdx.y * FD_N;
+    const int b = TALL ? o_tile / L : (int) blockIdx.z;
+    const int p0 = TALL ? o_tile - b * L : o_tile;                // first row of the tile inside its block
+    const int n_slab = spb;
+    const int2 * offr = off + (size_t) blockIdx.x * n_g + (TALL ? 0 : b * spb);
+    const _Float16 * zb = z16 + (TALL ? (int64_t) b * zcopy : (int64_t) b * L) + t_tile * ldz;
+    const char * Gb = (const char *) (gp + (size_t) 8 * b * L);
+
+    const int pl = tid & 127, gsel = tid >> 7;
+    const unsigned gs_r = (unsigned) (((((pl >> 3) ^ gsel) << 3) | (pl & 7)) << 3);          // element offset in a Gs image at hi = 0, g = gsel
+    const unsigned ws_p = (unsigned) (pl * FD_LD + 8 * gsel);
+    // staging: dword tid of the image = group tid >> 5, copy (tid >> 2) & 7, halves 2 (tid & 3) ..
+    const unsigned sg_src = (((unsigned) ((tid >> 2) & 7) * (unsigned) L + (unsigned) ((tid >> 5) << 3) + (unsigned) ((tid & 3) << 1)) << 1);
+    const unsigned xoff = (unsigned) ((tid >> 3) * ldz + (tid & 7) * 8);
+    const unsigned xs_w = (unsigned) ((tid >> 3) * FD_LD + (tid & 7) * 8);
+
+    unsigned sg = 0;            // the staged dword of the segment three slabs on
+    half8 gh[2];                // the two column groups of the tile two slabs on
+    half8 xq[3][4];             // x tiles in flight
+    uint4 eq[3];                // residual entries (four per thread) in flight
+    int ebeg[3], eend[3];       // their bucket bounds
+    int2 obe = make_int2(0, 0); // bucket bounds read a slab ahead of the entry loads that use them
+    auto clamp_slab = [&](int s) { return max(min(s, n_slab - 1), 0); };
+    auto fetch_off = [&](int s) { obe = Bn[clamp_slab(s)]; };
+    auto fetchX = [&](auto set_c, int s) {
+        constexpr int S = decltype(set_c)::value;
+        const _Float16 * xs0 = zb + clamp_slab(s) * FD_K;          // uniform
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xq[S][i] = *reinterpret_cast<const half8 *>(xs0 + (size_t) i * 64 * ldz + xoff);
+    };
+    auto fetchE = [&](auto set_c) {
+        constexpr int S = decltype(set_c)::value;
+        ebeg[S] = __builtin_amdgcn_readfirstlane(obe.x); eend[S] = __builtin_amdgcn_readfirstlane(obe.y);
+        const int e = ebeg[S] + 4 * tid;                           // buckets start and end at multiples of 4: one 16-byte load
+        eq[S] = *reinterpret_cast<const uint4 *>(ent + (e < eend[S] ? e : max(eend[S] - 4, 0)));      // clamped: read unconditionally
+    };
+    auto commitX = [&](auto set_c, unsigned xbuf, int half) {
+        constexpr int S = decltype(set_c)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#ifdef SDH_FP_XKEEP
+            { const half8 keep = xq[S][2 * half + i]; asm volatile("" :: "v"(keep)); }
+#else
+            *reinterpret_cast<half8 *>(Xs + xbuf + xs_w + (2 * half + i) * 64 * FD_LD) = xq[S][2 * half + i];
+#endif
+    };
+    auto seg_load = [&](int s) {                                   // global -> sg: the image dword of slab s
+        const unsigned base = ((unsigned) (p0 ^ (clamp_slab(s) << 6)) & ~127u) << 1;
+        sg = *reinterpret_cast<const unsigned *>(Gb + base + sg_src);
+    };
+    auto seg_commit = [&](int buf) { reinterpret_cast<unsigned *>(Gs + buf * FD_GS)[tid] = sg; };
+    auto tile_read = [&](int buf, int hi) {                        // hi: slab parity (the upper 64 of the segment's 128 positions)
+        const _Float16 * g = Gs + buf * FD_GS;
+        gh[0] = *reinterpret_cast<const half8 *>(g + (gs_r ^ (unsigned) (hi << 9)));
+        gh[1] = *reinterpret_cast<const half8 *>(g + (gs_r ^ (unsigned) (hi << 9) ^ (4u << 6)));
+    };
+    auto tile_write = [&](unsigned wbuf, int rr) { *reinterpret_cast<half8 *>(Ws + wbuf + ws_p + rr * 32) = gh[rr]; };
+
+    // the scatter step (see w0d_mfma_kernel)
+    auto entry_pos = [&](unsigned wd) { return (wd & 0xFFFFu) >> 1; };
+    auto entry_val = [&](unsigned wd) { const unsigned short vb = (unsigned short) (wd >> 16); _Float16 v; __builtin_memcpy(&v, &vb, 2); return v; };
+    auto add_atomic = [&](unsigned wbuf, unsigned wd) {
+        const unsigned pos = entry_pos(wd);
+        const _Float16 v = entry_val(wd);
+        const half2v add = (pos & 1u) ? half2v{(_Float16) 0.0f, v} : half2v{v, (_Float16) 0.0f};
+        __builtin_amdgcn_ds_atomic_fadd_v2f16((__attribute__((address_space(3))) half2v *) (Ws + wbuf + (pos & ~1u)), add);
+    };
+    _Float16 eold[4];
+    auto scatter_read = [&](auto set_c, unsigned Wb) {
+        constexpr int S = decltype(set_c)::value;
+        if constexpr (!ATOMIC) {
+            if (ebeg[S] + 256 * wave < eend[S]) {                  // (wave-uniform) a wave beyond the bucket's end has nothing to add
+                const unsigned wd[4] = {eq[S].x, eq[S].y, eq[S].z, eq[S].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) eold[i] = Ws[Wb + entry_pos(wd[i])];
+            }
+        }
+    };
+    auto scatter = [&](auto set_c, unsigned Wb) {
+        constexpr int S = decltype(set_c)::value;
+        if (ebeg[S] + 4 * tid < eend[S]) {
+            const unsigned wd[4] = {eq[S].x, eq[S].y, eq[S].z, eq[S].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (ATOMIC) add_atomic(Wb, wd[i]);
+                else Ws[Wb + entry_pos(wd[i])] = eold[i] + entry_val(wd[i]);
+            }
+        }
+        if constexpr (OVER)
+            for (int e = ebeg[S] + 2048 + tid; e < eend[S]; e += 512) {                   // a bucket beyond the prefetch
+                const unsigned wd = ent[e];
+                if constexpr (ATOMIC) add_atomic(Wb, wd);
+                else { const unsigned pos = Wb + entry_pos(wd); Ws[pos] = Ws[pos] + entry_val(wd); }
+            }
+    };
+
+    const int wr = wave & 1, wt = wave >> 1;                      // wave tile: rows wr*64.., tokens wt*64..
+    floatx16 acc[2][2];                                           // [token tile][row tile]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.0f;
+    const unsigned wfrag = (unsigned) ((wr * 64 + r) * FD_LD + 8 * h), xfrag = (unsigned) ((wt * 64 + r) * FD_LD + 8 * h);
+    half8 xf[2][2], wf[2][2];
+    auto frags = [&](int q, unsigned xbuf, unsigned wbuf, int ks) {
+        const _Float16 * Wb = Ws + wbuf + wfrag;
+        const _Float16 * Xb = Xs + xbuf + xfrag;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) xf[q][a] = *reinterpret_cast<const half8 *>(Xb + a * 32 * FD_LD + ks * 16);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) wf[q][c] = *reinterpret_cast<const half8 *>(Wb + c * 32 * FD_LD + ks * 16);
+    };
+    auto multiply = [&](int q) {
+#ifndef SDH_FD_NOMFMA
+#ifdef SDH_FP_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[q][a], wf[q][c], acc[a][c], 0, 0, 0);
+#ifdef SDH_FP_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+#endif
+    };
+
+    using set0 = std::integral_constant<int, 0>;
+    using set1 = std::integral_constant<int, 1>;
+    using set2 = std::integral_constant<int, 2>;
+    unsigned Wcur = 0, Wnxt = FD_R * FD_LD, Wnx2 = 2 * FD_R * FD_LD;      // element offsets of the three W tiles in rotation
+    unsigned xcur = 0, xnxt = FD_N * FD_LD;                               // and of the two x tiles
+    int par = 0;                                                          // parity of the slab
+    // slab s, on entry: LDS: Wcur = W0+D of slab s, Wnxt = W0 of slab s+1 (entries not yet added), Xs[xcur] = x of slab s,
+    // Gs[par] = segment of slab s+2; registers: sg = segment dword of slab s+3, sets (x, entries) of slabs s+1 (set c_c, used
+    // here) and s+2; the set a_c is free and receives slab s+3. The fragments of the first multiply step are in flight.
+    auto slab = [&](auto a_c, auto c_c, int s) {
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            frags((ks + 1) & 1, xcur, Wcur, ks + 1);
+            multiply(ks & 1);
+#if defined(SDH_FP_NOX)
+#define SDH_FP_X(...)
+#else
+#define SDH_FP_X(...) __VA_ARGS__
+#endif
+#if defined(SDH_FP_NOXW) || defined(SDH_FP_NOX)
+#define SDH_FP_XW(...)
+#else
+#define SDH_FP_XW(...) __VA_ARGS__
+#endif
+#if defined(SDH_FP_NOTILE)
+#define SDH_FP_TILE(...)
+#else
+#define SDH_FP_TILE(...) __VA_ARGS__
+#endif
+#if defined(SDH_FP_NOSCATTER)
+#define SDH_FP_SC(...)
+#else
+#define SDH_FP_SC(...) __VA_ARGS__
+#endif
+            if (ks == 0) {
+                SDH_FP_SC(fetchE(a_c);)                              // bucket s + 3 (bounds: fetch_off of the slab before)
+                SDH_FP_TILE(seg_commit(par ^ 1); seg_load(s + 4); tile_read(par, par);)
+                SDH_FP_SC(scatter_read(c_c, Wnxt);)
+            }
+            if (ks == 1) { SDH_FP_X(fetchX(a_c, s + 3);) SDH_FP_TILE(tile_write(Wnx2, 0);) SDH_FP_XW(commitX(c_c, xnxt, 0);) }
+            if (ks == 2) { SDH_FP_SC(fetch_off(s + 4);) SDH_FP_TILE(tile_write(Wnx2, 1);) SDH_FP_XW(commitX(c_c, xnxt, 1);) SDH_FP_SC(scatter(c_c, Wnxt);) }
+        }
+        __syncthreads();
+        { const unsigned t = Wcur; Wcur = Wnxt; Wnxt = Wnx2; Wnx2 = t; }
+        { const unsigned t = xcur; xcur = xnxt; xnxt = t; }
+        par ^= 1;
+        frags(0, xcur, Wcur, 0);                                     // the next slab's first step, behind the barrier
+        multiply(1);                                                 // this slab's last: the matrix pipe works through that LDS latency
+    };
+
+    for (int i = tid; i < n_slab; i += 512) Bn[i] = offr[i];
+    seg_load(0); seg_commit(0);
+    seg_load(1); seg_commit(1);
+    fetchX(set0{}, 0);
+    __syncthreads();
+    fetch_off(0);
+    fetchE(set0{});
+    tile_read(0, 0); tile_write(Wcur, 0); tile_write(Wcur, 1);
+    tile_read(1, 1); tile_write(Wnxt, 0); tile_write(Wnxt, 1);
+    commitX(set0{}, xcur, 0); commitX(set0{}, xcur, 1);
+    __syncthreads();
+    seg_load(2); seg_commit(0);
+    scatter_read(set0{}, Wcur);
+    scatter(set0{}, Wcur);
+    fetch_off(1); fetchE(set1{}); fetchX(set1{}, 1);               // as slab -2 would: slab 1 -> set 1
+    fetch_off(2); fetchE(set2{}); seg_load(3); fetchX(set2{}, 2);  // as slab -1 would: slab 2 -> set 2, segment of slab 3
+    fetch_off(3);
+    __syncthreads();
+    frags(0, xcur, Wcur, 0);
+    int s = 0;
+    for (; s + 2 < n_slab; s += 3) {                    // no branch inside the triple
+        slab(set0{}, set1{}, s);
+        slab(set1{}, set2{}, s + 1);
+        slab(set2{}, set0{}, s + 2);
+    }
+    if (s < n_slab) slab(set0{}, set1{}, s);
+    if (s + 1 < n_slab) slab(set1{}, set2{}, s + 1);
+
+    // C[row = token][col = o]: row = (e & 3) + 8 * (e >> 2) + 4 * h, col = r
+    const size_t col_off = TALL ? 0 : (size_t) b * L;
     int bad = 0;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -455,11 +875,20 @@ void fold_reduce_kernel(const float * __restrict__ part, int B, int L, int n_out
     y[t * ldy + o] = v;
 }
 
+// x image: q order: [T_pad][round64(n_in) + 64]; j order: tall [B][T_pad][L + 64], wide [T_pad][B * L + 64]
+static void fold_x_layout(const DeviceWeight & w, int64_t T, bool perm, int64_t & T_pad, int64_t & ld16, int64_t & zcopy, size_t & bytes) {
+    T_pad = (T + FD_N - 1) / FD_N * FD_N;
+    if (!perm) { ld16 = (w.n_in + FD_K - 1) / FD_K * FD_K + FD_K; zcopy = 0; bytes = (size_t) T_pad * (size_t) ld16 * 2; return; }
+    ld16 = (w.tall ? w.L : w.B * w.L) + FD_K;
+    zcopy = w.tall ? T_pad * ld16 : 0;
+    bytes = (size_t) T_pad * (size_t) ld16 * 2 * (size_t) (w.tall ? w.B : 1);
+}
+
 size_t w0_fold_ws_bytes(const DeviceWeight & w, int64_t T) {
-    const int64_t T_pad = (T + FD_N - 1) / FD_N * FD_N;
-    const int64_t ld16 = (w.n_in + FD_K - 1) / FD_K * FD_K + FD_K;
+    int64_t T_pad, ld16, zcopy; size_t xb;
+    fold_x_layout(w, T, w.fold_ent ? w.fold_perm : fold_perm_ok(w), T_pad, ld16, zcopy, xb);
     const size_t part = w.tall ? 0 : (size_t) T * (size_t) w.B * (size_t) w.L * 4;
-    return ((part + 255) & ~(size_t) 255) + (size_t) T_pad * (size_t) ld16 * 2;
+    return ((part + 255) & ~(size_t) 255) + xb;
 }
 
 // The whole op for T tokens: x16 pre-pass, the folded contraction, (wide) the block-order reduction. ws: w0_fold_ws_bytes.
@@ -470,37 +899,60 @@ int launch_w0_fold(DeviceWeight & w, const float * x, int64_t ldx, int64_t T, vo
     if (T <= 0) return SDH_OK;
     int rc = fold_ensure(w, s);
     if (rc != SDH_OK) return rc;
-    const int64_t T_pad = (T + FD_N - 1) / FD_N * FD_N;
-    const int64_t ld16 = (w.n_in + FD_K - 1) / FD_K * FD_K + FD_K;
+    const bool perm = w.fold_perm;
+    int64_t T_pad, ld16, zcopy; size_t xb;
+    fold_x_layout(w, T, perm, T_pad, ld16, zcopy, xb);
     const size_t part_bytes = w.tall ? 0 : (((size_t) T * (size_t) w.B * (size_t) w.L * 4 + 255) & ~(size_t) 255);
     float * part = (float *) ws;
     _Float16 * x16 = (_Float16 *) ((unsigned char *) ws + part_bytes);
-    if ((rc = launch_w0_x16(x, ldx, T, (int) w.n_in, x16, ld16, T_pad, s)) != SDH_OK) return rc;
-    const size_t lds = (size_t) (3 * FD_R + 2 * FD_N) * FD_LD * 2;
+    const size_t lds = (size_t) (3 * FD_R + 2 * FD_N) * FD_LD * 2 + (size_t) 2 * FD_GS * 2 + (size_t) (w.L / FD_K) * sizeof(int2);
+    if (lds > 160 * 1024) return 1;
     static const bool attr_ok = [] {
         bool ok = true;
-        const void * ks[8] = {(const void *) w0d_mfma_kernel<true, true, true>, (const void *) w0d_mfma_kernel<true, true, false>,
-                              (const void *) w0d_mfma_kernel<true, false, true>, (const void *) w0d_mfma_kernel<true, false, false>,
-                              (const void *) w0d_mfma_kernel<false, true, true>, (const void *) w0d_mfma_kernel<false, true, false>,
-                              (const void *) w0d_mfma_kernel<false, false, true>, (const void *) w0d_mfma_kernel<false, false, false>};
-        for (const void * k : ks) ok &= hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        auto set = [&](const void * k) { ok &= hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; };
+#define SDH_FD_SET4(TALL_, SC_) set((const void *) w0d_mfma_kernel<TALL_, SC_, false, false>); set((const void *) w0d_mfma_kernel<TALL_, SC_, false, true>); \
+        set((const void *) w0d_mfma_kernel<TALL_, SC_, true, false>); set((const void *) w0d_mfma_kernel<TALL_, SC_, true, true>)
+        SDH_FD_SET4(true, true); SDH_FD_SET4(true, false); SDH_FD_SET4(false, true); SDH_FD_SET4(false, false);
+#undef SDH_FD_SET4
+#define SDH_FP_SET4(TALL_) set((const void *) w0p_mfma_kernel<TALL_, false, false>); set((const void *) w0p_mfma_kernel<TALL_, false, true>); \
+        set((const void *) w0p_mfma_kernel<TALL_, true, false>); set((const void *) w0p_mfma_kernel<TALL_, true, true>)
+        SDH_FP_SET4(true); SDH_FP_SET4(false);
+#undef SDH_FP_SET4
+        set((const void *) fold_z16_kernel<true>); set((const void *) fold_z16_kernel<false>);
         return ok;
     }();
     if (!attr_ok) return 1;                                     // a device without the LDS for it: the caller's other forms
+    if (perm) {
+        const size_t zl = ((size_t) w.n_in * 4 + 15) & ~(size_t) 15;
+        const unsigned zg = (unsigned) (T_pad / 2);
+        if (w.tall) hipLaunchKernelGGL(fold_z16_kernel<true>, dim3(zg), dim3(1024), zl, s, x, ldx, T, (int) w.n_in, (int) w.L, (int) w.B, w.fold_p16, x16, ld16, zcopy);
+        else        hipLaunchKernelGGL(fold_z16_kernel<false>, dim3(zg), dim3(1024), zl, s, x, ldx, T, (int) w.n_in, (int) w.L, (int) w.B, w.fold_p16, x16, ld16, zcopy);
+        SDH_HIP_CHECK(hipGetLastError());
+    } else if ((rc = launch_w0_x16(x, ldx, T, (int) w.n_in, x16, ld16, T_pad, s)) != SDH_OK) return rc;
     const dim3 grid((unsigned) ((w.n_out + FD_R - 1) / FD_R), (unsigned) (T_pad / FD_N), (unsigned) (w.tall ? 1 : w.B));
     if (grid.y > 65535 || grid.z > 65535) { set_error("w0 fold: token chunk too large"); return SDH_ERR_UNSUPPORTED; }
-    const bool scaled = w.pack.off_d1 >= 0 || w.pack.off_d3 >= 0;          // else d1 = d3 = 1 (what the builder writes)
+    const bool scaled = fold_scaled(w);
     float * out = w.tall ? y : part;
     const int64_t ldo = w.tall ? ldy : (int64_t) w.B * w.L;
-#define SDH_FD_ARGS x16, ld16, T, (int) w.n_in, (int) w.n_out, (int) w.L, w.d1, w.d3, w.G, w.inv, w.fold_ent, w.fold_off, w.fold_ng, w.fold_spb, \
-        w.rs, out, ldo, nf_counter, zero_nf ? 1 : 0
-#define SDH_FD_LAUNCH(TALL_, SC_, AT_) hipLaunchKernelGGL((w0d_mfma_kernel<TALL_, SC_, AT_>), grid, dim3(512), lds, s, SDH_FD_ARGS)
+#define SDH_FD_ARGS x16, ld16, T, (int) w.n_in, (int) w.n_out, (int) w.L, w.d1, w.d3, w.G, w.inv, w.fold_ent, w.fold_off, w.fold_ng, \
+        w.fold_spb, w.rs, out, ldo, nf_counter, zero_nf ? 1 : 0
+#define SDH_FP_ARGS x16, ld16, zcopy, T, (int) w.n_out, (int) w.L, w.fold_gp, w.fold_ent, w.fold_off, w.fold_ng, \
+        w.fold_spb, w.rs, out, ldo, nf_counter, zero_nf ? 1 : 0
+#define SDH_FD_LAUNCH(TALL_, SC_, AT_) do { if (w.fold_over) hipLaunchKernelGGL((w0d_mfma_kernel<TALL_, SC_, AT_, true>), grid, dim3(512), lds, s, SDH_FD_ARGS); \
+        else hipLaunchKernelGGL((w0d_mfma_kernel<TALL_, SC_, AT_, false>), grid, dim3(512), lds, s, SDH_FD_ARGS); } while (0)
 #define SDH_FD_LAUNCH2(TALL_, SC_) do { if (w.fold_dup) SDH_FD_LAUNCH(TALL_, SC_, true); else SDH_FD_LAUNCH(TALL_, SC_, false); } while (0)
-    if (w.tall) { if (scaled) SDH_FD_LAUNCH2(true, true); else SDH_FD_LAUNCH2(true, false); }
-    else        { if (scaled) SDH_FD_LAUNCH2(false, true); else SDH_FD_LAUNCH2(false, false); }
+#define SDH_FP_LAUNCH(TALL_, AT_) do { if (w.fold_over) hipLaunchKernelGGL((w0p_mfma_kernel<TALL_, AT_, true>), grid, dim3(512), lds, s, SDH_FP_ARGS); \
+        else hipLaunchKernelGGL((w0p_mfma_kernel<TALL_, AT_, false>), grid, dim3(512), lds, s, SDH_FP_ARGS); } while (0)
+#define SDH_FP_LAUNCH2(TALL_) do { if (w.fold_dup) SDH_FP_LAUNCH(TALL_, true); else SDH_FP_LAUNCH(TALL_, false); } while (0)
+    if (perm)        { if (w.tall) SDH_FP_LAUNCH2(true); else SDH_FP_LAUNCH2(false); }
+    else if (w.tall) { if (scaled) SDH_FD_LAUNCH2(true, true); else SDH_FD_LAUNCH2(true, false); }
+    else             { if (scaled) SDH_FD_LAUNCH2(false, true); else SDH_FD_LAUNCH2(false, false); }
 #undef SDH_FD_ARGS
+#undef SDH_FP_ARGS
 #undef SDH_FD_LAUNCH2
 #undef SDH_FD_LAUNCH
+#undef SDH_FP_LAUNCH2
+#undef SDH_FP_LAUNCH
     SDH_HIP_CHECK(hipGetLastError());
     if (!w.tall) {
         const int64_t n = T * w.n_out;
