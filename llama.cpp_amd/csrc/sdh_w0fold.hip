@@ -48,6 +48,8 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int FD_R = 128, FD_N = 256, FD_K = 64, FD_LD = 72;
 constexpr int FD_GS = 8 * 128;                 // elements of one staged segment image
+constexpr int FP_LD = 80;                      // row pitch of the permuted kernel's W tiles: 160 bytes, conflict-free for the 16x16x32 B fragments
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 // ---- payload re-layout: entries bucketed by (row tile, k-slab) ------------------------------------------------
 struct FoldArgs {
@@ -72,9 +74,9 @@ __device__ inline void fold_place(const FoldArgs & a, int o, int k, int & g, int
     }
 }
 
-__device__ inline unsigned fold_entry(_Float16 v, int row, int col) {
+__device__ inline unsigned fold_entry(const FoldArgs & a, _Float16 v, int row, int col) {
     unsigned short vb; __builtin_memcpy(&vb, &v, 2);
-    return ((unsigned) vb << 16) | (unsigned) ((row * FD_LD + col) * 2);
+    return ((unsigned) vb << 16) | (unsigned) ((row * (a.perm ? FP_LD : FD_LD) + col) * 2);
 }
 
 // pass 0: count, pass 1: place (cursor starts at the bucket's offset)
@@ -95,7 +97,7 @@ void fold_bucket_kernel(const FoldArgs a, int * __restrict__ counts, int * __res
         if (PASS == 0) { atomicAdd(slot, 1); return; }
         const int pos = atomicAdd(slot, 1);
         const _Float16 v = a.val32 ? (_Float16) ((const float *) a.val)[e] : ((const _Float16 *) a.val)[e];
-        ent[pos] = fold_entry(v, row, col);
+        ent[pos] = fold_entry(a, v, row, col);
     } else {
         if (ii < 0) return;                                                        // :929-936
         const int64_t in0 = (int64_t) ii * a.block;
@@ -109,7 +111,7 @@ void fold_bucket_kernel(const FoldArgs a, int * __restrict__ counts, int * __res
             const int pos = atomicAdd(slot, 1);
             const int64_t vi = ((int64_t) o * a.nb + r) * a.block + (k - in0);
             const _Float16 v = a.val32 ? (_Float16) ((const float *) a.val)[vi] : ((const _Float16 *) a.val)[vi];
-            ent[pos] = fold_entry(v, row, col);
+            ent[pos] = fold_entry(a, v, row, col);
         }
     }
 }
@@ -151,8 +153,8 @@ void fold_scan_kernel(const int * __restrict__ counts, int * __restrict__ cursor
 // does any bucket hold the same (row, column) twice? one workgroup per bucket, a bitmap of the positions of a tile
 __global__ __launch_bounds__(256)
 void fold_dup_kernel(const unsigned * __restrict__ ent, const int2 * __restrict__ bounds, int * __restrict__ dup /* [0] flag, [1] largest bucket */) {
-    __shared__ unsigned bm[FD_R * FD_LD / 32];
-    for (int i = threadIdx.x; i < FD_R * FD_LD / 32; i += 256) bm[i] = 0u;
+    __shared__ unsigned bm[FD_R * FP_LD / 32];
+    for (int i = threadIdx.x; i < FD_R * FP_LD / 32; i += 256) bm[i] = 0u;
     __syncthreads();
     const int2 o = bounds[blockIdx.x];
     bool hit = false;
@@ -176,19 +178,28 @@ void fold_gp_kernel(const float * __restrict__ G, _Float16 * __restrict__ gp, in
 }
 
 // The pre-pass of the permuted form: z[t][j] = f16(x[t][perm1_b[j]]) (0 where block b has no such input, and for the padding
-// tokens). One workgroup of 16 waves per pair of tokens: their rows of x go to LDS once (f16), every base block gathers from there; the
-// permutation is read as 16-bit indices (fold_p16, -1 = no input), once per pair.
-//   tall: one copy per base block (z + b * zcopy), j in [0, L);   wide: one row of B * L columns
+// tokens), written in the order the contraction's waves read it: tiled [token / 32][column / 32][32 tokens][32 columns], so
+// that an A fragment of v_mfma_f32_16x16x32_f16 (16 tokens x 32 columns) is 1 KB of consecutive bytes and the four a wave
+// needs for a slab are 4 KB. One workgroup of 16 waves per four tokens and half of the columns: the rows of x go to LDS once (f16), every
+// base block gathers from there; the permutation is read as 16-bit indices (fold_p16, -1 = no input), once per four tokens.
+//   tall: one image per base block (z + b * zcopy) of kz = L columns;   wide: one image of kz = B * L columns
+constexpr int FZ_T = 4;
 template <bool TALL>
 __global__ __launch_bounds__(1024)
 void fold_z16_kernel(const float * __restrict__ x, int64_t ldx, int64_t T, int n_in, int L, int B, const short * __restrict__ p16,
-                     _Float16 * __restrict__ z, int64_t ldz, int64_t zcopy) {
+                     _Float16 * __restrict__ z, int kz, int64_t zcopy) {
     extern __shared__ __align__(16) unsigned char fz_smem[];
-    _Float16 * xr = (_Float16 *) fz_smem;                          // [2][n_in]
-    const int64_t t0 = 2 * (int64_t) blockIdx.x;
+    _Float16 * xr = (_Float16 *) fz_smem;                          // [FZ_T][n_in]
+    const int64_t t0 = FZ_T * (int64_t) blockIdx.x;
+    typedef short short8 __attribute__((ext_vector_type(8)));
+    const int gpb = L / 8, total = B * gpb, half = (total + 1) / 2;
+    const int g_end = min(total, ((int) blockIdx.y + 1) * half);
+    const int g_first = (int) blockIdx.y * half + (int) threadIdx.x;
+    // the first group's indices are asked for before the rows of x: the two round trips overlap
+    short8 q_next = *reinterpret_cast<const short8 *>(p16 + (size_t) min(g_first, total - 1) * 8);
     const bool vec = (ldx & 3) == 0 && (n_in & 3) == 0 && ((uintptr_t) x & 15) == 0;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < FZ_T; ++u) {
         if (t0 + u >= T) continue;
         const float * xt = x + (t0 + u) * ldx;
         _Float16 * xu = xr + (size_t) u * n_in;
@@ -203,17 +214,18 @@ void fold_z16_kernel(const float * __restrict__ x, int64_t ldx, int64_t T, int n
         }
     }
     __syncthreads();
-    const int gpb = L / 8;
-    for (int g = threadIdx.x; g < B * gpb; g += 1024) {
+    for (int g = g_first; g < g_end; g += 1024) {
         const int b = g / gpb, j0 = (g - b * gpb) * 8;
-        typedef short short8 __attribute__((ext_vector_type(8)));
-        const short8 q = *reinterpret_cast<const short8 *>(p16 + (size_t) b * L + j0);
+        const short8 q = q_next;
+        q_next = *reinterpret_cast<const short8 *>(p16 + (size_t) min(g + 1024, total - 1) * 8);
+        const int jj = TALL ? j0 : b * L + j0;                     // column in the image
+        _Float16 * zo = z + (TALL ? (int64_t) b * zcopy : (int64_t) 0) + ((t0 >> 5) * (int64_t) (kz >> 5) + (jj >> 5)) * 1024 + (t0 & 31) * 32 + (jj & 31);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < FZ_T; ++u) {
             half8 v;
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (t0 + u < T && q[e] >= 0) ? xr[(size_t) u * n_in + q[e]] : (_Float16) 0.0f;
-            *reinterpret_cast<half8 *>(z + (TALL ? (int64_t) b * zcopy : (int64_t) b * L) + (t0 + u) * ldz + j0) = v;
+            *reinterpret_cast<half8 *>(zo + u * 32) = v;
         }
     }
 }
@@ -236,7 +248,7 @@ static bool fold_scaled(const DeviceWeight & w) { return w.pack.off_d1 >= 0 || w
 static bool fold_perm_ok(const DeviceWeight & w) {
     const int64_t kz = w.tall ? w.L : w.B * w.L;
     static const bool off = getenv("SDH_FOLD_NO_PERM") != nullptr;               // A/B switch
-    return !off && !fold_scaled(w) && kz * 3 <= w.n_in * 4 && w.n_in <= 32767;     // 16-bit input indices; two f16 rows of x in the pre-pass's LDS
+    return !off && !fold_scaled(w) && kz * 3 <= w.n_in * 4 && w.n_in <= 20480;     // 16-bit input indices; four f16 rows of x in the pre-pass's LDS
 }
 
 int fold_ensure(DeviceWeight & w, hipStream_t s) {
@@ -613,37 +625,36 @@ void w0d_mfma_kernel(const _Float16 * __restrict__ x16, int64_t ld16, int64_t T,
 //             drain it (vmcnt(0..2) where ten loads may stay in flight). The bucket bounds sit in LDS for the same reason.
 template <bool TALL, bool ATOMIC /* the payload repeats a (row, input) pair */, bool OVER /* some bucket holds more than 2048 entries */>
 __global__ __launch_bounds__(512)
-void w0p_mfma_kernel(const _Float16 * __restrict__ z16, int64_t ldz, int64_t zcopy, int64_t T, int n_out, int L,
+void w0p_mfma_kernel(const _Float16 * __restrict__ z16, int64_t zcopy, int64_t T, int n_out, int L, int kz /* columns of one z image */,
                      const _Float16 * __restrict__ gp, const unsigned * __restrict__ ent, const int2 * __restrict__ off, int n_g, int spb,
                      const float * __restrict__ rs, float * __restrict__ out, int64_t ldo, int * __restrict__ nf_counter, int zero_nf) {
     extern __shared__ __align__(16) unsigned char fd_smem[];
-    _Float16 * Ws = (_Float16 *) fd_smem;                         // [3][FD_R][FD_LD]
-    _Float16 * Xs = Ws + 3 * FD_R * FD_LD;                        // [2][FD_N][FD_LD]
-    _Float16 * Gs = Xs + 2 * FD_N * FD_LD;                        // [2][16 groups][8 copies][8]
+    _Float16 * Ws = (_Float16 *) fd_smem;                         // [3][FD_R][FP_LD]
+    _Float16 * Gs = Ws + 3 * FD_R * FP_LD;                        // [2][16 groups][8 copies][8]
     int2 * Bn = (int2 *) (Gs + 2 * FD_GS);                        // [n_slab] bucket bounds of this workgroup
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, h = lane >> 5;
+    const int r = lane & 15, h = lane >> 4;                       // 16x16x32 operands: row (token or output row) r, columns 8 h .. 8 h + 7 of the 32
     const int o_tile = (int) blockIdx.x * FD_R;
     const int64_t t_tile = (int64_t) blockIdx.y * FD_N;
     const int b = TALL ? o_tile / L : (int) blockIdx.z;
     const int p0 = TALL ? o_tile - b * L : o_tile;                // first row of the tile inside its block
     const int n_slab = spb;
     const int2 * offr = off + (size_t) blockIdx.x * n_g + (TALL ? 0 : b * spb);
-    const _Float16 * zb = z16 + (TALL ? (int64_t) b * zcopy : (int64_t) b * L) + t_tile * ldz;
+    // x fragments of this wave: tokens t_tile + 32 wave .. + 32; the image is tiled [token / 32][column / 32][token half][16][32]
+    const _Float16 * zw = z16 + (TALL ? (int64_t) b * zcopy : (int64_t) 0) + ((t_tile >> 5) + wave) * ((int64_t) kz * 32)
+                        + (TALL ? (int64_t) 0 : (int64_t) b * L * 32) + r * 32 + h * 8;
     const char * Gb = (const char *) (gp + (size_t) 8 * b * L);
 
     const int pl = tid & 127, gsel = tid >> 7;
     const unsigned gs_r = (unsigned) (((((pl >> 3) ^ gsel) << 3) | (pl & 7)) << 3);          // element offset in a Gs image at hi = 0, g = gsel
-    const unsigned ws_p = (unsigned) (pl * FD_LD + 8 * gsel);
+    const unsigned ws_p = (unsigned) (pl * FP_LD + 8 * gsel);
     // staging: dword tid of the image = group tid >> 5, copy (tid >> 2) & 7, halves 2 (tid & 3) ..
     const unsigned sg_src = (((unsigned) ((tid >> 2) & 7) * (unsigned) L + (unsigned) ((tid >> 5) << 3) + (unsigned) ((tid & 3) << 1)) << 1);
-    const unsigned xoff = (unsigned) ((tid >> 3) * ldz + (tid & 7) * 8);
-    const unsigned xs_w = (unsigned) ((tid >> 3) * FD_LD + (tid & 7) * 8);
 
     unsigned sg = 0;            // the staged dword of the segment three slabs on
     half8 gh[2];                // the two column groups of the tile two slabs on
-    half8 xq[3][4];             // x tiles in flight
+    half8 xq[3][4];             // x fragments of three slabs, [set][2 * (32-column step) + token half]
     uint4 eq[3];                // residual entries (four per thread) in flight
     int ebeg[3], eend[3];       // their bucket bounds
     int2 obe = make_int2(0, 0); // bucket bounds read a slab ahead of the entry loads that use them
@@ -651,25 +662,15 @@ void w0p_mfma_kernel(const _Float16 * __restrict__ z16, int64_t ldz, int64_t zco
     auto fetch_off = [&](int s) { obe = Bn[clamp_slab(s)]; };
     auto fetchX = [&](auto set_c, int s) {
         constexpr int S = decltype(set_c)::value;
-        const _Float16 * xs0 = zb + clamp_slab(s) * FD_K;          // uniform
+        const _Float16 * xs0 = zw + (size_t) clamp_slab(s) * (4 * 512);                   // 4 KB per slab and wave, contiguous
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xq[S][i] = *reinterpret_cast<const half8 *>(xs0 + (size_t) i * 64 * ldz + xoff);
+        for (int i = 0; i < 4; ++i) xq[S][i] = *reinterpret_cast<const half8 *>(xs0 + i * 512);
     };
     auto fetchE = [&](auto set_c) {
         constexpr int S = decltype(set_c)::value;
         ebeg[S] = __builtin_amdgcn_readfirstlane(obe.x); eend[S] = __builtin_amdgcn_readfirstlane(obe.y);
         const int e = ebeg[S] + 4 * tid;                           // buckets start and end at multiples of 4: one 16-byte load
         eq[S] = *reinterpret_cast<const uint4 *>(ent + (e < eend[S] ? e : max(eend[S] - 4, 0)));      // clamped: read unconditionally
-    };
-    auto commitX = [&](auto set_c, unsigned xbuf, int half) {
-        constexpr int S = decltype(set_c)::value;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#ifdef SDH_FP_XKEEP
-            { const half8 keep = xq[S][2 * half + i]; asm volatile("" :: "v"(keep)); }
-#else
-            *reinterpret_cast<half8 *>(Xs + xbuf + xs_w + (2 * half + i) * 64 * FD_LD) = xq[S][2 * half + i];
-#endif
     };
     auto seg_load = [&](int s) {                                   // global -> sg: the image dword of slab s
         const unsigned base = ((unsigned) (p0 ^ (clamp_slab(s) << 6)) & ~127u) << 1;
@@ -721,109 +722,83 @@ void w0p_mfma_kernel(const _Float16 * __restrict__ z16, int64_t ldz, int64_t zco
             }
     };
 
-    const int wr = wave & 1, wt = wave >> 1;                      // wave tile: rows wr*64.., tokens wt*64..
-    floatx16 acc[2][2];                                           // [token tile][row tile]
+    // wave tile: all 128 rows x 32 tokens (no two waves want the same x: its fragments come straight from global memory), as
+    // 2 x 8 tiles of v_mfma_f32_16x16x32_f16 (the chip holds a higher clock under this shape than under 32x32x16 at the same
+    // cycles per flop). A multiply step = one 32-column half of the slab x one half of the rows: 4 W fragments, 8 MFMAs.
+    floatx4 acc[2][8];                                            // [token half][row tile of 16]
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < 8; ++c)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.0f;
-    const unsigned wfrag = (unsigned) ((wr * 64 + r) * FD_LD + 8 * h), xfrag = (unsigned) ((wt * 64 + r) * FD_LD + 8 * h);
-    half8 xf[2][2], wf[2][2];
-    auto frags = [&](int q, unsigned xbuf, unsigned wbuf, int ks) {
-        const _Float16 * Wb = Ws + wbuf + wfrag;
-        const _Float16 * Xb = Xs + xbuf + xfrag;
+            for (int e = 0; e < 4; ++e) acc[a][c][e] = 0.0f;
+    const unsigned wfrag = (unsigned) (r * FP_LD + 8 * h);
+    half8 wf[2][4];
+    auto frags = [&](int q, unsigned wbuf, int ks) {                // step ks: columns 32 (ks >> 1) .., rows 64 (ks & 1) ..
+        const _Float16 * Wb = Ws + wbuf + wfrag + (ks & 1) * 64 * FP_LD + (ks >> 1) * 32;
 #pragma unroll
-        for (int a = 0; a < 2; ++a) xf[q][a] = *reinterpret_cast<const half8 *>(Xb + a * 32 * FD_LD + ks * 16);
-#pragma unroll
-        for (int c = 0; c < 2; ++c) wf[q][c] = *reinterpret_cast<const half8 *>(Wb + c * 32 * FD_LD + ks * 16);
+        for (int c = 0; c < 4; ++c) wf[q][c] = *reinterpret_cast<const half8 *>(Wb + c * 16 * FP_LD);
     };
-    auto multiply = [&](int q) {
+    auto multiply = [&](int q, int ks, const half8 & x0, const half8 & x1) {
 #ifndef SDH_FD_NOMFMA
-#ifdef SDH_FP_PRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[q][a], wf[q][c], acc[a][c], 0, 0, 0);
-#ifdef SDH_FP_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
+        for (int c = 0; c < 4; ++c) {
+            acc[0][4 * (ks & 1) + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x0, wf[q][c], acc[0][4 * (ks & 1) + c], 0, 0, 0);
+            acc[1][4 * (ks & 1) + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x1, wf[q][c], acc[1][4 * (ks & 1) + c], 0, 0, 0);
+        }
 #endif
     };
 
     using set0 = std::integral_constant<int, 0>;
     using set1 = std::integral_constant<int, 1>;
     using set2 = std::integral_constant<int, 2>;
-    unsigned Wcur = 0, Wnxt = FD_R * FD_LD, Wnx2 = 2 * FD_R * FD_LD;      // element offsets of the three W tiles in rotation
-    unsigned xcur = 0, xnxt = FD_N * FD_LD;                               // and of the two x tiles
+    unsigned Wcur = 0, Wnxt = FD_R * FP_LD, Wnx2 = 2 * FD_R * FP_LD;      // element offsets of the three W tiles in rotation
     int par = 0;                                                          // parity of the slab
-    // slab s, on entry: LDS: Wcur = W0+D of slab s, Wnxt = W0 of slab s+1 (entries not yet added), Xs[xcur] = x of slab s,
-    // Gs[par] = segment of slab s+2; registers: sg = segment dword of slab s+3, sets (x, entries) of slabs s+1 (set c_c, used
-    // here) and s+2; the set a_c is free and receives slab s+3. The fragments of the first multiply step are in flight.
+    // slab s, on entry: LDS: Wcur = W0+D of slab s, Wnxt = W0 of slab s+1 (entries not yet added), Gs[par] = segment of slab
+    // s+2; registers: sg = segment dword of slab s+3, x fragments of slabs s (set a_c), s+1, s+2, entries of slabs s+1 (set
+    // c_c, added here) and s+2. The set a_c receives the entries of slab s+3 at once and its x fragments after the last
+    // multiply step. The W fragments of the first multiply step are in flight.
     auto slab = [&](auto a_c, auto c_c, int s) {
+        constexpr int A = decltype(a_c)::value;
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
-            frags((ks + 1) & 1, xcur, Wcur, ks + 1);
-            multiply(ks & 1);
-#if defined(SDH_FP_NOX)
-#define SDH_FP_X(...)
-#else
-#define SDH_FP_X(...) __VA_ARGS__
-#endif
-#if defined(SDH_FP_NOXW) || defined(SDH_FP_NOX)
-#define SDH_FP_XW(...)
-#else
-#define SDH_FP_XW(...) __VA_ARGS__
-#endif
-#if defined(SDH_FP_NOTILE)
-#define SDH_FP_TILE(...)
-#else
-#define SDH_FP_TILE(...) __VA_ARGS__
-#endif
-#if defined(SDH_FP_NOSCATTER)
-#define SDH_FP_SC(...)
-#else
-#define SDH_FP_SC(...) __VA_ARGS__
-#endif
+            frags((ks + 1) & 1, Wcur, ks + 1);
+            multiply(ks & 1, ks, xq[A][2 * (ks >> 1)], xq[A][2 * (ks >> 1) + 1]);
             if (ks == 0) {
-                SDH_FP_SC(fetchE(a_c);)                              // bucket s + 3 (bounds: fetch_off of the slab before)
-                SDH_FP_TILE(seg_commit(par ^ 1); seg_load(s + 4); tile_read(par, par);)
-                SDH_FP_SC(scatter_read(c_c, Wnxt);)
+                fetchE(a_c);                                         // bucket s + 3 (bounds: fetch_off of the slab before)
+                seg_commit(par ^ 1); seg_load(s + 4); tile_read(par, par);
+                scatter_read(c_c, Wnxt);
             }
-            if (ks == 1) { SDH_FP_X(fetchX(a_c, s + 3);) SDH_FP_TILE(tile_write(Wnx2, 0);) SDH_FP_XW(commitX(c_c, xnxt, 0);) }
-            if (ks == 2) { SDH_FP_SC(fetch_off(s + 4);) SDH_FP_TILE(tile_write(Wnx2, 1);) SDH_FP_XW(commitX(c_c, xnxt, 1);) SDH_FP_SC(scatter(c_c, Wnxt);) }
+            if (ks == 1) tile_write(Wnx2, 0);
+            if (ks == 2) { fetch_off(s + 4); tile_write(Wnx2, 1); scatter(c_c, Wnxt); }
         }
         __syncthreads();
         { const unsigned t = Wcur; Wcur = Wnxt; Wnxt = Wnx2; Wnx2 = t; }
-        { const unsigned t = xcur; xcur = xnxt; xnxt = t; }
         par ^= 1;
-        frags(0, xcur, Wcur, 0);                                     // the next slab's first step, behind the barrier
-        multiply(1);                                                 // this slab's last: the matrix pipe works through that LDS latency
+        frags(0, Wcur, 0);                                           // the next slab's first step, behind the barrier
+        multiply(1, 3, xq[A][2], xq[A][3]);                                       // this slab's last: the matrix pipe works through that LDS latency
+        fetchX(a_c, s + 3);
     };
 
     for (int i = tid; i < n_slab; i += 512) Bn[i] = offr[i];
     seg_load(0); seg_commit(0);
     seg_load(1); seg_commit(1);
-    fetchX(set0{}, 0);
     __syncthreads();
     fetch_off(0);
     fetchE(set0{});
     tile_read(0, 0); tile_write(Wcur, 0); tile_write(Wcur, 1);
     tile_read(1, 1); tile_write(Wnxt, 0); tile_write(Wnxt, 1);
-    commitX(set0{}, xcur, 0); commitX(set0{}, xcur, 1);
     __syncthreads();
     seg_load(2); seg_commit(0);
     scatter_read(set0{}, Wcur);
     scatter(set0{}, Wcur);
-    fetch_off(1); fetchE(set1{}); fetchX(set1{}, 1);               // as slab -2 would: slab 1 -> set 1
-    fetch_off(2); fetchE(set2{}); seg_load(3); fetchX(set2{}, 2);  // as slab -1 would: slab 2 -> set 2, segment of slab 3
+    // the loads in flight on the way into the loop, in the order the loop's slabs -3, -2, -1 would have issued them
+    fetchX(set0{}, 0);
+    fetch_off(1); fetchE(set1{}); fetchX(set1{}, 1);
+    fetch_off(2); fetchE(set2{}); seg_load(3); fetchX(set2{}, 2);
     fetch_off(3);
     __syncthreads();
-    frags(0, xcur, Wcur, 0);
+    frags(0, Wcur, 0);
     int s = 0;
     for (; s + 2 < n_slab; s += 3) {                    // no branch inside the triple
         slab(set0{}, set1{}, s);
@@ -833,19 +808,19 @@ void w0p_mfma_kernel(const _Float16 * __restrict__ z16, int64_t ldz, int64_t zco
     if (s < n_slab) slab(set0{}, set1{}, s);
     if (s + 1 < n_slab) slab(set1{}, set2{}, s + 1);
 
-    // C[row = token][col = o]: row = (e & 3) + 8 * (e >> 2) + 4 * h, col = r
+    // C[row = token][col = o] of a 16 x 16 tile: row = 4 h + e, col = r
     const size_t col_off = TALL ? 0 : (size_t) b * L;
     int bad = 0;
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int orow = o_tile + wr * 64 + c * 32 + r;
+    for (int c = 0; c < 8; ++c) {
+        const int orow = o_tile + c * 16 + r;
         if (orow >= n_out) continue;
         const float sc = (TALL && rs) ? rs[orow] : 1.0f;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int64_t t = t_tile + wt * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            for (int e = 0; e < 4; ++e) {
+                const int64_t t = t_tile + wave * 32 + a * 16 + 4 * h + e;
                 if (t >= T) continue;
                 float v = acc[a][c][e];
                 if (TALL) {
@@ -875,11 +850,11 @@ void fold_reduce_kernel(const float * __restrict__ part, int B, int L, int n_out
     y[t * ldy + o] = v;
 }
 
-// x image: q order: [T_pad][round64(n_in) + 64]; j order: tall [B][T_pad][L + 64], wide [T_pad][B * L + 64]
+// x image: q order: [T_pad][round64(n_in) + 64]; j order (tiled): tall B images of T_pad x L, wide one of T_pad x B * L
 static void fold_x_layout(const DeviceWeight & w, int64_t T, bool perm, int64_t & T_pad, int64_t & ld16, int64_t & zcopy, size_t & bytes) {
     T_pad = (T + FD_N - 1) / FD_N * FD_N;
     if (!perm) { ld16 = (w.n_in + FD_K - 1) / FD_K * FD_K + FD_K; zcopy = 0; bytes = (size_t) T_pad * (size_t) ld16 * 2; return; }
-    ld16 = (w.tall ? w.L : w.B * w.L) + FD_K;
+    ld16 = w.tall ? w.L : w.B * w.L;                             // columns of one image (tiled, not a row stride: see fold_z16_kernel)
     zcopy = w.tall ? T_pad * ld16 : 0;
     bytes = (size_t) T_pad * (size_t) ld16 * 2 * (size_t) (w.tall ? w.B : 1);
 }
@@ -905,7 +880,8 @@ int launch_w0_fold(DeviceWeight & w, const float * x, int64_t ldx, int64_t T, vo
     const size_t part_bytes = w.tall ? 0 : (((size_t) T * (size_t) w.B * (size_t) w.L * 4 + 255) & ~(size_t) 255);
     float * part = (float *) ws;
     _Float16 * x16 = (_Float16 *) ((unsigned char *) ws + part_bytes);
-    const size_t lds = (size_t) (3 * FD_R + 2 * FD_N) * FD_LD * 2 + (size_t) 2 * FD_GS * 2 + (size_t) (w.L / FD_K) * sizeof(int2);
+    const size_t lds = perm ? (size_t) 3 * FD_R * FP_LD * 2 + (size_t) 2 * FD_GS * 2 + (size_t) (w.L / FD_K) * sizeof(int2)
+                            : (size_t) (3 * FD_R + 2 * FD_N) * FD_LD * 2 + (size_t) 2 * FD_GS * 2 + (size_t) (w.L / FD_K) * sizeof(int2);
     if (lds > 160 * 1024) return 1;
     static const bool attr_ok = [] {
         bool ok = true;
@@ -923,10 +899,10 @@ int launch_w0_fold(DeviceWeight & w, const float * x, int64_t ldx, int64_t T, vo
     }();
     if (!attr_ok) return 1;                                     // a device without the LDS for it: the caller's other forms
     if (perm) {
-        const size_t zl = ((size_t) w.n_in * 4 + 15) & ~(size_t) 15;
-        const unsigned zg = (unsigned) (T_pad / 2);
-        if (w.tall) hipLaunchKernelGGL(fold_z16_kernel<true>, dim3(zg), dim3(1024), zl, s, x, ldx, T, (int) w.n_in, (int) w.L, (int) w.B, w.fold_p16, x16, ld16, zcopy);
-        else        hipLaunchKernelGGL(fold_z16_kernel<false>, dim3(zg), dim3(1024), zl, s, x, ldx, T, (int) w.n_in, (int) w.L, (int) w.B, w.fold_p16, x16, ld16, zcopy);
+        const size_t zl = ((size_t) w.n_in * 2 * FZ_T + 15) & ~(size_t) 15;
+        const dim3 zg((unsigned) (T_pad / FZ_T), 2);
+        if (w.tall) hipLaunchKernelGGL(fold_z16_kernel<true>, zg, dim3(1024), zl, s, x, ldx, T, (int) w.n_in, (int) w.L, (int) w.B, w.fold_p16, x16, (int) ld16, zcopy);
+        else        hipLaunchKernelGGL(fold_z16_kernel<false>, zg, dim3(1024), zl, s, x, ldx, T, (int) w.n_in, (int) w.L, (int) w.B, w.fold_p16, x16, (int) ld16, zcopy);
         SDH_HIP_CHECK(hipGetLastError());
     } else if ((rc = launch_w0_x16(x, ldx, T, (int) w.n_in, x16, ld16, T_pad, s)) != SDH_OK) return rc;
     const dim3 grid((unsigned) ((w.n_out + FD_R - 1) / FD_R), (unsigned) (T_pad / FD_N), (unsigned) (w.tall ? 1 : w.B));
@@ -936,7 +912,7 @@ int launch_w0_fold(DeviceWeight & w, const float * x, int64_t ldx, int64_t T, vo
     const int64_t ldo = w.tall ? ldy : (int64_t) w.B * w.L;
 #define SDH_FD_ARGS x16, ld16, T, (int) w.n_in, (int) w.n_out, (int) w.L, w.d1, w.d3, w.G, w.inv, w.fold_ent, w.fold_off, w.fold_ng, \
         w.fold_spb, w.rs, out, ldo, nf_counter, zero_nf ? 1 : 0
-#define SDH_FP_ARGS x16, ld16, zcopy, T, (int) w.n_out, (int) w.L, w.fold_gp, w.fold_ent, w.fold_off, w.fold_ng, \
+#define SDH_FP_ARGS x16, zcopy, T, (int) w.n_out, (int) w.L, (int) ld16, w.fold_gp, w.fold_ent, w.fold_off, w.fold_ng, \
         w.fold_spb, w.rs, out, ldo, nf_counter, zero_nf ? 1 : 0
 #define SDH_FD_LAUNCH(TALL_, SC_, AT_) do { if (w.fold_over) hipLaunchKernelGGL((w0d_mfma_kernel<TALL_, SC_, AT_, true>), grid, dim3(512), lds, s, SDH_FD_ARGS); \
         else hipLaunchKernelGGL((w0d_mfma_kernel<TALL_, SC_, AT_, false>), grid, dim3(512), lds, s, SDH_FD_ARGS); } while (0)
