@@ -619,6 +619,10 @@ void w0d_mfma_kernel(const _Float16 * __restrict__ x16, int64_t ld16, int64_t T,
 //             (loads alone, no multiplies: 58 GB/s measured here), and one slab ahead (32 KB) left the waves waiting on vmcnt
 //             with the matrix pipe idle — the multiply-only build of this kernel ran 54 us, the load-only build 58 us, both
 //             together 88 us.
+//   tried     the workgroups that read one x panel (base block, token tile) on one XCD instead of dealt round-robin: the same
+//             time within 1 % (85.4 / 86.4 us per call on a Mistral gate). In the pre-pass, the four tokens' values of an input
+//             side by side in LDS (8 gathers of 8 bytes per thread instead of 32 of 2, staged by dword loads): 12.3 / 21.4 us
+//             against 10.0 / 12.1 us (tall / wide Mistral tensors). Neither kept.
 //   vmcnt     every global load of the loop is issued unconditionally (indices clamped; work for slabs past the end lands in
 //             tiles nothing reads) and the prologue issues its last loads in the loop's order: a load behind a branch, or a
 //             different order on the way into the loop, makes the compiler's counted waits assume the shortest queue and
@@ -764,20 +768,29 @@ void w0p_mfma_kernel(const _Float16 * __restrict__ z16, int64_t zcopy, int64_t T
         for (int ks = 0; ks < 3; ++ks) {
             frags((ks + 1) & 1, Wcur, ks + 1);
             multiply(ks & 1, ks, xq[A][2 * (ks >> 1)], xq[A][2 * (ks >> 1) + 1]);
-            if (ks == 0) {
-                fetchE(a_c);                                         // bucket s + 3 (bounds: fetch_off of the slab before)
-                seg_commit(par ^ 1); seg_load(s + 4); tile_read(par, par);
-                scatter_read(c_c, Wnxt);
-            }
+            // (dev ablations: -DSDH_FP_NOSC / NOTILE / NOX drop the entries, the tile build, the x loads: results wrong, times
+            // 82.6 / 75.6 / 72.3 us against 81.0 per call on a Mistral gate; all three: 65.1; no multiplies: 39.8)
+#ifndef SDH_FP_NOSC
+            if (ks == 0) fetchE(a_c);                                // bucket s + 3 (bounds: fetch_off of the slab before)
+#endif
+#ifndef SDH_FP_NOTILE
+            if (ks == 0) { seg_commit(par ^ 1); seg_load(s + 4); tile_read(par, par); }
             if (ks == 1) tile_write(Wnx2, 0);
-            if (ks == 2) { fetch_off(s + 4); tile_write(Wnx2, 1); scatter(c_c, Wnxt); }
+            if (ks == 2) tile_write(Wnx2, 1);
+#endif
+#ifndef SDH_FP_NOSC
+            if (ks == 0) scatter_read(c_c, Wnxt);
+            if (ks == 2) { fetch_off(s + 4); scatter(c_c, Wnxt); }
+#endif
         }
         __syncthreads();
         { const unsigned t = Wcur; Wcur = Wnxt; Wnxt = Wnx2; Wnx2 = t; }
         par ^= 1;
         frags(0, Wcur, 0);                                           // the next slab's first step, behind the barrier
-        multiply(1, 3, xq[A][2], xq[A][3]);                                       // this slab's last: the matrix pipe works through that LDS latency
+        multiply(1, 3, xq[A][2], xq[A][3]);                          // this slab's last: the matrix pipe works through that LDS latency
+#ifndef SDH_FP_NOX
         fetchX(a_c, s + 3);
+#endif
     };
 
     for (int i = tid; i < n_slab; i += 512) Bn[i] = offr[i];
