@@ -30,7 +30,7 @@ extern "C" {
 
 /* 2: stream == NULL on device-I/O calls is HIP's legacy default stream (version 1: the library's private stream);
  *    SDH_FWD_NO_SPMM selects the row kernels' arithmetic; sdh_scan_params.reserved0 became kgrid_draws;
- *    sdh_debug_alloc_calls added. INTEGRATION.md "Migration notes". */
+ *    sdh_debug_alloc_calls, sdh_debug_fold_layout added. INTEGRATION.md "Migration notes". */
 #define SDH_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------------------ */
@@ -195,6 +195,10 @@ int64_t sdh_noalloc_scratch_bytes(void);   /* SDH_NOALLOC_SCRATCH_BYTES of the l
 /* Test hook (no counterpart in the reference): hipMalloc + hipHostMalloc + hipFree calls the library has made in this
  * process so far. tests/test_zz_no_alloc.py reads it around sdh_forward_noalloc calls and asserts a difference of 0. */
 int64_t sdh_debug_alloc_calls(void);
+/* Test hook (no counterpart in the reference): how the handle's residual is laid out for SDH_FWD_MFMA_FOLD. 0 = not built
+ * yet (no folded call so far); else bit 0 set, bit 1 = permuted order (j = inv_b[q]; w0p_mfma_kernel), bit 2 = some (row,
+ * input) pair repeats (atomic adds), bit 3 = some bucket holds more than 2048 entries (overflow variant). */
+int     sdh_debug_fold_layout(sdh_weight * w);
 
 /* Number of non-finite outputs produced by the most recent sdh_forward on this handle
  * (the reference's llama_seeddelta_nan_count, src/llama-seeddelta.cpp:77,382, per call).

@@ -1076,6 +1076,12 @@ int sdh_forward_noalloc(sdh_weight * h, const float * x, int64_t ldx, int64_t n_
 
 int64_t sdh_noalloc_scratch_bytes(void) { return (int64_t) NOALLOC_SCRATCH_BYTES; }
 int64_t sdh_debug_alloc_calls(void) { return (int64_t) sdh::g_alloc_calls.load(); }
+int sdh_debug_fold_layout(sdh_weight * h) {
+    if (!h) return 0;
+    const DeviceWeight * w = reinterpret_cast<const DeviceWeight *>(h);
+    if (!w->fold_ent) return 0;
+    return 1 | (w->fold_perm ? 2 : 0) | (w->fold_dup ? 4 : 0) | (w->fold_over ? 8 : 0);
+}
 
 int sdh_ffn_gate_up(sdh_weight * hg, sdh_weight * hu, int act, const float * x, int64_t ldx, int64_t n_tokens,
                     float * h, int64_t ldh, int flags, void * stream) {

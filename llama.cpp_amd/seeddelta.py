@@ -34,7 +34,7 @@ FWD_MFMA_FOLD = 0x40          # prefill as one dense contraction, residual folde
 ABI_SYMBOLS = [
     "sdh_init", "sdh_abi_version", "sdh_last_error", "sdh_device_synchronize", "sdh_library_stream",
     "sdh_weight_create", "sdh_weight_destroy", "sdh_weight_op_kind", "sdh_weight_payload_bytes",
-    "sdh_forward", "sdh_forward_noalloc", "sdh_noalloc_scratch_bytes", "sdh_debug_alloc_calls", "sdh_probe_stream_floor", "sdh_nonfinite_count", "sdh_w0_tile", "sdh_ffn_forward", "sdh_ffn_gate_up", "sdh_ffn_last_fused", "sdh_glu",
+    "sdh_forward", "sdh_forward_noalloc", "sdh_noalloc_scratch_bytes", "sdh_debug_alloc_calls", "sdh_debug_fold_layout", "sdh_probe_stream_floor", "sdh_nonfinite_count", "sdh_w0_tile", "sdh_ffn_forward", "sdh_ffn_gate_up", "sdh_ffn_last_fused", "sdh_glu",
     "sdh_ffn_stack_create", "sdh_ffn_stack_destroy", "sdh_ffn_stack_forward", "sdh_ffn_stack_status", "sdh_ffn_stack_payload_bytes",
     "sdh_profile_enable", "sdh_profile_read", "sdh_profile_span_begin", "sdh_profile_span_end",
     "sdh_dense_create", "sdh_dense_destroy", "sdh_dense_bytes",
@@ -126,6 +126,8 @@ def load_library(path: str = LIB_PATH):
     lib.sdh_forward_noalloc.argtypes = lib.sdh_forward.argtypes
     lib.sdh_noalloc_scratch_bytes.restype = C.c_int64
     lib.sdh_debug_alloc_calls.restype = C.c_int64
+    lib.sdh_debug_fold_layout.restype = C.c_int
+    lib.sdh_debug_fold_layout.argtypes = [C.c_void_p]
     lib.sdh_ffn_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64,
                                     C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
     lib.sdh_ffn_gate_up.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64,
@@ -280,6 +282,10 @@ class SeedDeltaWeight:
         """sdh_forward_noalloc; returns the status code (0, or SDH_ERR_TOO_LARGE = -5 ...) instead of raising."""
         return int(load_library().sdh_forward_noalloc(self._h, x_ptr, ldx, T, y_ptr, ldy, flags,
                                                       C.c_void_p(stream) if stream else None))
+
+    def fold_layout(self) -> int:
+        """test hook: sdh_debug_fold_layout (bit 1 = permuted order, bit 2 = duplicates, bit 3 = overflow buckets)"""
+        return int(load_library().sdh_debug_fold_layout(self._h))
 
     def nonfinite_count(self) -> int:
         n = load_library().sdh_nonfinite_count(self._h)

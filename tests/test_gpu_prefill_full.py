@@ -191,7 +191,51 @@ def test_mfma_fold_small_shapes(hip, dims, scheme, K, block):
         err = np.abs(y[:, o].astype(np.float64) - y_ref[:, o].astype(np.float64))
         assert np.all(err <= bound[int(o)]), (dims, scheme, int(o), float(np.max(err / bound[int(o)])))
     assert w.nonfinite_count() == 0
+    assert w.fold_layout() & 3 == 1                         # d1 / d3 present: the q-order kernel
     w.close()
+
+
+@pytest.mark.parametrize("dims", [(256, 640), (640, 256), (200, 1000), (1000, 200), (1024, 1024), (128, 128), (2048, 384)])
+@pytest.mark.parametrize("scheme,K,block", [("coo", 24, 16), ("block", 64, 16), ("block", 96, 32), ("coo", 120, 16)])
+def test_mfma_fold_permuted_order_small_shapes(hip, dims, scheme, K, block):
+    """The same odd dims with d1 = d3 = 1 (what the builder writes): the contraction runs in the permuted order j = inv_b[q]
+    (w0p_mfma_kernel: x permuted and tiled by the pre-pass, W0 tile built from one segment of G_b, entries bucketed by j).
+    Covers tall and wide with a partly filled last base block (columns of the block without an input multiply zeros), L =
+    128 (two slabs: only the loop's tail runs), duplicates (the atomic variant), bad indices, and with K = 120 of 128-256
+    inputs buckets of more than 2048 entries (the overflow variant). Every element against the oracle."""
+    n_in, n_out = dims
+    p = make_payload(n_in, n_out, scheme=scheme, K=K, block=block, base=True, seed=n_in + K + 1)
+    if scheme == "coo":
+        p.d_idx[::7, 0] = -1
+        p.d_idx[1::9, 1] = n_in + 3                         # out of range: skipped (:693)
+        if K < 100:
+            p.d_idx[2::5, 3] = p.d_idx[2::5, 2]             # duplicates sum
+    else:
+        p.b_idx[::6, 0] = -1
+        p.b_idx[1::8, 1] = (n_in + block - 1) // block - 1
+    for T in (37, 300):
+        x = make_x(n_in, T, seed=3)
+        y_ref = O.forward(p, x, nth=4)
+        w = hip.SeedDeltaWeight(p)
+        y = w.forward_host(x, hip.FWD_MFMA_FOLD)
+        rows = np.arange(n_out)
+        sel = np.arange(0, T, 7)
+        bound = fold_bound(p, x, y_ref, rows, sel)
+        worst = 0.0
+        for o in rows:
+            err = np.abs(y[sel, o].astype(np.float64) - y_ref[sel, o].astype(np.float64))
+            assert np.all(err <= bound[int(o)]), (dims, scheme, T, int(o), float(np.max(err / bound[int(o)])))
+            worst = max(worst, float(np.max(err / bound[int(o)])))
+        assert np.abs(y - y_ref).max() <= 2e-2 * np.abs(y_ref).max()
+        assert worst > 1e-4                                 # not the bit-exact forms: the folded path ran
+        assert w.nonfinite_count() == 0
+        lay = w.fold_layout()
+        assert lay & 2, lay                                 # ... in the permuted order
+        if scheme == "coo" and K < 100:
+            assert lay & 4, lay                             # the duplicates were seen
+        if scheme == "coo" and K >= 100 and n_in <= 256:
+            assert lay & 8, lay                             # buckets beyond the prefetch
+        w.close()
 
 
 def test_mfma_fold_counts_nonfinite_outputs(hip):
