@@ -352,6 +352,25 @@ def run_ffn(args, dev):
         ev_t, _ = timed_on_stream(block_t, max(4, reps // 8), st, seeddelta)
         by_tokens[str(T)] = ev_t * 1e3 / (max(4, reps // 8) * NL)
         del xT, yT
+    # one ubatch of prefill through the same layers: the default node forms, and every node as a folded f16 contraction
+    # (SDH_FWD_MFMA_FOLD: gate, up with the activation in its epilogue, down)
+    prefill_layer = {}
+    if not args.no_prefill:
+        T = 512
+        xT = torch.randn((T, n_embd), dtype=torch.float32, device=dev)
+        yT = torch.empty((T, n_embd), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        use = layers[:min(NL, 4)]
+        for name, fl in (("default", 0), ("mfma_fold", seeddelta.FWD_MFMA_FOLD)):
+            def block_p():
+                for wg, wu, wd in use:
+                    seeddelta.ffn_forward_device(wg, wu, wd, seeddelta.ACT_SILU, xT.data_ptr(), n_embd, T, yT.data_ptr(), n_embd, fl, sp)
+            ev_p, _ = timed_on_stream(block_p, 6, st, seeddelta, warm=2)
+            prefill_layer[name] = ev_p / (6 * len(use))
+        prefill_layer = {"tokens": T, "ms_per_layer": prefill_layer,
+                         "tokens_per_s_fold": T / prefill_layer["mfma_fold"] * 1e3,
+                         "mfma_frac_fold": 2.0 * 3 * n_embd * n_ff * T / (prefill_layer["mfma_fold"] * 1e-3) / (MFMA_F16_PEAK_TFLOPS * 1e12)}
+        del xT, yT
     for ws in layers:
         for w in ws:
             w.close()
@@ -361,6 +380,7 @@ def run_ffn(args, dev):
            "us_per_layer_node_by_node": us_nodes, "us_per_layer_node_by_node_host_clock": host_n * 1e3 / (reps * NL),
            "speedup_vs_node_by_node": us_nodes / us_block,
            "gate_up_single_launch": bool(fused), "distinct_layers": NL, "us_per_layer_by_tokens": by_tokens,
+           "prefill_layer": prefill_layer,
            "algorithmic_bytes_per_layer": alg,
            "timing": "HIP events recorded by the library on the explicit launch stream; host clock (synchronised) beside it",
            "roofline": {"bound": "hbm", "achieved": alg / us_block / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -790,6 +810,11 @@ def main():
         if ffn is not None:
             line["ffn_block"] = {"value": r3(ffn["value"]), "unit": ffn["unit"], "us_per_layer": r3(ffn["us_per_layer"]),
                                  "bound": "hbm", "frac": r3(ffn["roofline"]["frac"]), "timing_consistent": ffn["timing_consistent"]}
+            if ffn.get("prefill_layer"):
+                pl = ffn["prefill_layer"]
+                line["ffn_block"]["prefill_layer"] = {"tokens": pl["tokens"], "ms": r3(pl["ms_per_layer"]["default"]),
+                                                      "fold_ms": r3(pl["ms_per_layer"]["mfma_fold"]),
+                                                      "fold_tok_s": r3(pl["tokens_per_s_fold"]), "fold_mfma_frac": r3(pl["mfma_frac_fold"])}
         if stack is not None:
             line["ffn_stack"] = {"value": r3(stack["value"]), "unit": stack["unit"], "us_per_layer": r3(stack["us_per_layer"]),
                                  "bound": "hbm", "frac": r3(stack["roofline"]["frac"]), "handoff_timeouts": stack["handoff_timeouts"]}

@@ -576,7 +576,7 @@ static int sdh_forward_impl(sdh_weight * h, const float * x, int64_t ldx, int64_
     // T=192: 0.13 / 0.15). SDH_FWD_NO_MFMA keeps the fp32 forms.
     const int64_t row_entries = (w->kind == SDH_OP_BASE_BLOCK) ? w->nb * w->block : w->K;
     const bool fold_default = row_entries >= 512 && n_tokens >= 160 && !(flags & (SDH_FWD_NO_MFMA | SDH_FWD_W0_MFMA | SDH_FWD_NO_SPMM | SDH_FWD_INTERNAL_ROWS));
-    if (((flags & SDH_FWD_MFMA_FOLD) || fold_default) && has_base && !(flags & SDH_FWD_EXACT_ORDER) && !noalloc && !glu &&
+    if (((flags & SDH_FWD_MFMA_FOLD) || fold_default) && has_base && !(flags & SDH_FWD_EXACT_ORDER) && !noalloc &&
         w->w0_closed_form && w->L >= 128 && n_tokens > MAX_FUSED_TOKENS) {
         const int64_t fchunk = std::min<int64_t>(n_tokens, 2048);
         int rc = ensure_ws(w, w0_fold_ws_bytes(*w, fchunk));
@@ -590,7 +590,8 @@ static int sdh_forward_impl(sdh_weight * h, const float * x, int64_t ldx, int64_
         for (int64_t t0 = 0; t0 < n_tokens && rc == SDH_OK; t0 += fchunk) {
             const int64_t tc = std::min<int64_t>(fchunk, n_tokens - t0);
             rc = launch_w0_fold(*w, dx + t0 * dldx, dldx, tc, w->ws, dy + t0 * dldy, dldy, w->nf_ring + slot,
-                                (flags & SDH_FWD_ZERO_NONFINITE) != 0, s);
+                                (flags & SDH_FWD_ZERO_NONFINITE) != 0, s,
+                                glu ? glu->gate + t0 * glu->ldg : nullptr, glu ? glu->ldg : 0, glu ? glu->act : 0, glu ? glu->tab : nullptr);
         }
         if (rc < 0) return rc;
         if (rc == SDH_OK) {
@@ -788,8 +789,9 @@ static int ffn_gate_up(sdh_weight * hg, sdh_weight * hu, int act, const float * 
     // few tokens: the base terms of both tensors from ONE launch (2B blocks per token) into the tensors' workspaces
     const size_t per_tok = (size_t) g->B * (size_t) g->L * 4;
     const auto with_base = [](const DeviceWeight * w) { return w->kind == SDH_OP_BASE_COO || w->kind == SDH_OP_BASE_BLOCK; };
+    // (SDH_FWD_MFMA_FOLD: both nodes as folded contractions instead, the activation in the up node's epilogue)
     if (T > MAX_FUSED_TOKENS && T <= 1024 && g != u && with_base(g) && with_base(u) && g->tall && u->tall &&
-        !(flags & (SDH_FWD_EXACT_ORDER | SDH_FWD_W0_MFMA)) && per_tok * (size_t) T <= ((size_t) 64 << 20)) {
+        !(flags & (SDH_FWD_EXACT_ORDER | SDH_FWD_W0_MFMA | SDH_FWD_MFMA_FOLD)) && per_tok * (size_t) T <= ((size_t) 64 << 20)) {
         if ((rc = ensure_ws(g, per_tok * (size_t) T)) != SDH_OK) return rc;
         if ((rc = ensure_ws(u, per_tok * (size_t) T)) != SDH_OK) return rc;
         rc = launch_base_apply_pair(*g, *u, dx, dldx, T, g->ws, u->ws, s);

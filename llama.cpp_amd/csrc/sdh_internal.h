@@ -177,8 +177,10 @@ int launch_w0_x16(const float * x, int64_t ldx, int64_t T, int n_in, _Float16 * 
 // Prefill as one dense contraction: residual entries added to the W0 tile in LDS (sdh_w0fold.hip). ws: w0_fold_ws_bytes.
 // Returns SDH_OK if launched (y complete: row scale applied, non-finite outputs counted), 1 if the payload does not fit.
 size_t w0_fold_ws_bytes(const DeviceWeight & w, int64_t T);
+// glu_gate: as ffn_up inside a gated FFN the stored value is act(gate) * value (tall tensors, permuted kernel; else 1)
 int  launch_w0_fold(DeviceWeight & w, const float * x, int64_t ldx, int64_t T, void * ws, float * y, int64_t ldy,
-                    int * nf_counter, bool zero_nf, hipStream_t s);
+                    int * nf_counter, bool zero_nf, hipStream_t s,
+                    const float * glu_gate = nullptr, int64_t glu_ldg = 0, int glu_act = 0, const uint16_t * glu_tab = nullptr);
 void fold_free(DeviceWeight & w);
 
 // Prefill: token-tiled SpMM (sdh_spmm.hip). Returns SDH_OK if launched, 1 if the shape does not fit.

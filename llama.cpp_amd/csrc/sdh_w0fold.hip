@@ -38,6 +38,7 @@
 //   wide       K is split by base block over blockIdx.z (as the tiled W0 kernel); partial products go to [T][B][L]
 //              and fold_reduce_kernel sums them in block order, applies row_scale and the non-finite census.
 #include "sdh_internal.h"
+#include "sdh_delta_dev.h"
 #include <type_traits>
 
 namespace sdh {
@@ -631,7 +632,9 @@ template <bool TALL, bool ATOMIC /* the payload repeats a (row, input) pair */, 
 __global__ __launch_bounds__(512)
 void w0p_mfma_kernel(const _Float16 * __restrict__ z16, int64_t zcopy, int64_t T, int n_out, int L, int kz /* columns of one z image */,
                      const _Float16 * __restrict__ gp, const unsigned * __restrict__ ent, const int2 * __restrict__ off, int n_g, int spb,
-                     const float * __restrict__ rs, float * __restrict__ out, int64_t ldo, int * __restrict__ nf_counter, int zero_nf) {
+                     const float * __restrict__ rs, float * __restrict__ out, int64_t ldo, int * __restrict__ nf_counter, int zero_nf,
+                     const float * __restrict__ glu_gate /* tall only: out = act(gate) * value (ffn_up inside a gated FFN) */, int64_t glu_ldg,
+                     int glu_act, const uint16_t * __restrict__ glu_tab) {
     extern __shared__ __align__(16) unsigned char fd_smem[];
     _Float16 * Ws = (_Float16 *) fd_smem;                         // [3][FD_R][FP_LD]
     _Float16 * Gs = Ws + 3 * FD_R * FP_LD;                        // [2][16 groups][8 copies][8]
@@ -839,6 +842,7 @@ void w0p_mfma_kernel(const _Float16 * __restrict__ z16, int64_t zcopy, int64_t T
                 if (TALL) {
                     if (sc != 1.0f) v *= sc;                                           // :645
                     if (!__builtin_isfinite(v)) { ++bad; if (zero_nf) v = 0.0f; }
+                    if (glu_gate) v = glu_value(glu_act, glu_gate[t * glu_ldg + orow], v, glu_tab);   // after the node's guard, as store_output
                 }
                 out[t * ldo + col_off + orow] = v;
             }
@@ -882,8 +886,10 @@ size_t w0_fold_ws_bytes(const DeviceWeight & w, int64_t T) {
 // The whole op for T tokens: x16 pre-pass, the folded contraction, (wide) the block-order reduction. ws: w0_fold_ws_bytes.
 // Returns 1 when the payload does not fit the scheme (no closed-form W0, L < 128).
 int launch_w0_fold(DeviceWeight & w, const float * x, int64_t ldx, int64_t T, void * ws, float * y, int64_t ldy,
-                   int * nf_counter, bool zero_nf, hipStream_t s) {
+                   int * nf_counter, bool zero_nf, hipStream_t s,
+                   const float * glu_gate, int64_t glu_ldg, int glu_act, const uint16_t * glu_tab) {
     if (!w.w0_closed_form || w.L < FD_R || (w.L % FD_R) != 0) return 1;
+    if (glu_gate && !(w.tall && (w.fold_ent ? w.fold_perm : fold_perm_ok(w)))) return 1;      // the activation epilogue: permuted kernel, tall tensors
     if (T <= 0) return SDH_OK;
     int rc = fold_ensure(w, s);
     if (rc != SDH_OK) return rc;
@@ -926,7 +932,7 @@ int launch_w0_fold(DeviceWeight & w, const float * x, int64_t ldx, int64_t T, vo
 #define SDH_FD_ARGS x16, ld16, T, (int) w.n_in, (int) w.n_out, (int) w.L, w.d1, w.d3, w.G, w.inv, w.fold_ent, w.fold_off, w.fold_ng, \
         w.fold_spb, w.rs, out, ldo, nf_counter, zero_nf ? 1 : 0
 #define SDH_FP_ARGS x16, zcopy, T, (int) w.n_out, (int) w.L, (int) ld16, w.fold_gp, w.fold_ent, w.fold_off, w.fold_ng, \
-        w.fold_spb, w.rs, out, ldo, nf_counter, zero_nf ? 1 : 0
+        w.fold_spb, w.rs, out, ldo, nf_counter, zero_nf ? 1 : 0, glu_gate, glu_ldg, glu_act, glu_tab
 #define SDH_FD_LAUNCH(TALL_, SC_, AT_) do { if (w.fold_over) hipLaunchKernelGGL((w0d_mfma_kernel<TALL_, SC_, AT_, true>), grid, dim3(512), lds, s, SDH_FD_ARGS); \
         else hipLaunchKernelGGL((w0d_mfma_kernel<TALL_, SC_, AT_, false>), grid, dim3(512), lds, s, SDH_FD_ARGS); } while (0)
 #define SDH_FD_LAUNCH2(TALL_, SC_) do { if (w.fold_dup) SDH_FD_LAUNCH(TALL_, SC_, true); else SDH_FD_LAUNCH(TALL_, SC_, false); } while (0)

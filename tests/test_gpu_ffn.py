@@ -95,6 +95,50 @@ def test_ffn_fast_path_vs_reference_graph(hip, name):
     assert wg.nonfinite_count() == 0 and wu.nonfinite_count() == 0 and wd.nonfinite_count() == 0
 
 
+def fold_node_tol(p, x):
+    """per (token, output) bound of a node evaluated as a folded f16 contraction (SDH_FWD_MFMA_FOLD): the f16 roundings of x,
+    of W0 and of W0 + D against the dense |W|.|x| (2e-3: the 1.5e-3 of tests/test_gpu_prefill_full.py's fold_bound with
+    room for |W0 + D| < |W0| + |D| where they overlap), plus the fast path's ordering tolerance"""
+    return 2.0e-3 * (np.abs(x.astype(np.float64)) @ dense_abs(p).T) + 75.0 * fast_tolerance(p, x, None)
+
+
+@pytest.mark.parametrize("act", [O.ACT_SILU, O.ACT_GELU])
+@pytest.mark.parametrize("scheme,K,block", [("coo", 32, 16), ("block", 64, 16)])
+def test_ffn_folded_prefill(hip, act, scheme, K, block):
+    """sdh_ffn_gate_up / sdh_ffn_forward with SDH_FWD_MFMA_FOLD and many tokens: gate, up and down each as ONE folded
+    contraction in the permuted order, the activation in the up node's epilogue (act(gate) * up written by the GEMM)."""
+    n_embd, n_ff, T = 1024, 2816, 200
+    kw = dict(scheme=scheme, K=K, block=block, base=True)
+    gate, up, down = (make_payload(n_embd, n_ff, seed=31, **kw), make_payload(n_embd, n_ff, seed=32, **kw),
+                      make_payload(n_ff, n_embd, seed=33, **kw))
+    x = make_x(n_embd, T, seed=5)
+    wg, wu, wd = hip.SeedDeltaWeight(gate), hip.SeedDeltaWeight(up), hip.SeedDeltaWeight(down)
+    g = O.forward(gate, x).astype(np.float64)
+    u = O.forward(up, x).astype(np.float64)
+    tg, tu = fold_node_tol(gate, x), fold_node_tol(up, x)
+    h_ref32 = O.glu(act, g.astype(np.float32), u.astype(np.float32))
+    h_ref = h_ref32.astype(np.float64)
+    a = np.divide(h_ref, u, out=np.zeros_like(h_ref), where=u != 0)
+    hb = 1.13 * tg * np.abs(u) + np.abs(a) * tu + 1e-6 * np.abs(h_ref) + 1e-30
+    if act == O.ACT_GELU:
+        hb = hb + (1.13 * np.abs(g) * F16_ULP + np.abs(a) * F16_ULP) * np.abs(u)
+    h = hip.ffn_gate_up_host(wg, wu, x, act, hip.FWD_MFMA_FOLD)
+    err = np.abs(h.astype(np.float64) - h_ref)
+    assert np.all(err <= hb), f"h: max err/bound {np.max(err / hb):.3g}"
+    assert wg.fold_layout() & 2 and wu.fold_layout() & 2       # both nodes ran as permuted-order contractions
+    y = hip.ffn_forward_host(wg, wu, wd, x, act, hip.FWD_MFMA_FOLD)
+    y_ref = O.forward(down, h_ref32).astype(np.float64)
+    bound = fold_node_tol(down, h_ref32) + (dense_abs(down) @ hb.T).T
+    erry = np.abs(y.astype(np.float64) - y_ref)
+    assert np.all(erry <= bound), f"y: max err/bound {np.max(erry / bound):.3g}"
+    assert wd.fold_layout() & 2
+    assert np.max(erry / bound) > 1e-4                          # not the exact forms
+    y0 = hip.ffn_forward_host(wg, wu, wd, x, act)               # the default path is another one, and close
+    assert not np.array_equal(bits(y), bits(y0))
+    assert np.abs(y - y0).max() <= 2e-2 * np.abs(y0).max()
+    assert wg.nonfinite_count() == 0 and wu.nonfinite_count() == 0 and wd.nonfinite_count() == 0
+
+
 @pytest.mark.parametrize("act", [O.ACT_SILU, O.ACT_GELU])
 @pytest.mark.parametrize("scheme,K,block", [("coo", 32, 16), ("coo", 128, 16), ("block", 64, 16), ("block", 128, 32)])
 @pytest.mark.parametrize("dims", [(1024, 2816), (2048, 5632), (1152, 6912)])
