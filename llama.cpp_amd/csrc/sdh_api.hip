@@ -500,6 +500,26 @@ static int nf_slot(DeviceWeight * w, hipStream_t s, int * slot_out) {
 
 struct GluEpilogue { const float * gate; int64_t ldg; int act; const uint16_t * tab; };
 
+// From how many tokens on sdh_forward takes the folded f16 contraction (sdh_w0fold.hip) by itself — the measured crossovers
+// against the fastest fp32 form of each payload class on Mistral-7B tensors (tools/gpu/r03_fold_T.sh, us per call, fold /
+// others: gate COO K=128 73 / 79 at T=192; gate block16 74 / 82 at 256; down COO 74 / 80 at 192; down block16 91 / 92 at
+// 384; block 32 with K=1536 71 / 85 at 96). The folded call costs one round of workgroups (~70 us) up to 256 tokens.
+// INT64_MAX: never by default (no closed-form base; the q-order kernel only pays for long rows).
+static int64_t fold_min_tokens(const DeviceWeight * w) {
+    const bool has_base = w->kind == SDH_OP_BASE_COO || w->kind == SDH_OP_BASE_BLOCK;
+    if (!has_base || !w->w0_closed_form || w->L < 128 || (w->L % 128) != 0) return INT64_MAX;
+    const bool block = w->kind == SDH_OP_BASE_BLOCK;
+    const int64_t row_entries = block ? w->nb * w->block : w->K;
+    const bool perm = w0_fold_permuted(*w);
+    if (row_entries >= 512) return perm ? 96 : 160;
+    if (!perm) return INT64_MAX;
+    return block ? (w->tall ? 256 : 400) : 192;
+}
+// ... and the gated FFN block (three tensors, activation in the up node's epilogue): 222 / 217 us per Mistral layer at T=256,
+// 255 / 331 at 384 (tools/ffn_tokens.py)
+constexpr int64_t FFN_FOLD_MIN_TOKENS = 320;
+constexpr int FOLD_EXCLUDES = SDH_FWD_NO_MFMA | SDH_FWD_W0_MFMA | SDH_FWD_NO_SPMM | SDH_FWD_EXACT_ORDER;
+
 static int sdh_forward_impl(sdh_weight * h, const float * x, int64_t ldx, int64_t n_tokens,
                 float * y, int64_t ldy, int flags, void * stream,
                 float * ext_ws = nullptr, size_t ext_ws_bytes = 0, const GluEpilogue * glu = nullptr) {
@@ -571,11 +591,9 @@ static int sdh_forward_impl(sdh_weight * h, const float * x, int64_t ldx, int64_
     LibState & ls = lib();
     // Many tokens, one dense contraction per tensor: the residual folded into the W0 tile in LDS (SDH_FWD_MFMA_FOLD;
     // f16 operands, fp32 accumulation). The call is complete after it: row scale, non-finite census, everything.
-    // Taken on request, and by default where it wins by a wide margin: rows with 512 entries and more (config 3: block 32,
-    // K = 1536) from 160 tokens on — 0.15 ms per ubatch of 512 against 0.32 ms for the LDS rows kernel (T=128: 0.12 / 0.10,
-    // T=192: 0.13 / 0.15). SDH_FWD_NO_MFMA keeps the fp32 forms.
-    const int64_t row_entries = (w->kind == SDH_OP_BASE_BLOCK) ? w->nb * w->block : w->K;
-    const bool fold_default = row_entries >= 512 && n_tokens >= 160 && !(flags & (SDH_FWD_NO_MFMA | SDH_FWD_W0_MFMA | SDH_FWD_NO_SPMM | SDH_FWD_INTERNAL_ROWS));
+    // Taken on request, and by default from the payload class's crossover on (fold_min_tokens). SDH_FWD_NO_MFMA keeps the
+    // fp32 forms (bit-exact SpMM / rows kernels), as do SDH_FWD_NO_SPMM and SDH_FWD_EXACT_ORDER.
+    const bool fold_default = n_tokens >= fold_min_tokens(w) && !(flags & (FOLD_EXCLUDES | SDH_FWD_INTERNAL_ROWS));
     if (((flags & SDH_FWD_MFMA_FOLD) || fold_default) && has_base && !(flags & SDH_FWD_EXACT_ORDER) && !noalloc &&
         w->w0_closed_form && w->L >= 128 && n_tokens > MAX_FUSED_TOKENS) {
         const int64_t fchunk = std::min<int64_t>(n_tokens, 2048);
@@ -754,6 +772,14 @@ static int ffn_check(sdh_weight * hg, sdh_weight * hu, int act, const void * x, 
     return SDH_OK;
 }
 
+// From FFN_FOLD_MIN_TOKENS on the block runs as folded contractions by itself, if every tensor has the permuted form (gate and
+// up tall: the activation epilogue) and no flag asks for the fp32 forms
+static bool ffn_fold_default(const DeviceWeight * g, const DeviceWeight * u, const DeviceWeight * d, int64_t T, int flags) {
+    if (T < FFN_FOLD_MIN_TOKENS || (flags & (FOLD_EXCLUDES | SDH_FWD_NO_FUSE))) return false;
+    auto ok = [](const DeviceWeight * w) { return fold_min_tokens(w) != INT64_MAX && w0_fold_permuted(*w); };
+    return ok(g) && ok(u) && g->tall && u->tall && (!d || ok(d));
+}
+
 // h[t] = act(gate(x[t])) * up(x[t]) on device buffers; gbuf / ubuf: [T][n_ff] scratch for the node-by-node path
 static int ffn_gate_up(sdh_weight * hg, sdh_weight * hu, int act, const float * dx, int64_t dldx, int64_t T,
                        float * hbuf, float * gbuf, float * ubuf, int flags, hipStream_t s, float * h4buf = nullptr) {
@@ -852,7 +878,8 @@ static int sdh_ffn_gate_up_impl(sdh_weight * hg, sdh_weight * hu, int act, const
         dx = ws[0]; dldx = n_embd;
     }
     float * hbuf = dense_h ? h : ws[1];
-    const int sub = (flags & ~SDH_FWD_HOST_IO) | (n_tokens > MAX_FUSED_TOKENS ? SDH_FWD_INTERNAL_ROWS : 0);
+    int sub = (flags & ~SDH_FWD_HOST_IO) | (n_tokens > MAX_FUSED_TOKENS ? SDH_FWD_INTERNAL_ROWS : 0);
+    if (ffn_fold_default(g, reinterpret_cast<DeviceWeight *>(hu), nullptr, n_tokens, flags)) sub |= SDH_FWD_MFMA_FOLD;
     if ((rc = ffn_gate_up(hg, hu, act, dx, dldx, n_tokens, hbuf, ws[2], ws[3], sub, s)) != SDH_OK) return rc;
     if (host_io) return device_to_host_sync(ls, h, ldh, hbuf, n_ff, n_tokens, s);
     if (!dense_h) {
@@ -891,7 +918,8 @@ static int sdh_ffn_forward_impl(sdh_weight * hg, sdh_weight * hu, sdh_weight * h
         if ((rc = host_to_device(ls, ws[0], x, ldx, n_embd, n_tokens, s)) != SDH_OK) return rc;
         dx = ws[0]; dldx = n_embd; dy = ws[1]; dldy = d->n_out;
     }
-    const int sub = (flags & ~SDH_FWD_HOST_IO) | (n_tokens > MAX_FUSED_TOKENS ? SDH_FWD_INTERNAL_ROWS : 0);
+    int sub = (flags & ~SDH_FWD_HOST_IO) | (n_tokens > MAX_FUSED_TOKENS ? SDH_FWD_INTERNAL_ROWS : 0);
+    if (ffn_fold_default(g, reinterpret_cast<DeviceWeight *>(hu), d, n_tokens, flags)) sub |= SDH_FWD_MFMA_FOLD;
     // 5 tokens and more: node by node, the residual through the LDS rows kernels (SDH_FWD_INTERNAL_ROWS: COO payloads at
     // every token count, block payloads up to 32 tokens) and, up to 64 tokens, the base terms of gate and up from one
     // launch. Mistral layer, us, COO / block16: T=8 31 / 30 (56 / 58 through the tiled SpMM path, 49 / 37 as two groups of

@@ -182,6 +182,7 @@ int  launch_w0_fold(DeviceWeight & w, const float * x, int64_t ldx, int64_t T, v
                     int * nf_counter, bool zero_nf, hipStream_t s,
                     const float * glu_gate = nullptr, int64_t glu_ldg = 0, int glu_act = 0, const uint16_t * glu_tab = nullptr);
 void fold_free(DeviceWeight & w);
+bool w0_fold_permuted(const DeviceWeight & w);   // the handle's folded contraction runs (or would run) in the permuted order
 
 // Prefill: token-tiled SpMM (sdh_spmm.hip). Returns SDH_OK if launched, 1 if the shape does not fit.
 int launch_delta_spmm(const DeviceWeight & w, const DeltaLaunch & a, hipStream_t s);

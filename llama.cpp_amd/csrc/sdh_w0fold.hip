@@ -184,9 +184,15 @@ void fold_gp_kernel(const float * __restrict__ G, _Float16 * __restrict__ gp, in
 // needs for a slab are 4 KB. One workgroup of 16 waves per four tokens and half of the columns: the rows of x go to LDS once (f16), every
 // base block gathers from there; the permutation is read as 16-bit indices (fold_p16, -1 = no input), once per four tokens.
 //   tall: one image per base block (z + b * zcopy) of kz = L columns;   wide: one image of kz = B * L columns
-constexpr int FZ_T = 4;
+#ifndef SDH_FZ_T
+#define SDH_FZ_T 4
+#endif
+#ifndef SDH_FZ_NTH
+#define SDH_FZ_NTH 1024
+#endif
+constexpr int FZ_T = SDH_FZ_T, FZ_NTH = SDH_FZ_NTH;
 template <bool TALL>
-__global__ __launch_bounds__(1024)
+__global__ __launch_bounds__(FZ_NTH)
 void fold_z16_kernel(const float * __restrict__ x, int64_t ldx, int64_t T, int n_in, int L, int B, const short * __restrict__ p16,
                      _Float16 * __restrict__ z, int kz, int64_t zcopy) {
     extern __shared__ __align__(16) unsigned char fz_smem[];
@@ -205,20 +211,20 @@ void fold_z16_kernel(const float * __restrict__ x, int64_t ldx, int64_t T, int n
         const float * xt = x + (t0 + u) * ldx;
         _Float16 * xu = xr + (size_t) u * n_in;
         if (vec) {
-            for (int k = 4 * threadIdx.x; k < n_in; k += 4096) {
+            for (int k = 4 * threadIdx.x; k < n_in; k += 4 * FZ_NTH) {
                 const float4 v = *reinterpret_cast<const float4 *>(xt + k);
                 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
                 *reinterpret_cast<half4 *>(xu + k) = half4{(_Float16) v.x, (_Float16) v.y, (_Float16) v.z, (_Float16) v.w};
             }
         } else {
-            for (int k = threadIdx.x; k < n_in; k += 1024) xu[k] = (_Float16) xt[k];
+            for (int k = threadIdx.x; k < n_in; k += FZ_NTH) xu[k] = (_Float16) xt[k];
         }
     }
     __syncthreads();
-    for (int g = g_first; g < g_end; g += 1024) {
+    for (int g = g_first; g < g_end; g += FZ_NTH) {
         const int b = g / gpb, j0 = (g - b * gpb) * 8;
         const short8 q = q_next;
-        q_next = *reinterpret_cast<const short8 *>(p16 + (size_t) min(g + 1024, total - 1) * 8);
+        q_next = *reinterpret_cast<const short8 *>(p16 + (size_t) min(g + FZ_NTH, total - 1) * 8);
         const int jj = TALL ? j0 : b * L + j0;                     // column in the image
         _Float16 * zo = z + (TALL ? (int64_t) b * zcopy : (int64_t) 0) + ((t0 >> 5) * (int64_t) (kz >> 5) + (jj >> 5)) * 1024 + (t0 & 31) * 32 + (jj & 31);
 #pragma unroll
@@ -251,6 +257,8 @@ static bool fold_perm_ok(const DeviceWeight & w) {
     static const bool off = getenv("SDH_FOLD_NO_PERM") != nullptr;               // A/B switch
     return !off && !fold_scaled(w) && kz * 3 <= w.n_in * 4 && w.n_in <= 20480;     // 16-bit input indices; four f16 rows of x in the pre-pass's LDS
 }
+
+bool w0_fold_permuted(const DeviceWeight & w) { return w.fold_ent ? w.fold_perm : fold_perm_ok(w); }
 
 int fold_ensure(DeviceWeight & w, hipStream_t s) {
     if (w.fold_ent) return SDH_OK;
@@ -920,8 +928,8 @@ int launch_w0_fold(DeviceWeight & w, const float * x, int64_t ldx, int64_t T, vo
     if (perm) {
         const size_t zl = ((size_t) w.n_in * 2 * FZ_T + 15) & ~(size_t) 15;
         const dim3 zg((unsigned) (T_pad / FZ_T), 2);
-        if (w.tall) hipLaunchKernelGGL(fold_z16_kernel<true>, zg, dim3(1024), zl, s, x, ldx, T, (int) w.n_in, (int) w.L, (int) w.B, w.fold_p16, x16, (int) ld16, zcopy);
-        else        hipLaunchKernelGGL(fold_z16_kernel<false>, zg, dim3(1024), zl, s, x, ldx, T, (int) w.n_in, (int) w.L, (int) w.B, w.fold_p16, x16, (int) ld16, zcopy);
+        if (w.tall) hipLaunchKernelGGL(fold_z16_kernel<true>, zg, dim3(FZ_NTH), zl, s, x, ldx, T, (int) w.n_in, (int) w.L, (int) w.B, w.fold_p16, x16, (int) ld16, zcopy);
+        else        hipLaunchKernelGGL(fold_z16_kernel<false>, zg, dim3(FZ_NTH), zl, s, x, ldx, T, (int) w.n_in, (int) w.L, (int) w.B, w.fold_p16, x16, (int) ld16, zcopy);
         SDH_HIP_CHECK(hipGetLastError());
     } else if ((rc = launch_w0_x16(x, ldx, T, (int) w.n_in, x16, ld16, T_pad, s)) != SDH_OK) return rc;
     const dim3 grid((unsigned) ((w.n_out + FD_R - 1) / FD_R), (unsigned) (T_pad / FD_N), (unsigned) (w.tall ? 1 : w.B));

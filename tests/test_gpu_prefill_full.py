@@ -54,14 +54,21 @@ def test_prefill_T512_default_path(hip, cfg):
     w = hip.SeedDeltaWeight(p)
     y = w.forward_host(x)
     assert w.nonfinite_count() == 0
-    if SPMM_EXACT[cfg]:
-        assert np.array_equal(bits(y), bits(y_ref)), f"{cfg}: max abs diff {np.abs(y - y_ref).max()}"
-    else:
-        # rows of 512 entries and more: sdh_forward chooses the folded MFMA contraction from 160 tokens on (f16 bound,
-        # test_prefill_T512_mfma_fold); SDH_FWD_NO_MFMA keeps the fp32 row kernels, checked here
+    # 512 tokens are above every Mistral payload class's crossover (fold_min_tokens, csrc/sdh_api.hip): sdh_forward takes the
+    # folded f16 contraction by itself (its bound: test_prefill_T512_mfma_fold); SDH_FWD_NO_MFMA keeps the fp32 forms,
+    # checked here: the tiled SpMM bit for bit, the LDS rows kernel (rows of 512 entries and more) within the fast bound
+    # (a Gemma gate, 2560 inputs in blocks of 4096, has no permuted form — its blocks are 1.6 x its inputs — and stays exact)
+    folded = bool(w.fold_layout() & 2)
+    assert folded == cfg.startswith(("cfg4_mistral", "cfg3_mistral")), (cfg, w.fold_layout())
+    if folded:
         assert np.array_equal(bits(y), bits(w.forward_host(x, hip.FWD_MFMA_FOLD)))
         y = w.forward_host(x, hip.FWD_NO_MFMA)
         assert not np.array_equal(bits(y), bits(w.forward_host(x, hip.FWD_MFMA_FOLD)))
+    if SPMM_EXACT[cfg]:
+        assert np.array_equal(bits(y), bits(y_ref)), f"{cfg}: max abs diff {np.abs(y - y_ref).max()}"
+        # below the crossover the default IS the exact form
+        assert np.array_equal(bits(w.forward_host(x[:64])), bits(y_ref[:64]))
+    else:
         assert np.abs(y - y_ref).max() <= 1e-4 * np.abs(y_ref).max()          # every element, coarse
         sel = token_sample()
         check_fast(p, x[sel], y[sel], y_ref[sel])                             # sampled tokens, the stated bound
@@ -77,10 +84,11 @@ def test_prefill_T512_tt4_tile(hip):
     """COO with 4864 < n_in <= 9728 takes the TT=4 tile (a Gemma-3 1B ffn_down as a COO payload)."""
     p, x, y_ref = case("coo_tt4_6912x1152")
     w = hip.SeedDeltaWeight(p)
-    assert np.array_equal(bits(w.forward_host(x)), bits(y_ref))
+    assert np.array_equal(bits(w.forward_host(x, hip.FWD_NO_MFMA)), bits(y_ref))   # (the default at 512 tokens is the folded form)
     # ragged: a last tile with 1, 2, 3 tokens
     for t in (509, 510, 511):
-        assert np.array_equal(bits(w.forward_host(x[:t])), bits(y_ref[:t])), t
+        assert np.array_equal(bits(w.forward_host(x[:t], hip.FWD_NO_MFMA)), bits(y_ref[:t])), t
+    assert np.array_equal(bits(w.forward_host(x[:150])), bits(y_ref[:150]))         # below the crossover: exact by default
     w.close()
 
 

@@ -40,7 +40,7 @@ def test_noalloc_matches_forward_two_calls_in_a_row(hip, cfg):
     # second call: smaller (3 tokens), on the scratch the first call left behind
     cases = [(700, 1), (3, 2), (1, 3), (130, 4)]
     xs = [make_x(p.n_in, T, seed=seed) for T, seed in cases]
-    wants = [(ref.forward_host(x, hip.FWD_NO_FUSE), ref.forward_host(x)) for x in xs]
+    wants = [(ref.forward_host(x, hip.FWD_NO_FUSE | hip.FWD_NO_MFMA), ref.forward_host(x, hip.FWD_NO_MFMA)) for x in xs]   # the fp32 forms: the no-alloc call never folds
     xd = [torch.from_numpy(x).cuda() for x in xs]
     yd = [torch.full((x.shape[0], w.n_out), float("nan"), dtype=torch.float32, device="cuda") for x in xs]
     torch.cuda.synchronize()
@@ -58,7 +58,7 @@ def test_noalloc_matches_forward_two_calls_in_a_row(hip, cfg):
     assert w.nonfinite_count() == 0
     # control: the same 700-token call through sdh_forward on the same (workspace-free) handle DOES allocate, and
     # both detectors see it — so the zero above is a measurement, not a blind spot
-    rc = w.forward_device(xd[0].data_ptr(), w.n_in, 700, yd[0].data_ptr(), w.n_out, hip.FWD_NO_FUSE, 0)
+    rc = w.forward_device(xd[0].data_ptr(), w.n_in, 700, yd[0].data_ptr(), w.n_out, hip.FWD_NO_FUSE | hip.FWD_NO_MFMA, 0)
     torch.cuda.synchronize()
     assert lib.sdh_debug_alloc_calls() > calls0
     grown = 700 * p.base_d1.shape[0] * p.base_d1.shape[1] * 4           # v[T][B][L] f32: 44.8 MiB at Mistral dims
