@@ -120,10 +120,15 @@ typedef enum sdh_op_kind {
                                       results within 2e-3 * sum|terms| of the CPU op (tests state it), not bit-identical
                                       to it. The first call on a handle re-lays the residual out by (row tile, k-slab)
                                       on the device (once; it doubles the payload's footprint in HBM). Without any
-                                      flag sdh_forward takes this form by itself where it wins by a wide margin: rows
-                                      of 512 entries and more from 160 tokens on (Mistral down, block 32, K = 1536:
-                                      0.15 against 0.32 ms per ubatch of 512).                                   */
-#define SDH_FWD_NO_MFMA      0x80  /* never choose SDH_FWD_MFMA_FOLD by default: keep the fp32 forms            */
+                                      flag sdh_forward takes this form by itself from the measured crossover of the
+                                      payload's class on (payloads as the builder writes them, d1 = d3 = 1, blocks at
+                                      most a third longer than their inputs): COO from 192 tokens, block payloads from
+                                      256 (tall) / 400 (wide), rows of 512 entries and more from 96; sdh_ffn_gate_up /
+                                      sdh_ffn_forward from 320 tokens (Mistral-7B tensors at 512 tokens: 0.074-0.086 ms
+                                      against 0.13-0.36 ms for the fp32 forms). Fewer tokens: the fp32 forms.        */
+#define SDH_FWD_NO_MFMA      0x80  /* never choose SDH_FWD_MFMA_FOLD by default: keep the fp32 forms (the tiled SpMM,
+                                      bit-identical to the CPU op, or the rows kernels) at every token count; so do
+                                      SDH_FWD_NO_SPMM and SDH_FWD_EXACT_ORDER                                    */
 
 /* ---- library / device ----------------------------------------------------------------
  * sdh_init: bind the calling process to HIP device `device` and create the library's
