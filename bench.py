@@ -352,8 +352,9 @@ def run_ffn(args, dev):
         ev_t, _ = timed_on_stream(block_t, max(4, reps // 8), st, seeddelta)
         by_tokens[str(T)] = ev_t * 1e3 / (max(4, reps // 8) * NL)
         del xT, yT
-    # one ubatch of prefill through the same layers: the default node forms, and every node as a folded f16 contraction
-    # (SDH_FWD_MFMA_FOLD: gate, up with the activation in its epilogue, down)
+    # one ubatch of prefill through the same layers: the fp32 node forms (SDH_FWD_NO_MFMA), what sdh_ffn_forward chooses by itself
+    # (from 320 tokens on: every node as a folded f16 contraction), and that form on request (SDH_FWD_MFMA_FOLD: gate, up with
+    # the activation in its epilogue, down)
     prefill_layer = {}
     if not args.no_prefill:
         T = 512
@@ -361,11 +362,11 @@ def run_ffn(args, dev):
         yT = torch.empty((T, n_embd), dtype=torch.float32, device=dev)
         torch.cuda.synchronize()
         use = layers[:min(NL, 4)]
-        for name, fl in (("default", 0), ("mfma_fold", seeddelta.FWD_MFMA_FOLD)):
+        for name, fl in (("fp32", seeddelta.FWD_NO_MFMA), ("default", 0), ("mfma_fold", seeddelta.FWD_MFMA_FOLD)):
             def block_p():
                 for wg, wu, wd in use:
                     seeddelta.ffn_forward_device(wg, wu, wd, seeddelta.ACT_SILU, xT.data_ptr(), n_embd, T, yT.data_ptr(), n_embd, fl, sp)
-            ev_p, _ = timed_on_stream(block_p, 6, st, seeddelta, warm=2)
+            ev_p, _ = timed_on_stream(block_p, 6, st, seeddelta, warm=4)
             prefill_layer[name] = ev_p / (6 * len(use))
         prefill_layer = {"tokens": T, "ms_per_layer": prefill_layer,
                          "tokens_per_s_fold": T / prefill_layer["mfma_fold"] * 1e3,
@@ -509,7 +510,7 @@ def run_prefill(args, dev):
         for tag, flags in (("default", 0), ("fp32", seeddelta.FWD_NO_MFMA), ("w0_mfma", seeddelta.FWD_W0_MFMA),
                            ("rows_lds", seeddelta.FWD_NO_SPMM), ("mfma_fold", seeddelta.FWD_MFMA_FOLD)):
             fn = lambda: w.forward_device(x.data_ptr(), n_in, T, y.data_ptr(), n_out, flags=flags, stream=sp)   # noqa: E731
-            ev_ms, host_ms = timed_on_stream(fn, args.prefill_reps, st, seeddelta, warm=3)
+            ev_ms, host_ms = timed_on_stream(fn, args.prefill_reps, st, seeddelta, warm=10)      # (the first variant after an upload also warms the clocks)
             ms = ev_ms / args.prefill_reps
             d = {"ms": ms, "ms_host_clock": host_ms / args.prefill_reps, "tok_per_s": T / ms * 1e3,
                  "hbm": {"achieved": alg / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / ms / 1e6 / HBM_PEAK_GBS},
@@ -815,6 +816,7 @@ def main():
             if ffn.get("prefill_layer"):
                 pl = ffn["prefill_layer"]
                 line["ffn_block"]["prefill_layer"] = {"tokens": pl["tokens"], "ms": r3(pl["ms_per_layer"]["default"]),
+                                                      "fp32_ms": r3(pl["ms_per_layer"]["fp32"]),
                                                       "fold_ms": r3(pl["ms_per_layer"]["mfma_fold"]),
                                                       "fold_tok_s": r3(pl["tokens_per_s_fold"]), "fold_mfma_frac": r3(pl["mfma_frac_fold"])}
         if stack is not None:
