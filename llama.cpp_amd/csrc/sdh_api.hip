@@ -500,10 +500,11 @@ static int nf_slot(DeviceWeight * w, hipStream_t s, int * slot_out) {
 
 struct GluEpilogue { const float * gate; int64_t ldg; int act; const uint16_t * tab; };
 
-// From how many tokens on sdh_forward takes the folded f16 contraction (sdh_w0fold.hip) by itself — the measured crossovers
-// against the fastest fp32 form of each payload class on Mistral-7B tensors (tools/gpu/r03_fold_T.sh, us per call, fold /
-// others: gate COO K=128 73 / 79 at T=192; gate block16 74 / 82 at 256; down COO 74 / 80 at 192; down block16 91 / 92 at
-// 384; block 32 with K=1536 71 / 85 at 96). The folded call costs one round of workgroups (~70 us) up to 256 tokens.
+// From how many tokens on sdh_forward takes the folded f16 contraction (sdh_w0fold.hip) by itself — just above the measured
+// crossovers against the fastest fp32 form of each payload class on Mistral-7B tensors (tools/gpu/r03_fold_T.sh, us per call,
+// fold / others: gate COO K=128 57.5 / 55.4 at T=128, 61 / 80 at 192; gate block16 63 / 63 at 192, 64 / 83 at 256; down COO
+// 60 / 49 at 128, 66 / 80 at 192; down block16 68 / 64 at 256, 91 / 92 at 384; block 32 with K=1536 62 / 58 at 64, 64 / 86
+// at 96). The folded call costs one round of workgroups: ~57 us up to 128 tokens, ~63 up to 256 (token tiles of 128), ~88 at 512.
 // INT64_MAX: never by default (no closed-form base; the q-order kernel only pays for long rows).
 static int64_t fold_min_tokens(const DeviceWeight * w) {
     const bool has_base = w->kind == SDH_OP_BASE_COO || w->kind == SDH_OP_BASE_BLOCK;
@@ -511,13 +512,13 @@ static int64_t fold_min_tokens(const DeviceWeight * w) {
     const bool block = w->kind == SDH_OP_BASE_BLOCK;
     const int64_t row_entries = block ? w->nb * w->block : w->K;
     const bool perm = w0_fold_permuted(*w);
-    if (row_entries >= 512) return perm ? 96 : 160;
+    if (row_entries >= 512) return perm ? 80 : 160;
     if (!perm) return INT64_MAX;
-    return block ? (w->tall ? 256 : 400) : 192;
+    return block ? (w->tall ? 224 : 320) : 160;
 }
-// ... and the gated FFN block (three tensors, activation in the up node's epilogue): 222 / 217 us per Mistral layer at T=256,
-// 255 / 331 at 384 (tools/ffn_tokens.py)
-constexpr int64_t FFN_FOLD_MIN_TOKENS = 320;
+// ... and the gated FFN block (three tensors, activation in the up node's epilogue): us per Mistral layer, fold / others:
+// COO 176 / 180 at T=192, 177 / 194 at 224; block16 177 / 173 at 192, 176 / 207 at 224 (tools/ffn_tokens.py)
+constexpr int64_t FFN_FOLD_MIN_TOKENS = 224;
 constexpr int FOLD_EXCLUDES = SDH_FWD_NO_MFMA | SDH_FWD_W0_MFMA | SDH_FWD_NO_SPMM | SDH_FWD_EXACT_ORDER;
 
 static int sdh_forward_impl(sdh_weight * h, const float * x, int64_t ldx, int64_t n_tokens,

@@ -636,7 +636,8 @@ void w0d_mfma_kernel(const _Float16 * __restrict__ x16, int64_t ld16, int64_t T,
 //             tiles nothing reads) and the prologue issues its last loads in the loop's order: a load behind a branch, or a
 //             different order on the way into the loop, makes the compiler's counted waits assume the shortest queue and
 //             drain it (vmcnt(0..2) where ten loads may stay in flight). The bucket bounds sit in LDS for the same reason.
-template <bool TALL, bool ATOMIC /* the payload repeats a (row, input) pair */, bool OVER /* some bucket holds more than 2048 entries */>
+template <bool TALL, bool ATOMIC /* the payload repeats a (row, input) pair */, bool OVER /* some bucket holds more than 2048 entries */,
+          int NT /* tokens per wave: 32 (token tile 256) or 16 (token tile 128: up to 256 tokens, twice the workgroups) */>
 __global__ __launch_bounds__(512)
 void w0p_mfma_kernel(const _Float16 * __restrict__ z16, int64_t zcopy, int64_t T, int n_out, int L, int kz /* columns of one z image */,
                      const _Float16 * __restrict__ gp, const unsigned * __restrict__ ent, const int2 * __restrict__ off, int n_g, int spb,
@@ -651,13 +652,15 @@ void w0p_mfma_kernel(const _Float16 * __restrict__ z16, int64_t zcopy, int64_t T
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, h = lane >> 4;                       // 16x16x32 operands: row (token or output row) r, columns 8 h .. 8 h + 7 of the 32
     const int o_tile = (int) blockIdx.x * FD_R;
-    const int64_t t_tile = (int64_t) blockIdx.y * FD_N;
+    constexpr int NA = NT / 16;                                   // token halves (A fragments per 32-column step) of a wave
+    const int64_t t_tile = (int64_t) blockIdx.y * (8 * NT);
     const int b = TALL ? o_tile / L : (int) blockIdx.z;
     const int p0 = TALL ? o_tile - b * L : o_tile;                // first row of the tile inside its block
     const int n_slab = spb;
     const int2 * offr = off + (size_t) blockIdx.x * n_g + (TALL ? 0 : b * spb);
     // x fragments of this wave: tokens t_tile + 32 wave .. + 32; the image is tiled [token / 32][column / 32][token half][16][32]
-    const _Float16 * zw = z16 + (TALL ? (int64_t) b * zcopy : (int64_t) 0) + ((t_tile >> 5) + wave) * ((int64_t) kz * 32)
+    const int64_t tok0 = t_tile + wave * NT;                      // this wave's first token (a multiple of 16)
+    const _Float16 * zw = z16 + (TALL ? (int64_t) b * zcopy : (int64_t) 0) + (tok0 >> 5) * ((int64_t) kz * 32) + ((tok0 >> 4) & 1) * 512
                         + (TALL ? (int64_t) 0 : (int64_t) b * L * 32) + r * 32 + h * 8;
     const char * Gb = (const char *) (gp + (size_t) 8 * b * L);
 
@@ -669,7 +672,7 @@ void w0p_mfma_kernel(const _Float16 * __restrict__ z16, int64_t zcopy, int64_t T
 
     unsigned sg = 0;            // the staged dword of the segment three slabs on
     half8 gh[2];                // the two column groups of the tile two slabs on
-    half8 xq[3][4];             // x fragments of three slabs, [set][2 * (32-column step) + token half]
+    half8 xq[3][2 * NA];        // x fragments of three slabs, [set][NA * (32-column step) + token half]
     uint4 eq[3];                // residual entries (four per thread) in flight
     int ebeg[3], eend[3];       // their bucket bounds
     int2 obe = make_int2(0, 0); // bucket bounds read a slab ahead of the entry loads that use them
@@ -677,9 +680,9 @@ void w0p_mfma_kernel(const _Float16 * __restrict__ z16, int64_t zcopy, int64_t T
     auto fetch_off = [&](int s) { obe = Bn[clamp_slab(s)]; };
     auto fetchX = [&](auto set_c, int s) {
         constexpr int S = decltype(set_c)::value;
-        const _Float16 * xs0 = zw + (size_t) clamp_slab(s) * (4 * 512);                   // 4 KB per slab and wave, contiguous
+        const _Float16 * xs0 = zw + (size_t) clamp_slab(s) * (4 * 512);                   // NT = 32: 4 KB per slab and wave, contiguous
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xq[S][i] = *reinterpret_cast<const half8 *>(xs0 + i * 512);
+        for (int i = 0; i < 2 * NA; ++i) xq[S][i] = *reinterpret_cast<const half8 *>(xs0 + (i / NA) * 1024 + (i % NA) * 512);
     };
     auto fetchE = [&](auto set_c) {
         constexpr int S = decltype(set_c)::value;
@@ -740,9 +743,9 @@ void w0p_mfma_kernel(const _Float16 * __restrict__ z16, int64_t zcopy, int64_t T
     // wave tile: all 128 rows x 32 tokens (no two waves want the same x: its fragments come straight from global memory), as
     // 2 x 8 tiles of v_mfma_f32_16x16x32_f16 (the chip holds a higher clock under this shape than under 32x32x16 at the same
     // cycles per flop). A multiply step = one 32-column half of the slab x one half of the rows: 4 W fragments, 8 MFMAs.
-    floatx4 acc[2][8];                                            // [token half][row tile of 16]
+    floatx4 acc[NA][8];                                           // [token half][row tile of 16]
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int c = 0; c < 8; ++c)
 #pragma unroll
@@ -754,13 +757,13 @@ void w0p_mfma_kernel(const _Float16 * __restrict__ z16, int64_t zcopy, int64_t T
 #pragma unroll
         for (int c = 0; c < 4; ++c) wf[q][c] = *reinterpret_cast<const half8 *>(Wb + c * 16 * FP_LD);
     };
-    auto multiply = [&](int q, int ks, const half8 & x0, const half8 & x1) {
+    auto multiply = [&](int q, int ks, const half8 * xk) {          // xk: the NA fragments of this step's 32 columns
 #ifndef SDH_FD_NOMFMA
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            acc[0][4 * (ks & 1) + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x0, wf[q][c], acc[0][4 * (ks & 1) + c], 0, 0, 0);
-            acc[1][4 * (ks & 1) + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x1, wf[q][c], acc[1][4 * (ks & 1) + c], 0, 0, 0);
-        }
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+                acc[a][4 * (ks & 1) + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xk[a], wf[q][c], acc[a][4 * (ks & 1) + c], 0, 0, 0);
 #endif
     };
 
@@ -778,7 +781,7 @@ void w0p_mfma_kernel(const _Float16 * __restrict__ z16, int64_t zcopy, int64_t T
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
             frags((ks + 1) & 1, Wcur, ks + 1);
-            multiply(ks & 1, ks, xq[A][2 * (ks >> 1)], xq[A][2 * (ks >> 1) + 1]);
+            multiply(ks & 1, ks, &xq[A][NA * (ks >> 1)]);
             // (dev ablations: -DSDH_FP_NOSC / NOTILE / NOX drop the entries, the tile build, the x loads: results wrong, times
             // 82.6 / 75.6 / 72.3 us against 81.0 per call on a Mistral gate; all three: 65.1; no multiplies: 39.8)
 #ifndef SDH_FP_NOSC
@@ -798,7 +801,7 @@ void w0p_mfma_kernel(const _Float16 * __restrict__ z16, int64_t zcopy, int64_t T
         { const unsigned t = Wcur; Wcur = Wnxt; Wnxt = Wnx2; Wnx2 = t; }
         par ^= 1;
         frags(0, Wcur, 0);                                           // the next slab's first step, behind the barrier
-        multiply(1, 3, xq[A][2], xq[A][3]);                          // this slab's last: the matrix pipe works through that LDS latency
+        multiply(1, 3, &xq[A][NA]);                                  // this slab's last: the matrix pipe works through that LDS latency
 #ifndef SDH_FP_NOX
         fetchX(a_c, s + 3);
 #endif
@@ -841,10 +844,10 @@ void w0p_mfma_kernel(const _Float16 * __restrict__ z16, int64_t zcopy, int64_t T
         if (orow >= n_out) continue;
         const float sc = (TALL && rs) ? rs[orow] : 1.0f;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < NA; ++a)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int64_t t = t_tile + wave * 32 + a * 16 + 4 * h + e;
+                const int64_t t = tok0 + a * 16 + 4 * h + e;
                 if (t >= T) continue;
                 float v = acc[a][c][e];
                 if (TALL) {
@@ -917,9 +920,9 @@ int launch_w0_fold(DeviceWeight & w, const float * x, int64_t ldx, int64_t T, vo
         set((const void *) w0d_mfma_kernel<TALL_, SC_, true, false>); set((const void *) w0d_mfma_kernel<TALL_, SC_, true, true>)
         SDH_FD_SET4(true, true); SDH_FD_SET4(true, false); SDH_FD_SET4(false, true); SDH_FD_SET4(false, false);
 #undef SDH_FD_SET4
-#define SDH_FP_SET4(TALL_) set((const void *) w0p_mfma_kernel<TALL_, false, false>); set((const void *) w0p_mfma_kernel<TALL_, false, true>); \
-        set((const void *) w0p_mfma_kernel<TALL_, true, false>); set((const void *) w0p_mfma_kernel<TALL_, true, true>)
-        SDH_FP_SET4(true); SDH_FP_SET4(false);
+#define SDH_FP_SET4(TALL_, NT_) set((const void *) w0p_mfma_kernel<TALL_, false, false, NT_>); set((const void *) w0p_mfma_kernel<TALL_, false, true, NT_>); \
+        set((const void *) w0p_mfma_kernel<TALL_, true, false, NT_>); set((const void *) w0p_mfma_kernel<TALL_, true, true, NT_>)
+        SDH_FP_SET4(true, 32); SDH_FP_SET4(false, 32); SDH_FP_SET4(true, 16); SDH_FP_SET4(false, 16);
 #undef SDH_FP_SET4
         set((const void *) fold_z16_kernel<true>); set((const void *) fold_z16_kernel<false>);
         return ok;
@@ -935,6 +938,11 @@ int launch_w0_fold(DeviceWeight & w, const float * x, int64_t ldx, int64_t T, vo
     const dim3 grid((unsigned) ((w.n_out + FD_R - 1) / FD_R), (unsigned) (T_pad / FD_N), (unsigned) (w.tall ? 1 : w.B));
     if (grid.y > 65535 || grid.z > 65535) { set_error("w0 fold: token chunk too large"); return SDH_ERR_UNSUPPORTED; }
     const bool scaled = fold_scaled(w);
+    // up to 256 tokens the permuted kernel takes token tiles of 128 (16 tokens per wave): twice the workgroups, each with
+    // half the multiplies, where tiles of 256 would leave half the CUs (or more) without a workgroup
+    static const bool no_half = getenv("SDH_FOLD_NO_HALF_TILES") != nullptr;      // A/B switch
+    const bool half_tiles = perm && T <= 256 && !no_half;
+    const dim3 pgrid(grid.x, half_tiles ? (unsigned) ((T + 127) / 128) : grid.y, grid.z);
     float * out = w.tall ? y : part;
     const int64_t ldo = w.tall ? ldy : (int64_t) w.B * w.L;
 #define SDH_FD_ARGS x16, ld16, T, (int) w.n_in, (int) w.n_out, (int) w.L, w.d1, w.d3, w.G, w.inv, w.fold_ent, w.fold_off, w.fold_ng, \
@@ -944,8 +952,9 @@ int launch_w0_fold(DeviceWeight & w, const float * x, int64_t ldx, int64_t T, vo
 #define SDH_FD_LAUNCH(TALL_, SC_, AT_) do { if (w.fold_over) hipLaunchKernelGGL((w0d_mfma_kernel<TALL_, SC_, AT_, true>), grid, dim3(512), lds, s, SDH_FD_ARGS); \
         else hipLaunchKernelGGL((w0d_mfma_kernel<TALL_, SC_, AT_, false>), grid, dim3(512), lds, s, SDH_FD_ARGS); } while (0)
 #define SDH_FD_LAUNCH2(TALL_, SC_) do { if (w.fold_dup) SDH_FD_LAUNCH(TALL_, SC_, true); else SDH_FD_LAUNCH(TALL_, SC_, false); } while (0)
-#define SDH_FP_LAUNCH(TALL_, AT_) do { if (w.fold_over) hipLaunchKernelGGL((w0p_mfma_kernel<TALL_, AT_, true>), grid, dim3(512), lds, s, SDH_FP_ARGS); \
-        else hipLaunchKernelGGL((w0p_mfma_kernel<TALL_, AT_, false>), grid, dim3(512), lds, s, SDH_FP_ARGS); } while (0)
+#define SDH_FP_LAUNCH0(TALL_, AT_, OV_) do { if (half_tiles) hipLaunchKernelGGL((w0p_mfma_kernel<TALL_, AT_, OV_, 16>), pgrid, dim3(512), lds, s, SDH_FP_ARGS); \
+        else hipLaunchKernelGGL((w0p_mfma_kernel<TALL_, AT_, OV_, 32>), pgrid, dim3(512), lds, s, SDH_FP_ARGS); } while (0)
+#define SDH_FP_LAUNCH(TALL_, AT_) do { if (w.fold_over) SDH_FP_LAUNCH0(TALL_, AT_, true); else SDH_FP_LAUNCH0(TALL_, AT_, false); } while (0)
 #define SDH_FP_LAUNCH2(TALL_) do { if (w.fold_dup) SDH_FP_LAUNCH(TALL_, true); else SDH_FP_LAUNCH(TALL_, false); } while (0)
     if (perm)        { if (w.tall) SDH_FP_LAUNCH2(true); else SDH_FP_LAUNCH2(false); }
     else if (w.tall) { if (scaled) SDH_FD_LAUNCH2(true, true); else SDH_FD_LAUNCH2(true, false); }
@@ -955,6 +964,7 @@ int launch_w0_fold(DeviceWeight & w, const float * x, int64_t ldx, int64_t T, vo
 #undef SDH_FD_LAUNCH2
 #undef SDH_FD_LAUNCH
 #undef SDH_FP_LAUNCH2
+#undef SDH_FP_LAUNCH0
 #undef SDH_FP_LAUNCH
     SDH_HIP_CHECK(hipGetLastError());
     if (!w.tall) {
