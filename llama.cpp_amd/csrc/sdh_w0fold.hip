@@ -632,6 +632,8 @@ void w0d_mfma_kernel(const _Float16 * __restrict__ x16, int64_t ld16, int64_t T,
 //             time within 1 % (85.4 / 86.4 us per call on a Mistral gate). In the pre-pass, the four tokens' values of an input
 //             side by side in LDS (8 gathers of 8 bytes per thread instead of 32 of 2, staged by dword loads): 12.3 / 21.4 us
 //             against 10.0 / 12.1 us (tall / wide Mistral tensors). Neither kept.
+//             Token tiles of 128 at 512 tokens as well (448 workgroups, two per CU when compiled for 128 registers): 122 against
+//             89 us per call; the 128-token tiles compiled for two workgroups per CU at up to 256 tokens: no difference.
 //   vmcnt     every global load of the loop is issued unconditionally (indices clamped; work for slabs past the end lands in
 //             tiles nothing reads) and the prologue issues its last loads in the loop's order: a load behind a branch, or a
 //             different order on the way into the loop, makes the compiler's counted waits assume the shortest queue and
