@@ -308,6 +308,9 @@ void ffn_stack_kernel(const StackArgs a) {
             if (threadIdx.x == 0) stk_stamp_l = (smp >= 0 && l < 64) ? l : -1;
 #endif
             STK_STAMP(smp, l, 0);
+#ifdef SDH_STK_STAMPS
+            if (smp >= 0 && threadIdx.x == 0 && l < 64) stk_stamp_lds[l * 8 + 7] = __builtin_amdgcn_s_memtime();   // shader clock beside the real-time stamp 0
+#endif
             const unsigned tag = a.tag0 + (unsigned) l;
             BasePackDesc pd = a.pd[which];
             pd.pack = a.layers[l].pack[which];

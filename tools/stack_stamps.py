@@ -45,3 +45,8 @@ for smp in range(7):
     for l in range(NL):
         print("  L%-2d " % l + " ".join("%8.2f" % rel[smp, l, k] for k in range(len(ev[kind]))))
 print("per-layer period (gate base publish to publish):", np.diff(rel[0, :, 3]))
+# shader clock the base workgroup saw: slot 7 holds s_memtime beside the real-time stamp of slot 0
+for smp in range(3):
+    dt_clk = np.diff(buf[smp, :, 7].astype(np.int64))
+    dt_rt = np.diff(buf[smp, :, 0].astype(np.int64))
+    print(names[smp], "shader clock between layer tops, GHz:", np.round(dt_clk / np.maximum(dt_rt, 1) * 0.1, 3))
