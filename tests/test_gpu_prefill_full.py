@@ -246,6 +246,25 @@ def test_mfma_fold_permuted_order_small_shapes(hip, dims, scheme, K, block):
         w.close()
 
 
+def test_mfma_fold_token_counts_and_chunks(hip):
+    """The folded contraction across its token regimes on one payload: token tiles of 128 (up to 256 tokens), of 256, and a
+    call longer than one workspace chunk (2048 tokens): a token's result never depends on the batch it came in."""
+    p = make_payload(1024, 2816, scheme="coo", K=32, base=True, seed=77)
+    x = make_x(1024, 2500, seed=9)
+    w = hip.SeedDeltaWeight(p)
+    y = w.forward_host(x, hip.FWD_MFMA_FOLD)                   # 2048 + 452
+    assert w.fold_layout() & 2 and w.nonfinite_count() == 0
+    for t0, t1 in ((0, 5), (5, 133), (100, 356), (300, 1324), (2047, 2500), (0, 2049)):
+        yt = w.forward_host(x[t0:t1], hip.FWD_MFMA_FOLD)
+        assert np.array_equal(bits(yt), bits(y[t0:t1])), (t0, t1)
+    y_ref = O.forward(p, x[::50], nth=4)
+    assert np.abs(y[::50] - y_ref).max() <= 2e-2 * np.abs(y_ref).max()
+    # by default: exact below the class's crossover (COO: 160 tokens), folded from there on
+    assert np.array_equal(bits(w.forward_host(x[:159])), bits(O.forward(p, x[:159], nth=4)))
+    assert np.array_equal(bits(w.forward_host(x[:160])), bits(y[:160]))
+    w.close()
+
+
 def test_mfma_fold_counts_nonfinite_outputs(hip):
     p = make_payload(512, 768, scheme="coo", K=16, base=True, seed=5)
     x = make_x(512, 12, seed=1)
