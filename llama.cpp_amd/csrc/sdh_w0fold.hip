@@ -279,6 +279,14 @@ int fold_ensure(DeviceWeight & w, hipStream_t s) {
     const size_t off_bytes = (size_t) tiles * (a.n_g + 1) * sizeof(int);
     const size_t ent_words = (size_t) cap + (size_t) 4 * tiles * a.n_g + 4;       // every bucket padded to a multiple of 4
     int * counts = nullptr, * cursor = nullptr; unsigned * ent = nullptr; int2 * bounds = nullptr; _Float16 * gp = nullptr; short * p16 = nullptr;
+    bool done = false;
+    struct Cleanup {                                               // whatever way this function is left early, nothing it allocated stays behind
+        int *& counts; int *& cursor; unsigned *& ent; int2 *& bounds; _Float16 *& gp; short *& p16; bool & done;
+        ~Cleanup() {
+            (void) hipFree(counts); (void) hipFree(cursor);
+            if (!done) { (void) hipFree(ent); (void) hipFree(bounds); (void) hipFree(gp); (void) hipFree(p16); }
+        }
+    } cleanup{counts, cursor, ent, bounds, gp, p16, done};
     SDH_HIP_CHECK(hipMalloc((void **) &counts, off_bytes));
     SDH_HIP_CHECK(hipMalloc((void **) &cursor, off_bytes));
     SDH_HIP_CHECK(hipMalloc((void **) &bounds, (size_t) tiles * a.n_g * sizeof(int2)));
@@ -306,8 +314,7 @@ int fold_ensure(DeviceWeight & w, hipStream_t s) {
     int dup[2] = {0, 0};
     SDH_HIP_CHECK(hipMemcpyAsync(dup, counts, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     SDH_HIP_CHECK(hipStreamSynchronize(s));
-    SDH_HIP_CHECK(hipFree(cursor));
-    SDH_HIP_CHECK(hipFree(counts));
+    done = true;
     w.fold_dup = dup[0] != 0;
     w.fold_over = dup[1] > 4 * 512;                               // some bucket holds more than the four entries per thread of the prefetch
     w.fold_perm = perm; w.fold_gp = gp; w.fold_p16 = p16;
