@@ -366,7 +366,7 @@ def run_ffn(args, dev):
             def block_p():
                 for wg, wu, wd in use:
                     seeddelta.ffn_forward_device(wg, wu, wd, seeddelta.ACT_SILU, xT.data_ptr(), n_embd, T, yT.data_ptr(), n_embd, fl, sp)
-            ev_p, _ = timed_on_stream(block_p, 6, st, seeddelta, warm=4)
+            ev_p, _ = timed_on_stream(block_p, 6, st, seeddelta, warm=30 if name == "fp32" else 6)     # (the first variant also brings the clocks up)
             prefill_layer[name] = ev_p / (6 * len(use))
         prefill_layer = {"tokens": T, "ms_per_layer": prefill_layer,
                          "tokens_per_s_fold": T / prefill_layer["mfma_fold"] * 1e3,
@@ -507,7 +507,7 @@ def run_prefill(args, dev):
         # mfma_fold: SDH_FWD_MFMA_FOLD, the whole op as one dense contraction (residual added to the W0 tile in LDS)
         # default: what sdh_forward chooses by itself — at 512 tokens the folded contraction for every Mistral payload class;
         # fp32: SDH_FWD_NO_MFMA, the default's choice among the fp32 forms (bit-exact tiled SpMM, or the rows kernel for long rows)
-        for _ in range(40):                                   # bring the clocks up before the first timed variant (it read 10 % slow)
+        for _ in range(400):                                  # ~35 ms of load: the chip reaches its steady clocks only after 20+ ms (the first variant read 10 % slow behind 40 calls)
             w.forward_device(x.data_ptr(), n_in, T, y.data_ptr(), n_out, flags=0, stream=sp)
         st.synchronize()
         for tag, flags in (("default", 0), ("fp32", seeddelta.FWD_NO_MFMA), ("w0_mfma", seeddelta.FWD_W0_MFMA),

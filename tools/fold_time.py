@@ -19,7 +19,7 @@ for name in os.environ.get("WL", "cfg4_mistral_gate_coo_k128,cfg4_mistral_down_c
     x = torch.randn((T, p.n_in), dtype=torch.float32, device="cuda")
     y = torch.empty((T, p.n_out), dtype=torch.float32, device="cuda")
     fn = lambda: w.forward_device(x.data_ptr(), p.n_in, T, y.data_ptr(), p.n_out, flags=flags, stream=st.cuda_stream)
-    for _ in range(5):
+    for _ in range(int(os.environ.get("WARM", "300"))):
         fn()
     st.synchronize()
     seeddelta.profile_span_begin(st.cuda_stream)
