@@ -2,7 +2,9 @@
 random shapes, schemes, dtypes, token counts and flag sets for a time budget; stops at the first mismatch and
 prints the case so that it can be turned into a test. Bars are those of tests/test_gpu_forward.py: EXACT_ORDER and
 the tiled SpMM path (T >= 6, no NO_SPMM) bit-identical to the oracle, the other fast paths within fast_tolerance,
-W0_MFMA within its f16 bound.      python3 tools/fuzz_forward.py [seconds] [seed]"""
+W0_MFMA within its f16 bound, the folded contraction (SDH_FWD_MFMA_FOLD, and the default / NO_FUSE dispatch where the
+token count is above the payload class's crossover) within tests/test_gpu_prefill_full.py's fold_bound.
+    python3 tools/fuzz_forward.py [seconds] [seed]"""
 import os
 import sys
 import time
@@ -13,6 +15,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def dense_abs_sum(O, p):
+    """|rs| * (|W0| + |D|) as a dense (n_out, n_in) matrix: the folded contraction's bound multiplies it with |x|"""
+    A = np.abs(O.w0_tile(p, 0, p.n_out, 0, p.n_in).astype(np.float64))
+    rows = np.arange(p.n_out)
+    if p.d_idx is not None:
+        idx, val = p.d_idx.astype(np.int64), np.abs(p.d_val.astype(np.float64))
+        ok = (idx >= 0) & (idx < p.n_in)
+        np.add.at(A, (np.broadcast_to(rows[:, None], idx.shape)[ok], idx[ok]), val[ok])
+    else:
+        bi, bv = p.b_idx.astype(np.int64), np.abs(p.b_val.astype(np.float64))
+        block = bv.shape[2]
+        cols = bi[:, :, None] * block + np.arange(block)[None, None, :]
+        ok = (bi[:, :, None] >= 0) & (cols < p.n_in)
+        np.add.at(A, (np.broadcast_to(rows[:, None, None], cols.shape)[ok], cols[ok]), bv[ok])
+    if p.row_scale is not None:
+        A *= np.abs(p.row_scale.astype(np.float64))[:, None]
+    return A
 
 
 def main():
@@ -35,7 +56,7 @@ def main():
         block = int(rng.choice([8, 12, 16, 32]))
         K = int(rng.choice([1, 8, 20, 32, 64, 96, 128, 256, 384, 512, 1024, 1536]))
         base = bool(rng.random() < 0.7)
-        T = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 17, 40, 130, 300]))
+        T = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 17, 40, 130, 170, 260, 300, 420]))
         kw = dict(scheme=scheme, K=K, block=block, base=base, row_scale=bool(rng.random() < 0.8), d13_random=bool(base and rng.random() < 0.5),
                   seed=int(rng.integers(1 << 30)))
         if rng.random() < 0.25:
@@ -55,10 +76,15 @@ def main():
         flagsets = [("default", 0), ("exact", hip.FWD_EXACT_ORDER), ("no_fuse", hip.FWD_NO_FUSE), ("no_spmm", hip.FWD_NO_SPMM)]
         if base:
             flagsets.append(("w0_mfma", hip.FWD_W0_MFMA))
+            flagsets.append(("fold", hip.FWD_MFMA_FOLD))            # after default / no_fuse: fold_layout() != 0 there means THEY folded
         tol = None
+        fold_A = None
         for name, fl in flagsets:
             y = w.forward_host(x, fl)
-            exact = name == "exact" or (name in ("default", "no_fuse") and T >= 6)
+            folded = base and T >= 5 and name in ("default", "no_fuse", "fold") and w.fold_layout() != 0
+            exact = not folded and (name == "exact" or (name in ("default", "no_fuse") and T >= 6))
+            if folded:
+                name = name if name == "fold" else name + "_folded"
             ok = True
             if exact:
                 ok = np.array_equal(y.view(np.uint32), y_ref.view(np.uint32))
@@ -68,6 +94,10 @@ def main():
                 if tol is None:
                     tol = fast_tolerance(p, x, y_ref)
                 bound = tol
+                if folded:
+                    if fold_A is None:
+                        fold_A = dense_abs_sum(O, p)
+                    bound = 1.5e-3 * (np.abs(x.astype(np.float64)) @ fold_A.T) + 75.0 * tol
                 if name == "w0_mfma":
                     W0 = np.abs(O.w0_tile(p, 0, n_out, 0, n_in).astype(np.float64))
                     rs = np.abs(p.row_scale.astype(np.float64))[None, :] if p.row_scale is not None else 1.0
