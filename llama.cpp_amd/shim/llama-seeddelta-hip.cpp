@@ -68,6 +68,14 @@ struct payload_entry {
 
 std::mutex g_mu;        // payload cache, FFN node list, library init
 std::mutex g_call_mu;   // one evaluation at a time: contexts that share a model share its sdh_weight handles
+
+// SEEDDELTA_HIP_FP32=1: keep the fp32 forms for large ubatches too (SDH_FWD_NO_MFMA). Without it ubatches above a payload
+// class's crossover (80-320 tokens) run as folded f16 contractions on the matrix cores: ~1e-3 relative per output, as any GPU
+// backend's f16 GEMM, instead of the CPU op's fp32 arithmetic.
+int extra_flags() {
+    static const int f = [] { const char * e = std::getenv("SEEDDELTA_HIP_FP32"); return (e && *e && *e != '0') ? SDH_FWD_NO_MFMA : 0; }();
+    return f;
+}
                         // (hand-off granules, non-finite ring, workspace) and the library's host-I/O staging
 std::unordered_map<payload_key, payload_entry, payload_key_hash> g_payloads;
 bool g_inited = false;
@@ -302,7 +310,7 @@ void seeddelta_hip_op(ggml_tensor * dst, int ith, int /*nth*/, void * userdata) 
     int64_t ldx = n_in;
     const float * xs = packed_x(n.x, n_in, n_tok, &ldx);
     const int64_t ldy = n_tok > 1 ? (int64_t) (dst->nb[1] / sizeof(float)) : n_out;
-    if (sdh_forward(w, xs, ldx, n_tok, (float *) dst->data, ldy, SDH_FWD_HOST_IO, nullptr) != SDH_OK) {
+    if (sdh_forward(w, xs, ldx, n_tok, (float *) dst->data, ldy, SDH_FWD_HOST_IO | extra_flags(), nullptr) != SDH_OK) {
         die("sdh_forward");
     }
     const int64_t bad = sdh_nonfinite_count(w);
@@ -362,7 +370,7 @@ void seeddelta_hip_ffn_op(ggml_tensor * dst, int ith, int /*nth*/, void * userda
     const float * xs = packed_x(x, n_embd, n_tok, &ldx);
     const int64_t n_out = dst->ne[0];
     const int64_t ldy = n_tok > 1 ? (int64_t) (dst->nb[1] / sizeof(float)) : n_out;
-    const int flags = SDH_FWD_HOST_IO | SDH_FWD_ZERO_NONFINITE;
+    const int flags = SDH_FWD_HOST_IO | SDH_FWD_ZERO_NONFINITE | extra_flags();
     if (sdh_ffn_forward(wg, wu, wd, f->gelu ? SDH_ACT_GELU : SDH_ACT_SILU, xs, ldx, n_tok, (float *) dst->data, ldy, flags, nullptr) != SDH_OK) {
         die("sdh_ffn_forward");
     }
