@@ -89,6 +89,32 @@ def test_reference_cpu_op_and_hip_shim_agree_end_to_end(hip, model, case):
     assert abs(e["ppl_seeddelta"] - e["ppl_base"]) > 1e-6 * e["ppl_base"]
 
 
+def test_large_ubatch_runs_the_folded_contraction_end_to_end(hip, model):
+    """A prompt evaluated in ubatches of 512 tokens: above every payload class's crossover, so the shim's sdh_forward calls run
+    as folded f16 contractions on the matrix cores. Against the reference's CPU op on the same GGUF the logits
+    agree to 1e-3 of their scale and the perplexity to 1e-4 relative (north star: 1e-3); with SEEDDELTA_HIP_FP32=1 the shim keeps the
+    fp32 forms and meets the tight bounds of the test above at this ubatch size too."""
+    d, base, tok = model
+    out = str(d / "big_ubatch")
+    p = SC.ScanParams(base_max_samples=512, base_perm_trials=2, eval_cols=16, eval_x=4, scheme="block", K=128, block=32, base=True, row_scale=True)
+    summ = PE.policy_eval(base, tok, out, [SHIM_BIN], params=p, layers="0-1", strip_dense=False,
+                          ctx_list=(128,), chunks=1, n_predict=4, threads=8, batch=64, prompts=(4,), base_runner=[REF_BIN])
+    sd = summ["model_sd"]
+    la, lb, lc = (str(d / ("big_%s.logits" % k)) for k in ("ref", "fold", "fp32"))
+    ref = PE.run_runner([REF_BIN], sd, tok, 512, 512, 2, 8, True, logits_out=la)
+    fold = PE.run_runner([SHIM_BIN], sd, tok, 512, 512, 2, 8, True, logits_out=lb)
+    fp32 = PE.run_runner([SHIM_BIN], sd, tok, 512, 512, 2, 8, True, logits_out=lc, env=dict(os.environ, SEEDDELTA_HIP_FP32="1"))
+    a, b, c = (np.fromfile(f, dtype=np.float32) for f in (la, lb, lc))
+    assert a.shape == b.shape == c.shape and a.size > 0 and np.isfinite(b).all()
+    scale = np.abs(a).max()
+    assert np.abs(a - c).max() <= 2e-4 * scale and abs(fp32["ppl"] - ref["ppl"]) <= 1e-5 * ref["ppl"]
+    assert np.abs(a - b).max() <= 1e-3 * scale, (np.abs(a - b).max(), scale)                 # measured: 1.3e-4
+    assert abs(fold["ppl"] - ref["ppl"]) <= 1e-4 * ref["ppl"], (fold["ppl"], ref["ppl"])      # measured: 3.8e-6 (north star: 1e-3)
+    assert not np.array_equal(b, c)                            # the two shim runs did take different forms
+    print("large ubatch: max |dlogit| / scale folded %.2e, fp32 %.2e; PPL rel folded %.2e, fp32 %.2e" % (
+        np.abs(a - b).max() / scale, np.abs(a - c).max() / scale, abs(fold["ppl"] - ref["ppl"]) / ref["ppl"], abs(fp32["ppl"] - ref["ppl"]) / ref["ppl"]))
+
+
 def test_shim_build_without_seeddelta_flag_is_the_dense_model(hip, model):
     """--seeddelta off: both builds evaluate the dense weights (src/llama-context.cpp:140-146), bit-identically."""
     d, base, tok = model
