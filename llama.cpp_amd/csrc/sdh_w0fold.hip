@@ -4,37 +4,39 @@
 //
 // The reference evaluates the base term and the residual side by side for every output (src/llama-seeddelta.cpp
 // :1088-1127 tall, :1128-1175 wide). For many tokens the residual's per-row gathers are what costs (0.94 G scattered
-// LDS reads per ubatch of a Mistral gate); the dense product W0.x is a real GEMM. So this kernel builds the W0 tile of
-// a k-slab in LDS exactly as w0_mfma_tile_kernel does (closed form G_b[(p ^ inv_b[q])], bit-exact in fp32, rounded to
-// f16 once) and then ADDS the residual entries that fall into that (row tile, slab) to it, in LDS, before the matrix
-// cores read it: the residual becomes part of the B operand and costs one LDS atomic per entry and workgroup instead
-// of one gather-MAC per entry and token. The payload is re-laid out once per handle, on the device, for that: entries
-// bucketed by (128-row tile, 64-wide k-slab), each a 32-bit word {f16 value, row in tile, column in slab}; block
-// payloads are expanded to entries, invalid indices dropped (reference skip rules :693, :929-936).
+// LDS reads per ubatch of a Mistral gate); the dense product W0.x is a real GEMM. So the kernels here build the W0 tile
+// of a k-slab in LDS (closed form G_b[(p ^ inv_b[q])], bit-exact in fp32, rounded to f16 once) and then ADD the residual
+// entries that fall into that (row tile, slab) to it, in LDS, before the matrix cores read it: the residual becomes part
+// of the B operand and costs one LDS add per entry and workgroup instead of one gather-MAC per entry and token. The
+// payload is re-laid out once per handle, on the device, for that: entries bucketed by (128-row tile, 64-wide k-slab),
+// each a 32-bit word {f16 value, byte offset in the tile}; buckets padded to multiples of four with null entries (value
+// +0 at a pad column); block payloads are expanded to entries, invalid indices dropped (reference skip rules :693,
+// :929-936).
 //
-// Numerics: f16 operands (x, W0 + D), fp32 accumulation, row_scale in fp32 in the epilogue — the tolerance of the
-// MFMA base path (tests state it), not the bit-exact order of the SpMM / FWHT forms, which stay available.
+// Numerics: f16 operands (x, W0 + D), fp32 accumulation, row_scale in fp32 in the epilogue — the stated f16 bound of the
+// tests, not the bit-exact order of the SpMM / FWHT forms, which stay available (SDH_FWD_NO_MFMA).
 //
+// Two kernels:
+//   w0p_mfma_kernel  the contraction in the PERMUTED order j = inv_b[q], for payloads whose d1 and d3 are all ones (what
+//                    the builder writes) and whose base blocks are at most a third longer than their inputs. W0[p][j] =
+//                    G_b[p ^ j] is then a plain XOR-circulant, the x image is permuted and fragment-tiled by a pre-pass, and
+//                    the x fragments never touch LDS. Its notes stand above the kernel. 0.074-0.086 ms per Mistral-7B
+//                    tensor and ubatch of 512.
+//   w0d_mfma_kernel  the contraction in q order, for everything else that has a closed-form base: W0 tile gathered from G_b
+//                    (16 dword gathers, 8 readlanes, 16 multiplies and 16 conversions per thread and slab), x tile staged
+//                    in LDS, 8 waves of 64 rows x 64 tokens of v_mfma_f32_32x32x16_f16. 0.11-0.13 ms. Its layout:
 //   workgroup  512 threads = 8 waves; tile 128 rows x 256 tokens x 64 k per slab.
 //   LDS        Ws[3][128][72] f16 (three W tiles in rotation: slab s is multiplied while the residual of slab s+1 is
 //              added to the tile written one slab earlier and the W0 tile of slab s+2 is written — one barrier per
-//              slab), Xs[2][256][72] f16. 129 KB.
-//   adds       ds_pk_add_f16 (the pair that holds the element, the other half +0): no read-modify-write sequence,
-//              and duplicate (row, column) entries of a hand-made payload sum as the reference sums them.
-//   tried      sixteen waves of 32 rows x 64 tokens per workgroup (four waves per SIMD, 128 registers) instead of eight of
-//              64 x 64: the same time within 1 % (136.7 / 135.4 us per call on a Mistral gate) — the kernel is not short
-//              of independent chains; SQ counters (profiles/r03_e_pmc_fold_and_scan.json): MFMA busy 0.22, VALU 0.29,
-//              LDS 0.22, waves waiting 0.41 of their cycles, no pipe saturated. Per slab and CU the texture path
-//              moves 64 KB, the LDS 176 KB, the matrix pipe runs 128 MFMAs: ~0.5 + 0.7 + 0.5 us if nothing overlapped,
-//              1.9 us measured.
-//   permuted   (PERM, payloads whose d1 and d3 are all ones — what the builder writes) With j = inv_b[q] as the contraction
-//              index, W0[p][j] = G_b[p ^ j]: inside a (128-row, 64-column) tile that is seg[pl ^ jl] for one aligned 128-float
-//              segment of G_b, so 8 consecutive columns of a row are an aligned group of 8 of G_b permuted by XOR with
-//              (row & 7). fold_gp holds G_b in f16 under each of those 8 permutations; a thread then builds 16 elements of
-//              the tile with two 16-byte loads and two ds_write_b128 and no arithmetic (the q-order form: 16 dword
-//              gathers, 8 readlanes, 16 multiplies and 16 conversions per thread and slab — VALU busy 0.30 against MFMA
-//              busy 0.22 in the counters above). The pre-pass writes x in j order (z[j] = x[perm1_b[j]], zero where the
-//              block has no such input; tall: one copy per base block), the buckets hold the entries' j columns.
+//              slab), Xs[2][256][72] f16, the bucket bounds. 133 KB.
+//   adds       a 16-bit LDS read, v_add_f16, a 16-bit LDS write per entry (the reads issued at the first multiply step, the
+//              writes two steps later); ds_pk_add_f16 when a payload repeats a (row, input) pair, which sums them as the
+//              reference sums them.
+//   tried      (on the q-order kernel, before the permuted one existed) sixteen waves of 32 rows x 64 tokens per workgroup
+//              (four waves per SIMD, 128 registers) instead of eight of 64 x 64: the same time within 1 % (136.7 / 135.4 us
+//              per call on a Mistral gate); SQ counters (profiles/r03_e_pmc_fold_and_scan.json): MFMA busy 0.22, VALU
+//              0.29, LDS 0.22, waves waiting 0.41 of their cycles. What those waits were: the vmcnt note above
+//              w0p_mfma_kernel.
 //   wide       K is split by base block over blockIdx.z (as the tiled W0 kernel); partial products go to [T][B][L]
 //              and fold_reduce_kernel sums them in block order, applies row_scale and the non-finite census.
 #include "sdh_internal.h"
