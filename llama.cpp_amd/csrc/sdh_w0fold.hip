@@ -626,17 +626,24 @@ void w0d_mfma_kernel(const _Float16 * __restrict__ x16, int64_t ld16, int64_t T,
 }
 
 // ---- the contraction in the permuted order --------------------------------------------------------------------------
-// Same tiles, same LDS image, same scatter step as above; what differs:
+// Same W tiles in rotation and the same scatter step as w0d_mfma_kernel; what differs:
 //   W0 tile   The 128 x 64 tile of slab s is seg[pl ^ jl] for ONE aligned 128-element segment of G_b (at (p0 ^ 64 s) & ~127): 256
 //             bytes, 2 KB under the 8 permutations of fold_gp. Each thread brings one dword of that image per slab (global ->
 //             register -> Gs, laid out [group of 8][copy][8] so that the 16 lanes of a read pass fall on 16 distinct bank quads),
 //             and the tile is built LDS -> LDS: thread (pl, gsel) copies the groups (pl >> 3) ^ g ^ 8 hi of copy pl & 7 to row pl,
 //             columns 8 g .. 8 g + 7, g = gsel and gsel + 4. No arithmetic, 2 KB of L2 traffic per slab instead of 32 KB.
-//   depth     x tiles and entries are loaded THREE slabs ahead into three register sets in rotation (the loop is unrolled by
-//             three; which LDS buffer a slab reads is a runtime offset): a CU gets 60-70 GB/s from L2 with ~70 KB in flight
-//             (loads alone, no multiplies: 58 GB/s measured here), and one slab ahead (32 KB) left the waves waiting on vmcnt
-//             with the matrix pipe idle — the multiply-only build of this kernel ran 54 us, the load-only build 58 us, both
-//             together 88 us.
+//   x         never in LDS: the pre-pass (fold_z16_kernel) writes z[t][j] = f16(x[t][perm1_b[j]]) tiled [token / 32][column / 32]
+//             [32][32], an A fragment of v_mfma_f32_16x16x32_f16 is 1 KB of consecutive bytes, and every wave owns all 128 rows
+//             of the tile for its own 32 (or 16) tokens, so no two waves want the same fragment. W tiles at a 160-byte pitch
+//             make the B fragments of that MFMA shape conflict-free; under it the chip holds a higher clock than under
+//             32x32x16 at the same cycles per flop (79.7 -> 74.0 us).
+//   depth     x fragments and entries are loaded THREE slabs ahead into three register sets in rotation (the loop is unrolled
+//             by three; which W tile a slab reads is a runtime offset): a CU gets 60-70 GB/s from L2 with ~70 KB in flight, and
+//             one slab ahead left the waves waiting on vmcnt with the matrix pipe idle. The last multiply step of a slab is
+//             issued behind the barrier, after the next slab's first W fragments have been asked for.
+//   clocks    the chip holds ~1.6 GHz under this kernel (126 k shader cycles in ~78 us) and needs 20+ ms of load to settle:
+//             time it behind a few hundred calls (tools/fold_time.py does), and read "0.35 of the f16 peak" as 0.52 of the
+//             matrix-pipe cycles the chip actually delivers.
 //   tried     the workgroups that read one x panel (base block, token tile) on one XCD instead of dealt round-robin: the same
 //             time within 1 % (85.4 / 86.4 us per call on a Mistral gate). In the pre-pass, the four tokens' values of an input
 //             side by side in LDS (8 gathers of 8 bytes per thread instead of 32 of 2, staged by dword loads): 12.3 / 21.4 us
