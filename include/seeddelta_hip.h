@@ -121,9 +121,10 @@ typedef enum sdh_op_kind {
                                       to it. The first call on a handle re-lays the residual out by (row tile, k-slab)
                                       on the device (once; it doubles the payload's footprint in HBM). Without any
                                       flag sdh_forward takes this form by itself from the measured crossover of the
-                                      payload's class on (payloads as the builder writes them, d1 = d3 = 1, blocks at
+                                      payload's class on. Payloads as the builder writes them (d1 = d3 = 1, blocks at
                                       most a third longer than their inputs): COO from 160 tokens, block payloads from
-                                      224 (tall) / 320 (wide), rows of 512 entries and more from 80; sdh_ffn_gate_up /
+                                      224 (tall) / 320 (wide), rows of 512 entries and more from 80; other payloads with
+                                      a closed-form base: COO from 320, tall block payloads from 448, long rows from 160; sdh_ffn_gate_up /
                                       sdh_ffn_forward from 224 tokens (Mistral-7B tensors at 512 tokens: 0.074-0.086 ms
                                       against 0.13-0.36 ms for the fp32 forms). Fewer tokens: the fp32 forms.        */
 #define SDH_FWD_NO_MFMA      0x80  /* never choose SDH_FWD_MFMA_FOLD by default: keep the fp32 forms (the tiled SpMM,

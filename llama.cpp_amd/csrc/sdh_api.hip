@@ -505,7 +505,7 @@ struct GluEpilogue { const float * gate; int64_t ldg; int act; const uint16_t * 
 // fold / others: gate COO K=128 57.5 / 55.4 at T=128, 61 / 80 at 192; gate block16 63 / 63 at 192, 64 / 83 at 256; down COO
 // 60 / 49 at 128, 66 / 80 at 192; down block16 68 / 64 at 256, 91 / 92 at 384; block 32 with K=1536 62 / 58 at 64, 64 / 86
 // at 96). The folded call costs one round of workgroups: ~57 us up to 128 tokens, ~63 up to 256 (token tiles of 128), ~88 at 512.
-// INT64_MAX: never by default (no closed-form base; the q-order kernel only pays for long rows).
+// INT64_MAX: never by default (no closed-form base; wide block payloads in q order).
 static int64_t fold_min_tokens(const DeviceWeight * w) {
     const bool has_base = w->kind == SDH_OP_BASE_COO || w->kind == SDH_OP_BASE_BLOCK;
     if (!has_base || !w->w0_closed_form || w->L < 128 || (w->L % 128) != 0) return INT64_MAX;
@@ -513,8 +513,13 @@ static int64_t fold_min_tokens(const DeviceWeight * w) {
     const int64_t row_entries = block ? w->nb * w->block : w->K;
     const bool perm = w0_fold_permuted(*w);
     if (row_entries >= 512) return perm ? 80 : 160;
-    if (!perm) return INT64_MAX;
-    return block ? (w->tall ? 224 : 320) : 160;
+    if (perm) return block ? (w->tall ? 224 : 320) : 160;
+    // the q-order kernel (d1 / d3 present, or blocks much longer than their inputs — Gemma's 1152 / 2560 inputs in blocks of
+    // 2048 / 4096) costs ~1.5 us per slab: Mistral tensors 111-127 us at T=512 against 143-189 (fp32; down block16: 125, a tie)
+    // and ~100 against 63-106 at 256; a Gemma-3 4B gate (COO) 58 / 68 at 256 and 62 / 119 at 512; a Gemma-3 1B gate
+    // (block16, K=64) 32 / 27 at 256 and 34 / 49 at 512, its down 43 / 35 at 512
+    if (block) return w->tall ? 448 : INT64_MAX;
+    return 320;
 }
 // ... and the gated FFN block (three tensors, activation in the up node's epilogue): us per Mistral layer, fold / others:
 // COO 176 / 180 at T=192, 177 / 194 at 224; block16 177 / 173 at 192, 176 / 207 at 224 (tools/ffn_tokens.py)

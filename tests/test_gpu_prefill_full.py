@@ -57,9 +57,10 @@ def test_prefill_T512_default_path(hip, cfg):
     # 512 tokens are above every Mistral payload class's crossover (fold_min_tokens, csrc/sdh_api.hip): sdh_forward takes the
     # folded f16 contraction by itself (its bound: test_prefill_T512_mfma_fold); SDH_FWD_NO_MFMA keeps the fp32 forms,
     # checked here: the tiled SpMM bit for bit, the LDS rows kernel (rows of 512 entries and more) within the fast bound
-    # (a Gemma gate, 2560 inputs in blocks of 4096, has no permuted form — its blocks are 1.6 x its inputs — and stays exact)
-    folded = bool(w.fold_layout() & 2)
-    assert folded == cfg.startswith(("cfg4_mistral", "cfg3_mistral")), (cfg, w.fold_layout())
+    # (a Gemma gate, 2560 inputs in blocks of 4096, has no permuted form — its blocks are 1.6 x its inputs: q-order kernel)
+    folded = w.fold_layout() != 0
+    assert folded, (cfg, w.fold_layout())
+    assert bool(w.fold_layout() & 2) == cfg.startswith(("cfg4_mistral", "cfg3_mistral")), (cfg, w.fold_layout())
     if folded:
         assert np.array_equal(bits(y), bits(w.forward_host(x, hip.FWD_MFMA_FOLD)))
         y = w.forward_host(x, hip.FWD_NO_MFMA)
@@ -99,9 +100,14 @@ def test_prefill_ctx2048_as_four_ubatches(hip):
     w = hip.SeedDeltaWeight(p)
     x4 = make_x(p.n_in, 2048, seed=23)
     ref4 = O.forward(p, x4, nth=16)
-    parts = [w.forward_host(x4[i:i + 512]) for i in range(0, 2048, 512)]
+    parts = [w.forward_host(x4[i:i + 512], hip.FWD_NO_MFMA) for i in range(0, 2048, 512)]       # the fp32 form (512 tokens fold by default)
     assert np.array_equal(bits(np.concatenate(parts)), bits(ref4))
-    assert np.array_equal(bits(w.forward_host(x4)), bits(ref4))               # one call of 2048
+    assert np.array_equal(bits(w.forward_host(x4, hip.FWD_NO_MFMA)), bits(ref4))               # one call of 2048
+    # the default dispatch: folded (q order), and batching still does not matter
+    yd = w.forward_host(x4)
+    assert w.fold_layout() & 3 == 1
+    assert np.array_equal(bits(np.concatenate([w.forward_host(x4[i:i + 512]) for i in range(0, 2048, 512)])), bits(yd))
+    assert np.abs(yd - ref4).max() <= 2e-2 * np.abs(ref4).max()
     w.close()
 
 
