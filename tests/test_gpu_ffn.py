@@ -137,6 +137,14 @@ def test_ffn_folded_prefill(hip, act, scheme, K, block):
     assert not np.array_equal(bits(y), bits(y0))
     assert np.abs(y - y0).max() <= 2e-2 * np.abs(y0).max()
     assert wg.nonfinite_count() == 0 and wu.nonfinite_count() == 0 and wd.nonfinite_count() == 0
+    # from 224 tokens on the block takes the folded forms by itself; SDH_FWD_NO_MFMA keeps the fp32 ones
+    x3 = make_x(n_embd, 300, seed=6)
+    y3 = hip.ffn_forward_host(wg, wu, wd, x3, act)
+    assert np.array_equal(bits(y3), bits(hip.ffn_forward_host(wg, wu, wd, x3, act, hip.FWD_MFMA_FOLD)))
+    y3f = hip.ffn_forward_host(wg, wu, wd, x3, act, hip.FWD_NO_MFMA)
+    assert not np.array_equal(bits(y3), bits(y3f)) and np.abs(y3 - y3f).max() <= 2e-2 * np.abs(y3f).max()
+    h3 = hip.ffn_gate_up_host(wg, wu, x3, act)
+    assert np.array_equal(bits(h3), bits(hip.ffn_gate_up_host(wg, wu, x3, act, hip.FWD_MFMA_FOLD)))
 
 
 @pytest.mark.parametrize("act", [O.ACT_SILU, O.ACT_GELU])
