@@ -851,6 +851,30 @@ static int ffn_gate_up(sdh_weight * hg, sdh_weight * hu, int act, const float * 
             }
         }
     }
+    // many tokens as folded contractions: gate and up in ONE two-pass launch that writes act(gate) * up (sdh_w0fold.hip)
+    static const bool no_pair = getenv("SDH_FOLD_NO_PAIR") != nullptr;            // A/B switch
+    if ((flags & SDH_FWD_MFMA_FOLD) && T > 256 && g != u && !(flags & SDH_FWD_EXACT_ORDER) && !no_pair) {
+        const int64_t fchunk = std::min<int64_t>(T, 2048);
+        if ((rc = ensure_ws(g, w0_fold_ws_bytes(*g, fchunk))) != SDH_OK) return rc;
+        if ((rc = ensure_ws(u, w0_fold_ws_bytes(*u, fchunk))) != SDH_OK) return rc;
+        int sg = 0, su = 0;
+        if ((rc = nf_slot(g, s, &sg)) != SDH_OK) return rc;
+        if ((rc = nf_slot(u, s, &su)) != SDH_OK) return rc;
+        rc = SDH_OK;
+        for (int64_t t0 = 0; t0 < T && rc == SDH_OK; t0 += fchunk) {
+            const int64_t tc = std::min<int64_t>(fchunk, T - t0);
+            rc = launch_w0_fold_pair(*g, *u, dx + t0 * dldx, dldx, tc, hbuf + t0 * n_ff, n_ff, g->nf_ring + sg, u->nf_ring + su,
+                                     (flags & SDH_FWD_ZERO_NONFINITE) != 0, act, ls.gelu_tab, s);
+        }
+        if (rc < 0) return rc;
+        if (rc == SDH_OK) {
+            g->seq++; u->seq++;
+            g->last_stream = u->last_stream = s;
+            ls.span_forwards += 2;
+            return SDH_OK;
+        }
+        // rc == 1: the pair does not fit (only possible before anything was launched): node by node
+    }
     rc = sdh_forward(hg, dx, dldx, T, gbuf, n_ff, flags, s);
     g->base_ready = false;
     if (rc != SDH_OK) { u->base_ready = false; return rc; }

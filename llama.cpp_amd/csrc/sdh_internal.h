@@ -181,6 +181,9 @@ size_t w0_fold_ws_bytes(const DeviceWeight & w, int64_t T);
 int  launch_w0_fold(DeviceWeight & w, const float * x, int64_t ldx, int64_t T, void * ws, float * y, int64_t ldy,
                     int * nf_counter, bool zero_nf, hipStream_t s,
                     const float * glu_gate = nullptr, int64_t glu_ldg = 0, int glu_act = 0, const uint16_t * glu_tab = nullptr);
+// gate and up of a gated FFN as one two-pass launch (tall, one shape, permuted order); each handle's ws holds its x image
+int  launch_w0_fold_pair(DeviceWeight & g, DeviceWeight & u, const float * x, int64_t ldx, int64_t T, float * h, int64_t ldh,
+                         int * nf_g, int * nf_u, bool zero_nf, int act, const uint16_t * tab, hipStream_t s);
 void fold_free(DeviceWeight & w);
 bool w0_fold_permuted(const DeviceWeight & w);   // the handle's folded contraction runs (or would run) in the permuted order
 

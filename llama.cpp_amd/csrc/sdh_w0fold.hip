@@ -51,6 +51,8 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int FD_R = 128, FD_N = 256, FD_K = 64, FD_LD = 72;
 constexpr int FD_GS = 8 * 128;                 // elements of one staged segment image
+// the second tensor (up) of the two-pass launch for a gated FFN: same shape and layout constants as the first
+struct FoldSecond { const _Float16 * z16; const _Float16 * gp; const unsigned * ent; const int2 * off; const float * rs; int * nf; };
 constexpr int FP_LD = 80;                      // row pitch of the permuted kernel's W tiles: 160 bytes, conflict-free for the 16x16x32 B fragments
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
@@ -655,13 +657,15 @@ void w0d_mfma_kernel(const _Float16 * __restrict__ x16, int64_t ld16, int64_t T,
 //             different order on the way into the loop, makes the compiler's counted waits assume the shortest queue and
 //             drain it (vmcnt(0..2) where ten loads may stay in flight). The bucket bounds sit in LDS for the same reason.
 template <bool TALL, bool ATOMIC /* the payload repeats a (row, input) pair */, bool OVER /* some bucket holds more than 2048 entries */,
-          int NT /* tokens per wave: 32 (token tile 256) or 16 (token tile 128: up to 256 tokens, twice the workgroups) */>
+          int NT /* tokens per wave: 32 (token tile 256) or 16 (token tile 128: up to 256 tokens, twice the workgroups) */,
+          bool DUAL = false /* gate and up of a gated FFN in one launch: two passes over the same tile (first the tensor of the
+                               main arguments = gate, then `second` = up), out = act(gate) * up; tall tensors of one shape */>
 __global__ __launch_bounds__(512)
 void w0p_mfma_kernel(const _Float16 * __restrict__ z16, int64_t zcopy, int64_t T, int n_out, int L, int kz /* columns of one z image */,
                      const _Float16 * __restrict__ gp, const unsigned * __restrict__ ent, const int2 * __restrict__ off, int n_g, int spb,
                      const float * __restrict__ rs, float * __restrict__ out, int64_t ldo, int * __restrict__ nf_counter, int zero_nf,
                      const float * __restrict__ glu_gate /* tall only: out = act(gate) * value (ffn_up inside a gated FFN) */, int64_t glu_ldg,
-                     int glu_act, const uint16_t * __restrict__ glu_tab) {
+                     int glu_act, const uint16_t * __restrict__ glu_tab, const FoldSecond second) {
     extern __shared__ __align__(16) unsigned char fd_smem[];
     _Float16 * Ws = (_Float16 *) fd_smem;                         // [3][FD_R][FP_LD]
     _Float16 * Gs = Ws + 3 * FD_R * FP_LD;                        // [2][16 groups][8 copies][8]
@@ -676,10 +680,12 @@ void w0p_mfma_kernel(const _Float16 * __restrict__ z16, int64_t zcopy, int64_t T
     const int p0 = TALL ? o_tile - b * L : o_tile;                // first row of the tile inside its block
     const int n_slab = spb;
     const int2 * offr = off + (size_t) blockIdx.x * n_g + (TALL ? 0 : b * spb);
+    const unsigned * entp = ent;                                  // (offr, entp, zw, Gb: rebound for the second pass of DUAL)
     // x fragments of this wave: tokens t_tile + 32 wave .. + 32; the image is tiled [token / 32][column / 32][token half][16][32]
     const int64_t tok0 = t_tile + wave * NT;                      // this wave's first token (a multiple of 16)
-    const _Float16 * zw = z16 + (TALL ? (int64_t) b * zcopy : (int64_t) 0) + (tok0 >> 5) * ((int64_t) kz * 32) + ((tok0 >> 4) & 1) * 512
+    const int64_t z_off = (TALL ? (int64_t) b * zcopy : (int64_t) 0) + (tok0 >> 5) * ((int64_t) kz * 32) + ((tok0 >> 4) & 1) * 512
                         + (TALL ? (int64_t) 0 : (int64_t) b * L * 32) + r * 32 + h * 8;
+    const _Float16 * zw = z16 + z_off;
     const char * Gb = (const char *) (gp + (size_t) 8 * b * L);
 
     const int pl = tid & 127, gsel = tid >> 7;
@@ -706,7 +712,7 @@ void w0p_mfma_kernel(const _Float16 * __restrict__ z16, int64_t zcopy, int64_t T
         constexpr int S = decltype(set_c)::value;
         ebeg[S] = __builtin_amdgcn_readfirstlane(obe.x); eend[S] = __builtin_amdgcn_readfirstlane(obe.y);
         const int e = ebeg[S] + 4 * tid;                           // buckets start and end at multiples of 4: one 16-byte load
-        eq[S] = *reinterpret_cast<const uint4 *>(ent + (e < eend[S] ? e : max(eend[S] - 4, 0)));      // clamped: read unconditionally
+        eq[S] = *reinterpret_cast<const uint4 *>(entp + (e < eend[S] ? e : max(eend[S] - 4, 0)));      // clamped: read unconditionally
     };
     auto seg_load = [&](int s) {                                   // global -> sg: the image dword of slab s
         const unsigned base = ((unsigned) (p0 ^ (clamp_slab(s) << 6)) & ~127u) << 1;
@@ -752,7 +758,7 @@ void w0p_mfma_kernel(const _Float16 * __restrict__ z16, int64_t zcopy, int64_t T
         }
         if constexpr (OVER)
             for (int e = ebeg[S] + 2048 + tid; e < eend[S]; e += 512) {                   // a bucket beyond the prefetch
-                const unsigned wd = ent[e];
+                const unsigned wd = entp[e];
                 if constexpr (ATOMIC) add_atomic(Wb, wd);
                 else { const unsigned pos = Wb + entry_pos(wd); Ws[pos] = Ws[pos] + entry_val(wd); }
             }
@@ -825,42 +831,64 @@ void w0p_mfma_kernel(const _Float16 * __restrict__ z16, int64_t zcopy, int64_t T
 #endif
     };
 
-    for (int i = tid; i < n_slab; i += 512) Bn[i] = offr[i];
-    seg_load(0); seg_commit(0);
-    seg_load(1); seg_commit(1);
-    __syncthreads();
-    fetch_off(0);
-    fetchE(set0{});
-    tile_read(0, 0); tile_write(Wcur, 0); tile_write(Wcur, 1);
-    tile_read(1, 1); tile_write(Wnxt, 0); tile_write(Wnxt, 1);
-    __syncthreads();
-    seg_load(2); seg_commit(0);
-    scatter_read(set0{}, Wcur);
-    scatter(set0{}, Wcur);
-    // the loads in flight on the way into the loop, in the order the loop's slabs -3, -2, -1 would have issued them
-    fetchX(set0{}, 0);
-    fetch_off(1); fetchE(set1{}); fetchX(set1{}, 1);
-    fetch_off(2); fetchE(set2{}); seg_load(3); fetchX(set2{}, 2);
-    fetch_off(3);
-    __syncthreads();
-    frags(0, Wcur, 0);
-    int s = 0;
-    for (; s + 2 < n_slab; s += 3) {                    // no branch inside the triple
-        slab(set0{}, set1{}, s);
-        slab(set1{}, set2{}, s + 1);
-        slab(set2{}, set0{}, s + 2);
+    auto run_pass = [&]() {
+        par = 0;
+        for (int i = tid; i < n_slab; i += 512) Bn[i] = offr[i];
+        seg_load(0); seg_commit(0);
+        seg_load(1); seg_commit(1);
+        __syncthreads();
+        fetch_off(0);
+        fetchE(set0{});
+        tile_read(0, 0); tile_write(Wcur, 0); tile_write(Wcur, 1);
+        tile_read(1, 1); tile_write(Wnxt, 0); tile_write(Wnxt, 1);
+        __syncthreads();
+        seg_load(2); seg_commit(0);
+        scatter_read(set0{}, Wcur);
+        scatter(set0{}, Wcur);
+        // the loads in flight on the way into the loop, in the order the loop's slabs -3, -2, -1 would have issued them
+        fetchX(set0{}, 0);
+        fetch_off(1); fetchE(set1{}); fetchX(set1{}, 1);
+        fetch_off(2); fetchE(set2{}); seg_load(3); fetchX(set2{}, 2);
+        fetch_off(3);
+        __syncthreads();
+        frags(0, Wcur, 0);
+        int s = 0;
+        for (; s + 2 < n_slab; s += 3) {                    // no branch inside the triple
+            slab(set0{}, set1{}, s);
+            slab(set1{}, set2{}, s + 1);
+            slab(set2{}, set0{}, s + 2);
+        }
+        if (s < n_slab) slab(set0{}, set1{}, s);
+        if (s + 1 < n_slab) slab(set1{}, set2{}, s + 1);
+    };
+    run_pass();
+    floatx4 accg[DUAL ? NA : 1][8];
+    if constexpr (DUAL) {
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                accg[a][c] = acc[a][c];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[a][c][e] = 0.0f;
+            }
+        __syncthreads();                                            // the first pass's last LDS reads are behind us
+        offr = second.off + (size_t) blockIdx.x * n_g;
+        entp = second.ent;
+        zw = second.z16 + z_off;
+        Gb = (const char *) (second.gp + (size_t) 8 * b * L);
+        run_pass();
     }
-    if (s < n_slab) slab(set0{}, set1{}, s);
-    if (s + 1 < n_slab) slab(set1{}, set2{}, s + 1);
 
     // C[row = token][col = o] of a 16 x 16 tile: row = 4 h + e, col = r
     const size_t col_off = TALL ? 0 : (size_t) b * L;
-    int bad = 0;
+    int bad = 0, bad2 = 0;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const int orow = o_tile + c * 16 + r;
         if (orow >= n_out) continue;
         const float sc = (TALL && rs) ? rs[orow] : 1.0f;
+        const float sc2 = (DUAL && second.rs) ? second.rs[orow] : 1.0f;
 #pragma unroll
         for (int a = 0; a < NA; ++a)
 #pragma unroll
@@ -868,7 +896,14 @@ void w0p_mfma_kernel(const _Float16 * __restrict__ z16, int64_t zcopy, int64_t T
                 const int64_t t = tok0 + a * 16 + 4 * h + e;
                 if (t >= T) continue;
                 float v = acc[a][c][e];
-                if (TALL) {
+                if constexpr (DUAL) {                                      // each node's guard, then the activation (store_output)
+                    float g = accg[a][c][e];
+                    if (sc != 1.0f) g *= sc;
+                    if (!__builtin_isfinite(g)) { ++bad; if (zero_nf) g = 0.0f; }
+                    if (sc2 != 1.0f) v *= sc2;
+                    if (!__builtin_isfinite(v)) { ++bad2; if (zero_nf) v = 0.0f; }
+                    v = glu_value(glu_act, g, v, glu_tab);
+                } else if (TALL) {
                     if (sc != 1.0f) v *= sc;                                           // :645
                     if (!__builtin_isfinite(v)) { ++bad; if (zero_nf) v = 0.0f; }
                     if (glu_gate) v = glu_value(glu_act, glu_gate[t * glu_ldg + orow], v, glu_tab);   // after the node's guard, as store_output
@@ -876,6 +911,7 @@ void w0p_mfma_kernel(const _Float16 * __restrict__ z16, int64_t zcopy, int64_t T
                 out[t * ldo + col_off + orow] = v;
             }
     }
+    if (DUAL && bad2) atomicAdd(second.nf, bad2);
     if (TALL && bad) atomicAdd(nf_counter, bad);
 }
 
@@ -966,7 +1002,7 @@ int launch_w0_fold(DeviceWeight & w, const float * x, int64_t ldx, int64_t T, vo
 #define SDH_FD_ARGS x16, ld16, T, (int) w.n_in, (int) w.n_out, (int) w.L, w.d1, w.d3, w.G, w.inv, w.fold_ent, w.fold_off, w.fold_ng, \
         w.fold_spb, w.rs, out, ldo, nf_counter, zero_nf ? 1 : 0
 #define SDH_FP_ARGS x16, zcopy, T, (int) w.n_out, (int) w.L, (int) ld16, w.fold_gp, w.fold_ent, w.fold_off, w.fold_ng, \
-        w.fold_spb, w.rs, out, ldo, nf_counter, zero_nf ? 1 : 0, glu_gate, glu_ldg, glu_act, glu_tab
+        w.fold_spb, w.rs, out, ldo, nf_counter, zero_nf ? 1 : 0, glu_gate, glu_ldg, glu_act, glu_tab, FoldSecond{}
 #define SDH_FD_LAUNCH(TALL_, SC_, AT_) do { if (w.fold_over) hipLaunchKernelGGL((w0d_mfma_kernel<TALL_, SC_, AT_, true>), grid, dim3(512), lds, s, SDH_FD_ARGS); \
         else hipLaunchKernelGGL((w0d_mfma_kernel<TALL_, SC_, AT_, false>), grid, dim3(512), lds, s, SDH_FD_ARGS); } while (0)
 #define SDH_FD_LAUNCH2(TALL_, SC_) do { if (w.fold_dup) SDH_FD_LAUNCH(TALL_, SC_, true); else SDH_FD_LAUNCH(TALL_, SC_, false); } while (0)
@@ -991,6 +1027,54 @@ int launch_w0_fold(DeviceWeight & w, const float * x, int64_t ldx, int64_t T, vo
                            w.rs, y, ldy, nf_counter, zero_nf ? 1 : 0);
         SDH_HIP_CHECK(hipGetLastError());
     }
+    return SDH_OK;
+}
+
+// Gate and up of a gated FFN as ONE two-pass launch: every workgroup contracts its (row tile, token tile) for gate, keeps the
+// accumulators, contracts the same tile for up and writes act(gate) * up — no gate output in memory, no second launch. Tall
+// tensors of one shape, both in the permuted order; the caller sends more than 256 tokens per call (fewer: the two-launch form
+// with token tiles of 128). Each tensor's permuted x image goes to its own workspace (w0_fold_ws_bytes). Arithmetic per tensor
+// and the activation are those of the two-launch form: the same bits. Returns 1 when the pair does not fit (before any launch).
+int launch_w0_fold_pair(DeviceWeight & g, DeviceWeight & u, const float * x, int64_t ldx, int64_t T, float * h, int64_t ldh,
+                        int * nf_g, int * nf_u, bool zero_nf, int act, const uint16_t * tab, hipStream_t s) {
+    auto fits = [](const DeviceWeight & w) { return w.w0_closed_form && w.L >= FD_R && (w.L % FD_R) == 0 && w.tall && w0_fold_permuted(w); };
+    if (!fits(g) || !fits(u) || g.n_in != u.n_in || g.n_out != u.n_out || g.L != u.L || g.B != u.B) return 1;
+    if (T <= 0) return SDH_OK;
+    int rc = fold_ensure(g, s);
+    if (rc == SDH_OK) rc = fold_ensure(u, s);
+    if (rc != SDH_OK) return rc;
+    if (!g.fold_perm || !u.fold_perm || g.fold_ng != u.fold_ng) return 1;
+    int64_t T_pad, kz, zcopy; size_t xb;
+    fold_x_layout(g, T, true, T_pad, kz, zcopy, xb);
+    const size_t lds = (size_t) 3 * FD_R * FP_LD * 2 + (size_t) 2 * FD_GS * 2 + (size_t) (g.L / FD_K) * sizeof(int2);
+    if (lds > 160 * 1024) return 1;
+    static const bool attr_ok = [] {
+        bool ok = true;
+        auto set = [&](const void * k) { ok &= hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; };
+        set((const void *) w0p_mfma_kernel<true, false, false, 32, true>); set((const void *) w0p_mfma_kernel<true, false, true, 32, true>);
+        set((const void *) w0p_mfma_kernel<true, true, false, 32, true>); set((const void *) w0p_mfma_kernel<true, true, true, 32, true>);
+        set((const void *) fold_z16_kernel<true>);
+        return ok;
+    }();
+    if (!attr_ok) return 1;
+    _Float16 * zg = (_Float16 *) g.ws, * zu = (_Float16 *) u.ws;
+    const size_t zl = ((size_t) g.n_in * 2 * FZ_T + 15) & ~(size_t) 15;
+    const dim3 zgrid((unsigned) (T_pad / FZ_T), 2);
+    hipLaunchKernelGGL(fold_z16_kernel<true>, zgrid, dim3(FZ_NTH), zl, s, x, ldx, T, (int) g.n_in, (int) g.L, (int) g.B, g.fold_p16, zg, (int) kz, zcopy);
+    hipLaunchKernelGGL(fold_z16_kernel<true>, zgrid, dim3(FZ_NTH), zl, s, x, ldx, T, (int) u.n_in, (int) u.L, (int) u.B, u.fold_p16, zu, (int) kz, zcopy);
+    SDH_HIP_CHECK(hipGetLastError());
+    const dim3 grid((unsigned) ((g.n_out + FD_R - 1) / FD_R), (unsigned) (T_pad / FD_N), 1);
+    if (grid.y > 65535) { set_error("w0 fold: token chunk too large"); return SDH_ERR_UNSUPPORTED; }
+    const FoldSecond sec{zu, u.fold_gp, u.fold_ent, u.fold_off, u.rs, nf_u};
+    const bool atomic = g.fold_dup || u.fold_dup, over = g.fold_over || u.fold_over;     // the general variants are correct for either tensor
+#define SDH_FP2_ARGS zg, zcopy, T, (int) g.n_out, (int) g.L, (int) kz, g.fold_gp, g.fold_ent, g.fold_off, g.fold_ng, g.fold_spb, g.rs, h, ldh, \
+        nf_g, zero_nf ? 1 : 0, (const float *) nullptr, (int64_t) 0, act, tab, sec
+    if (atomic) { if (over) hipLaunchKernelGGL((w0p_mfma_kernel<true, true, true, 32, true>), grid, dim3(512), lds, s, SDH_FP2_ARGS);
+                  else      hipLaunchKernelGGL((w0p_mfma_kernel<true, true, false, 32, true>), grid, dim3(512), lds, s, SDH_FP2_ARGS); }
+    else        { if (over) hipLaunchKernelGGL((w0p_mfma_kernel<true, false, true, 32, true>), grid, dim3(512), lds, s, SDH_FP2_ARGS);
+                  else      hipLaunchKernelGGL((w0p_mfma_kernel<true, false, false, 32, true>), grid, dim3(512), lds, s, SDH_FP2_ARGS); }
+#undef SDH_FP2_ARGS
+    SDH_HIP_CHECK(hipGetLastError());
     return SDH_OK;
 }
 

@@ -145,6 +145,9 @@ def test_ffn_folded_prefill(hip, act, scheme, K, block):
     assert not np.array_equal(bits(y3), bits(y3f)) and np.abs(y3 - y3f).max() <= 2e-2 * np.abs(y3f).max()
     h3 = hip.ffn_gate_up_host(wg, wu, x3, act)
     assert np.array_equal(bits(h3), bits(hip.ffn_gate_up_host(wg, wu, x3, act, hip.FWD_MFMA_FOLD)))
+    # above 256 tokens gate and up are ONE two-pass launch; up to 256 they are two launches: the same bits token by token
+    h2 = hip.ffn_gate_up_host(wg, wu, x3[:256], act, hip.FWD_MFMA_FOLD)
+    assert np.array_equal(bits(h3[:256]), bits(h2))
 
 
 @pytest.mark.parametrize("act", [O.ACT_SILU, O.ACT_GELU])
