@@ -707,7 +707,8 @@ def main():
             kname = "decode_fused_kernel replayed from a hipGraph (base + residual in one launch)"
         elif fused:
             dur_s, n, how = span_ms / 1e3 / launches, launches, "HIP events on the launch stream around the timed region / launches"
-            kname = "decode_fused_kernel (base + residual in one launch)" if T == 1 else \
+            kname = ("decode_direct_kernel (each workgroup forms its rows' base term; one launch)" if seeddelta.last_decode_kind() == 1
+                     else "decode_fused_kernel (base + residual in one launch)") if T == 1 else \
                 "decode_fused_nt_kernel (2-4 tokens in one launch; shapes it does not cover run as two kernels)"
         else:
             seeddelta.profile_enable(True)

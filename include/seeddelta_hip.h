@@ -30,7 +30,7 @@ extern "C" {
 
 /* 2: stream == NULL on device-I/O calls is HIP's legacy default stream (version 1: the library's private stream);
  *    SDH_FWD_NO_SPMM selects the row kernels' arithmetic; sdh_scan_params.reserved0 became kgrid_draws;
- *    sdh_debug_alloc_calls, sdh_debug_fold_layout added. INTEGRATION.md "Migration notes". */
+ *    sdh_debug_alloc_calls, sdh_debug_fold_layout, sdh_debug_last_decode_kind, SDH_FWD_NO_DIRECT added. INTEGRATION.md "Migration notes". */
 #define SDH_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------------------ */
@@ -130,6 +130,10 @@ typedef enum sdh_op_kind {
 #define SDH_FWD_NO_MFMA      0x80  /* never choose SDH_FWD_MFMA_FOLD by default: keep the fp32 forms (the tiled SpMM,
                                       bit-identical to the CPU op, or the rows kernels) at every token count; so do
                                       SDH_FWD_NO_SPMM and SDH_FWD_EXACT_ORDER                                    */
+#define SDH_FWD_NO_DIRECT   0x100  /* one token, payloads with a base: never the launch in which every workgroup forms
+                                      the base term of its own rows (sdh_direct.hip; fp32, within the fast path's bound,
+                                      not the reference's butterfly order): keep the fused launch whose base term has the
+                                      bits of the FWHT form                                                              */
 
 /* ---- library / device ----------------------------------------------------------------
  * sdh_init: bind the calling process to HIP device `device` and create the library's
@@ -205,6 +209,10 @@ int64_t sdh_debug_alloc_calls(void);
  * yet (no folded call so far); else bit 0 set, bit 1 = permuted order (j = inv_b[q]; w0p_mfma_kernel), bit 2 = some (row,
  * input) pair repeats (atomic adds), bit 3 = some bucket holds more than 2048 entries (overflow variant). */
 int     sdh_debug_fold_layout(sdh_weight * w);
+/* Test / measurement hook (no counterpart in the reference): which launch the most recent one-token sdh_forward with a base
+ * took in this process: 1 = direct (every workgroup forms its rows' base term, sdh_direct.hip), 2 = fused (base workgroups
+ * hand over, sdh_decode.hip), 3 = two kernels, 0 = none yet. */
+int     sdh_debug_last_decode_kind(void);
 
 /* Number of non-finite outputs produced by the most recent sdh_forward on this handle
  * (the reference's llama_seeddelta_nan_count, src/llama-seeddelta.cpp:77,382, per call).

@@ -157,6 +157,7 @@ static void free_weight(DeviceWeight * w) {
     (void) hipFree(w->pack_dev); (void) hipFree(w->handoff);
     (void) hipFree(w->G); (void) hipFree(w->inv); (void) hipFree(w->nf_ring); (void) hipFree(w->ws);
     fold_free(*w);
+    direct_free(*w);
     delete w;
 }
 
@@ -660,7 +661,12 @@ static int sdh_forward_impl(sdh_weight * h, const float * x, int64_t ldx, int64_
         if (has_base && tc >= 1 && tc <= MAX_FUSED_TOKENS && !(flags & SDH_FWD_NO_FUSE) && !noalloc) {
             int pair, rc = prof_begin(pair);
             if (rc != SDH_OK) return rc;
-            rc = launch_decode_fused(*w, a, s);
+            rc = (tc == 1 && !(flags & SDH_FWD_NO_DIRECT)) ? launch_decode_direct(*w, a, s) : 1;
+            if (tc == 1) ls.last_decode_kind = rc == SDH_OK ? 1 : 3;
+            if (rc == 1) {
+                rc = launch_decode_fused(*w, a, s);
+                if (tc == 1 && rc == SDH_OK) ls.last_decode_kind = 2;
+            }
             if (rc < 0) return rc;
             if (rc == SDH_OK) {
                 rc = prof_end(pair);
@@ -1136,6 +1142,7 @@ int sdh_forward_noalloc(sdh_weight * h, const float * x, int64_t ldx, int64_t n_
 
 int64_t sdh_noalloc_scratch_bytes(void) { return (int64_t) NOALLOC_SCRATCH_BYTES; }
 int64_t sdh_debug_alloc_calls(void) { return (int64_t) sdh::g_alloc_calls.load(); }
+int sdh_debug_last_decode_kind(void) { return lib().last_decode_kind; }
 int sdh_debug_fold_layout(sdh_weight * h) {
     if (!h) return 0;
     const DeviceWeight * w = reinterpret_cast<const DeviceWeight *>(h);

@@ -1,0 +1,509 @@
+// sdh_direct.hip — batch-1 decode of a SeedDelta weight with a base: every workgroup forms the base term of ITS OWN rows.
+//
+// The fused launch of sdh_decode.hip gives the base transform to B workgroups (one CU per block: two FWHTs of L behind
+// the block's loads) and hands every element over to the residual waves through memory; that chain (≈ 6 us) is what
+// the launch takes, not the 13 MB payload stream (profiles/r03_d_decode_ablation.txt). Here nothing is handed over.
+//
+//   v = H_L D2 H_L z,   z[j] = x_b[p1[j]]                                  (src/llama-seeddelta.cpp:497-574, depth 2, no P2)
+//   H_L = (H_{L/16} (x) I_16) (I (x) H_16), index i = 16 ih + il, so for the 16 rows p = 16 ph + r of one workgroup
+//   v[16 ph + r] = sum_k (-1)^<r,k>  sum_jh D2h[ph ^ jh][k] * Zt[jh][k]
+//   Zt[jh][.]  = H_16 (z[16 jh .. 16 jh + 15])                             one 16-point transform per 16 inputs, in registers
+//   D2h[s][k]  = sum_t (-1)^<s,t> d2[16 t + k]                             a table built once per weight (the H_{L/16} part)
+//
+// i.e. L multiply-adds and L/16 small transforms per base block and workgroup instead of two transforms of L on one CU,
+// and every workgroup reads x (57 KB on cfg3), the permutation (2 bytes per input) and D2h (4 bytes per input) from L2
+// instead of waiting for another CU. The workgroup stages x in LDS once (zero-padded): the permutation gather and the
+// residual's activation gathers both read it there. 16 rows per workgroup, 16 G threads (G lanes per row).
+//
+// Arithmetic: fp32 throughout, but not the reference's butterfly order — the result is within the fast path's bound
+// (a few ulp of sum |terms|), not bit-identical to the FWHT forms; SDH_FWD_EXACT_ORDER and SDH_FWD_NO_DIRECT never come here.
+#include "sdh_internal.h"
+#include "sdh_base_dev.h"
+#include "sdh_delta_dev.h"
+
+#include <algorithm>
+
+namespace sdh {
+
+struct DirectArgs {
+    const unsigned short * p1b;   // [B][L] byte offset (4 * p1[j]) inside the block of the input that permuted position j reads
+    const float * d2h;            // [B][L / 16][16]
+    const float * d3;             // [B][L] or null (all ones)
+    int nseg_blk;                 // L / 16
+    int nblk;                     // base blocks a row sums over: wide B, tall 1
+    int xlen;                     // floats of x staged in LDS, zero past n_in: wide B * L, tall L
+    int base_threads;             // threads that form the base sums (a multiple of 64)
+};
+
+// D2h[b][s][k] = sum_t (-1)^popcount(s & t) d2[b][16 t + k], accumulated in double
+__global__ __launch_bounds__(256) void direct_d2h_kernel(const float * __restrict__ d2, float * __restrict__ d2h, int L) {
+    const int b = blockIdx.y, nseg = L >> 4;
+    const int i = blockIdx.x * 256 + threadIdx.x;            // s * 16 + k
+    if (i >= L) return;
+    const int s = i >> 4, k = i & 15;
+    const float * d = d2 + (size_t) b * L;
+    double acc = 0.0;
+    for (int t = 0; t < nseg; ++t) {
+        const double v = (double) d[16 * t + k];
+        acc += (__popc(s & t) & 1) ? -v : v;
+    }
+    d2h[(size_t) b * L + i] = (float) acc;
+}
+__global__ __launch_bounds__(256) void direct_p1b_kernel(const int * __restrict__ p1, unsigned short * __restrict__ p1b, int n, int L) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int j = p1 ? p1[i] : (i & (L - 1));
+    p1b[i] = (unsigned short) (4 * j);
+}
+
+// ---- the row's payload, loaded before x is staged, used after ------------------------------------------------------------
+template <bool BLOCK, int NS>
+struct RowRegs {
+    Vec8<uint16_t> vv[NS];
+    Vec8<uint16_t> ii[BLOCK ? 1 : NS];
+    int  blk[NS];
+    int  off[NS];
+    bool ok[NS];
+};
+
+template <bool BLOCK, int NS>
+__device__ __forceinline__ void direct_row_load(const DeltaParams & p, int orow, bool row_ok, int l, int G, RowRegs<BLOCK, NS> & r) {
+    const uint16_t * vrow = reinterpret_cast<const uint16_t *>(p.val) + (size_t) orow * p.Ktot;
+    const uint16_t * irow = reinterpret_cast<const uint16_t *>(p.idx) + (size_t) orow * (BLOCK ? p.nb : p.Ktot);
+    int e0[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        const int e = (u * G + l) * 8;
+        r.ok[u] = row_ok & (e < p.Ktot);
+        e0[u] = r.ok[u] ? e : 0;
+    }
+    if constexpr (BLOCK) {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            r.off[u] = e0[u] & (p.block - 1);
+            r.blk[u] = idx_to_i32<uint16_t>(__builtin_nontemporal_load(irow + (e0[u] >> p.block_shift)));
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) r.ii[u].template load<true>(irow + e0[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < NS; ++u) r.vv[u].template load<true>(vrow + e0[u]);
+}
+
+// the operations of delta_row_partial on the loaded row, activations from LDS
+template <bool BLOCK, int NS>
+__device__ __forceinline__ float direct_row_dot(const DeltaParams & p, const float * xs, RowRegs<BLOCK, NS> & r) {
+    float acc = 0.0f;
+    if constexpr (BLOCK) {
+        float4 xa[NS], xb[NS];
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const int raw = (r.blk[u] << p.block_shift) + r.off[u];
+            r.ok[u] = r.ok[u] & ((unsigned) r.blk[u] < (unsigned) p.n_blk_in) & (raw < p.n_in);
+            const int in0 = r.ok[u] ? raw : 0;
+            xa[u] = *reinterpret_cast<const float4 *>(xs + in0);
+            xb[u] = *reinterpret_cast<const float4 *>(xs + in0 + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < NS; ++u) acc = add_if(acc, r.ok[u], dot8<uint16_t>(r.vv[u], xa[u], xb[u]));
+    } else {
+        float xv[NS][8];
+        bool okj[NS][8];
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = idx_to_i32<uint16_t>(r.ii[u].get(j));
+                okj[u][j] = r.ok[u] & ((unsigned) i < (unsigned) p.n_in);
+                xv[u][j] = xs[okj[u][j] ? i : 0];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = add_if(acc, okj[u][j], __fmul_rn(val_to_f32<uint16_t>(r.vv[u].get(j)), xv[u][j]));
+        }
+    }
+    return acc;
+}
+
+// 16-point Walsh-Hadamard transform in registers, two butterflies per packed add
+__device__ __forceinline__ void wht16(float (&z)[16]) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const f32x2 uu = {z[r], z[r]};
+        const f32x2 ww = {z[r + 1], -z[r + 1]};
+        const f32x2 o = uu + ww;
+        z[r] = o.x; z[r + 1] = o.y;
+    }
+#pragma unroll
+    for (int rb = 2; rb < 16; rb <<= 1) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            if ((r & rb) == 0) {
+                const f32x2 a = {z[r], z[r + 1]};
+                const f32x2 b = {z[r | rb], z[(r | rb) + 1]};
+                const f32x2 s = a + b, d = a - b;
+                z[r] = s.x; z[r + 1] = s.y;
+                z[r | rb] = d.x; z[(r | rb) + 1] = d.y;
+            }
+        }
+    }
+}
+
+// One stage of the cross-lane reduce-scatter on lane bit K: N values per lane become N / 2, each the sum of the two
+// lanes' values of one half (the lane whose bit is clear keeps the lower half).
+template <int K, int N>
+__device__ __forceinline__ void scatter_stage(float (&a)[16], int lane) {
+    const bool hi = (lane >> K) & 1;
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) {
+        const float keep = hi ? a[i + N / 2] : a[i];
+        const float send = hi ? a[i] : a[i + N / 2];
+        a[i] = keep + base_lane_xor<K>(send);
+    }
+}
+
+struct DirectSegTabs { uint4 pa, pb; float4 d0, d1, d2, d3; };
+
+__device__ __forceinline__ void direct_tabs_load(DirectSegTabs & t, const DirectArgs & da, int L, int b0, int ph, int sg, int nseg) {
+    const int sgc = sg < nseg ? sg : 0;                      // past the end: a valid address, the result is not used
+    const int bb = sgc / da.nseg_blk, jh = sgc - bb * da.nseg_blk;
+    const size_t blk = (size_t) (b0 + bb) * L;
+    const uint4 * pp = reinterpret_cast<const uint4 *>(da.p1b + blk + (jh << 4));
+    const float4 * dd = reinterpret_cast<const float4 *>(da.d2h + blk + ((ph ^ jh) << 4));
+#ifdef SDH_DD_NOTABLOAD            // dev A/B: the segment's arithmetic without its table loads
+    const unsigned a = (unsigned) (size_t) pp & 0x3FFCu, c = (unsigned) (size_t) dd;
+    t.pa = make_uint4(a, a ^ 0x40, a ^ 0x80, a ^ 0xC0); t.pb = make_uint4(a ^ 0x100, a ^ 0x140, a ^ 0x180, a ^ 0x1C0);
+    t.d0 = make_float4(__uint_as_float(c), 1.0f, 2.0f, 3.0f); t.d1 = t.d0; t.d2 = t.d0; t.d3 = t.d0;
+#else
+    t.pa = pp[0]; t.pb = pp[1];
+    t.d0 = dd[0]; t.d1 = dd[1]; t.d2 = dd[2]; t.d3 = dd[3];
+#endif
+}
+
+// Timeline stamps (dev build -DSDH_DD_STAMPS, tools/direct_stamps.py): lane 0 of the first base wave and of the first row
+// wave keep the 100 MHz real-time counter in registers and store them when the role is over.
+#ifdef SDH_DD_STAMPS
+__device__ unsigned long long dd_stamps[4096 * 2 * 8];
+#define DD_T(k) do { __builtin_amdgcn_sched_barrier(0); tstamp[k] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define DD_DECL unsigned long long tstamp[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define DD_FLUSH(role, cond) do { if (cond) { for (int q_ = 0; q_ < 8; ++q_) dd_stamps[(blockIdx.x * 2 + (role)) * 8 + q_] = tstamp[q_]; } } while (0)
+#else
+#define DD_T(k) do { } while (0)
+#define DD_DECL do { } while (0)
+#define DD_FLUSH(role, cond) do { } while (0)
+#endif
+
+// x -> LDS, zero past n_in. The first pass (4 x 16 bytes per thread) is split in two so that a role can issue its other
+// loads in between: stage_issue first, the role's own loads next, stage_store last. Branch-free (clamped address, select):
+// the compiler's waits stay exact counts. n_in % 4 == 0 and x 16-byte aligned (host).
+template <bool ONEPASS>
+__device__ __forceinline__ void stage_issue(const DeltaParams & p, int tid, int nthr, float4 (&xq)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = (tid + u * nthr) * 4;
+#ifndef SDH_DD_NOX                 // dev A/B (tools/build_variants.sh; results wrong on purpose): LDS zero-filled, x not read
+        xq[u] = *reinterpret_cast<const float4 *>(p.x + (i < p.n_in ? i : 0));
+#else
+        xq[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#endif
+    }
+}
+template <bool ONEPASS>
+__device__ __forceinline__ void stage_store(const DeltaParams & p, const DirectArgs & da, float * xs, int tid, int nthr, const float4 (&xq)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = (tid + u * nthr) * 4;
+        const float4 q = i < p.n_in ? xq[u] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (ONEPASS || i < da.xlen) *reinterpret_cast<float4 *>(xs + i) = q;     // ONEPASS: xlen == 16 * nthr exactly (host)
+    }
+    if constexpr (!ONEPASS) {
+        for (int i = (tid + 4 * nthr) * 4; i < da.xlen; i += nthr * 4) {  // narrow workgroups, long x: the rest
+            float4 q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#ifndef SDH_DD_NOX
+            if (i < p.n_in) q = *reinterpret_cast<const float4 *>(p.x + i);
+#endif
+            *reinterpret_cast<float4 *>(xs + i) = q;
+        }
+    }
+}
+
+// Workgroup = 16 rows = 16 G threads (G lanes per row). The first half of the waves forms the base sums, the second half
+// the rows' residual sums, two 64-lane row slots per wave: each role's loads are its own (a wave's loads return in
+// order and its waits count them in order: a wave that had the payload stream ahead of x or the tables in its queue waited
+// for HBM before it could start). Order of issue in both roles: x first.
+template <bool BLOCK, int STEPS, bool ONEPASS>
+__global__ __launch_bounds__(1024)
+void decode_direct_kernel(const DeltaParams p, const DirectArgs da) {
+    extern __shared__ __align__(16) float xs[];              // [xlen] activations, then [8 waves][4][16] partial base sums
+    float * const red = xs + da.xlen;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
+    const int nbw = nthr >> 7;                               // base waves; the others are row waves
+    const int row0 = blockIdx.x * 16;
+    const int L = p.L;
+    const int b0 = p.tall ? row0 / L : 0;
+
+    if (wave < nbw) {
+        // ---- base role: acc[k] = sum over this thread's segments of D2h[ph ^ jh][k] * Zt[jh][k] ----------------------------
+        const int ph = (row0 - b0 * L) >> 4;
+        const int nseg = da.nblk * da.nseg_blk;
+        const int bt = nbw * 64;
+        DD_DECL;
+        DD_T(0);
+        float4 xq[4];
+        stage_issue<ONEPASS>(p, tid, nthr, xq);
+        // The CU's vector-memory front end takes the waves' requests in order, 64 bytes a clock: tables requested here
+        // (96 KB per workgroup) would stand ahead of the x requests of the row waves, which start a little later, and the
+        // barrier below waits for those. So: x first, stored, and only then the tables (in flight across the barrier).
+        stage_store<ONEPASS>(p, da, xs, tid, nthr, xq);
+        __builtin_amdgcn_sched_barrier(0);
+        DirectSegTabs tb0, tb1;
+        direct_tabs_load(tb0, da, L, b0, ph, tid, nseg);
+        direct_tabs_load(tb1, da, L, b0, ph, tid + bt, nseg);
+        DD_T(1);
+        __syncthreads();
+        DD_T(2);
+        float acc[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
+#ifndef SDH_DD_NOBASE              // dev A/B: no base sums
+        auto segment = [&](const DirectSegTabs & t, int sg, bool valid) {
+            const int bb = sg / da.nseg_blk;
+            const char * xb = reinterpret_cast<const char *>(xs) + (p.tall ? 0 : (size_t) bb * L * 4);
+            const unsigned pw[8] = {t.pa.x, t.pa.y, t.pa.z, t.pa.w, t.pb.x, t.pb.y, t.pb.z, t.pb.w};
+            float z[16];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#ifdef SDH_DD_NOGATHER             // dev A/B: no LDS gather (the offsets stand in for the values)
+                z[2 * i]     = __uint_as_float(pw[i] & 0xFFFFu);
+                z[2 * i + 1] = __uint_as_float(pw[i] >> 16);
+#else
+                z[2 * i]     = *reinterpret_cast<const float *>(xb + (pw[i] & 0xFFFFu));
+                z[2 * i + 1] = *reinterpret_cast<const float *>(xb + (pw[i] >> 16));
+#endif
+            }
+#ifndef SDH_DD_NOWHT               // dev A/B: no 16-point transforms
+            wht16(z);
+#endif
+            const float dv[16] = {t.d0.x, t.d0.y, t.d0.z, t.d0.w, t.d1.x, t.d1.y, t.d1.z, t.d1.w,
+                                  t.d2.x, t.d2.y, t.d2.z, t.d2.w, t.d3.x, t.d3.y, t.d3.z, t.d3.w};
+            if (valid) {                                     // a trip's second segment may lie past the end (uniform per wave from L = 1024 on)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[k] = __builtin_fmaf(dv[k], z[k], acc[k]);
+            }
+        };
+        for (int sg = tid; sg < nseg; sg += 2 * bt) {
+            if (sg != tid) {                                 // later trips (narrow workgroups): loaded here, latency not hidden
+                direct_tabs_load(tb0, da, L, b0, ph, sg, nseg);
+                direct_tabs_load(tb1, da, L, b0, ph, sg + bt, nseg);
+            }
+            segment(tb0, sg, true);
+            segment(tb1, sg + bt < nseg ? sg + bt : 0, sg + bt < nseg);
+        }
+#endif
+        DD_T(3);
+        // across the lanes, reduce-scatter: each step halves the values a lane holds and adds the partner's half. Lane bits 5
+        // and 4 by half-register swaps (the swap is the exchange: one swap and one add per pair), bits 1 and 0 by DPP moves;
+        // the four lanes that differ in bits 2 and 3 keep separate partial sums (the row waves add them up).
+#ifndef SDH_DD_NOSCATTER           // dev A/B: no cross-lane reduction
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = swap32_add(acc[i], acc[i + 8]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = swap16_add(acc[i], acc[i + 4]);
+        {
+            const bool hi = (lane & 2) != 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float keep = hi ? acc[i + 2] : acc[i], send = hi ? acc[i] : acc[i + 2];
+                acc[i] = keep + dpp_partner<0x4E>(send);                          // quad_perm [2,3,0,1]
+            }
+        }
+        {
+            const bool hi = (lane & 1) != 0;
+            const float keep = hi ? acc[1] : acc[0], send = hi ? acc[0] : acc[1];
+            acc[0] = keep + dpp_partner<0xB1>(send);                              // quad_perm [1,0,3,2]
+        }
+#endif
+        const int k = (((lane >> 5) & 1) << 3) | (((lane >> 4) & 1) << 2) | (lane & 3);
+        red[(wave * 4 + ((lane >> 2) & 3)) * 16 + k] = acc[0];
+        DD_T(4);
+        __syncthreads();
+        DD_T(5);
+        DD_FLUSH(0, tid == 0);
+        return;
+    }
+
+    // ---- row role: two 64-lane slots of rows per wave ------------------------------------------------------------------------
+    const int G = p.G, l = lane & (G - 1);
+    int rloc[2], o[2];
+    bool row_ok[2], leader[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        rloc[u] = ((wave - nbw) * 2 + u) * (64 / G) + lane / G;
+        o[u] = row0 + rloc[u];
+        row_ok[u] = o[u] < p.n_out;
+        leader[u] = row_ok[u] && l == 0;
+    }
+    DD_DECL;
+    DD_T(0);
+    float4 xq[4];
+    stage_issue<ONEPASS>(p, tid, nthr, xq);
+    __builtin_amdgcn_sched_barrier(0);
+    RowRegs<BLOCK, STEPS> rr[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#ifdef SDH_DD_NODELTA              // dev A/B: no payload stream
+        direct_row_load<BLOCK, STEPS>(p, 0, row_ok[u], l, G, rr[u]);
+#else
+        direct_row_load<BLOCK, STEPS>(p, row_ok[u] ? o[u] : 0, row_ok[u], l, G, rr[u]);
+#endif
+    }
+    stage_store<ONEPASS>(p, da, xs, tid, nthr, xq);          // nothing conditional has been issued so far: the waits for x are exact
+    DD_T(1);
+    __syncthreads();
+    DD_T(2);
+    float scale[2] = {1.0f, 1.0f}, s3[2] = {1.0f, 1.0f};     // first used at the very end
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (leader[u] && p.rs) scale[u] = p.rs[o[u]];
+        if (leader[u] && da.d3) s3[u] = da.d3[o[u]];         // tall: block b0, position o - b0 L; wide: no d3 here (host)
+    }
+    float dsum[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#ifdef SDH_DD_NODOT                // dev A/B: payload loaded, not multiplied
+        dsum[u] = __uint_as_float(rr[u].vv[0].q.x ^ rr[u].vv[STEPS - 1].q.w);
+#else
+        dsum[u] = direct_row_dot<BLOCK, STEPS>(p, xs, rr[u]);
+#endif
+        dsum[u] = group_reduce(dsum[u], G);
+    }
+    DD_T(3);
+    __syncthreads();
+    DD_T(4);
+    // the 16 sums, then H_16 across the lanes: lane r (mod 16) ends with v[16 ph + r]. Cross-lane moves by half-register
+    // swaps and DPP only: no LDS round trip stands between the barrier and the store.
+    const int kk = lane & 15;
+    float sv = 0.0f;
+    {
+        float part[8];                                       // all reads in flight together (at most 8 base waves x 4 partials / 4 lane groups)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = (lane >> 4) + 4 * q;
+            part[q] = red[(e < nbw * 4 ? e : 0) * 16 + kk];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sv += ((lane >> 4) + 4 * q < nbw * 4) ? part[q] : 0.0f;
+    }
+    sv = swap16_add(sv, sv);
+    sv = swap32_add(sv, sv);                                 // every 16-lane row now holds the 16 sums
+    {
+        float partner;
+        partner = dpp_partner<0xB1>(sv);         sv = (lane & 1) ? partner - sv : partner + sv;
+        partner = dpp_partner<0x4E>(sv);         sv = (lane & 2) ? partner - sv : partner + sv;
+        partner = lane_xor_partner(sv, 4, lane); sv = (lane & 4) ? partner - sv : partner + sv;
+        partner = lane_xor_partner(sv, 8, lane); sv = (lane & 8) ? partner - sv : partner + sv;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        float vrow;
+        if (G == 64) vrow = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sv), rloc[u] & 15));   // one row per slot: uniform
+        else         vrow = __shfl(sv, rloc[u] & 15, 64);
+        if (leader[u]) store_output(p, o[u], 0, vrow * s3[u] + dsum[u], scale[u]);
+    }
+    DD_T(5);
+    DD_FLUSH(1, tid == nbw * 64);
+}
+
+// ---- host ---------------------------------------------------------------------------------------------------------------
+static int direct_ensure(DeviceWeight & w, hipStream_t s) {
+    if (w.dir_d2h) return SDH_OK;
+    const size_t n = (size_t) w.B * (size_t) w.L;
+    float * d2h = nullptr; unsigned short * p1b = nullptr;
+    SDH_HIP_CHECK(hipMalloc((void **) &d2h, n * sizeof(float)));
+    if (hipMalloc((void **) &p1b, n * sizeof(unsigned short)) != hipSuccess) { (void) hipFree(d2h); set_error("direct decode: out of device memory"); return SDH_ERR_HIP; }
+    hipLaunchKernelGGL(direct_d2h_kernel, dim3((unsigned) ((w.L + 255) / 256), (unsigned) w.B), dim3(256), 0, s, w.d2, d2h, (int) w.L);
+    hipLaunchKernelGGL(direct_p1b_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, w.p1, p1b, (int) n, (int) w.L);
+    if (hipGetLastError() != hipSuccess) { (void) hipFree(d2h); (void) hipFree(p1b); set_error("direct decode: table kernels failed"); return SDH_ERR_HIP; }
+    w.dir_d2h = d2h; w.dir_p1b = p1b;
+    return SDH_OK;
+}
+void direct_free(DeviceWeight & w) {
+    (void) hipFree(w.dir_d2h); (void) hipFree(w.dir_p1b);
+    w.dir_d2h = nullptr; w.dir_p1b = nullptr;
+}
+
+template <bool BLOCK, bool ONEPASS>
+static int direct_launch_steps(int steps, const DeltaParams & p, const DirectArgs & da, unsigned grid, unsigned nthr, size_t lds, hipStream_t s) {
+    static const bool attr_ok = [] {
+        bool ok = true;
+        auto set = [&](const void * k) { ok &= hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; };
+        set((const void *) decode_direct_kernel<BLOCK, 1, ONEPASS>); set((const void *) decode_direct_kernel<BLOCK, 2, ONEPASS>);
+        set((const void *) decode_direct_kernel<BLOCK, 3, ONEPASS>); set((const void *) decode_direct_kernel<BLOCK, 4, ONEPASS>);
+        return ok;
+    }();
+    if (!attr_ok) return 1;
+    switch (steps) {
+        case 1: hipLaunchKernelGGL((decode_direct_kernel<BLOCK, 1, ONEPASS>), dim3(grid), dim3(nthr), lds, s, p, da); break;
+        case 2: hipLaunchKernelGGL((decode_direct_kernel<BLOCK, 2, ONEPASS>), dim3(grid), dim3(nthr), lds, s, p, da); break;
+        case 3: hipLaunchKernelGGL((decode_direct_kernel<BLOCK, 3, ONEPASS>), dim3(grid), dim3(nthr), lds, s, p, da); break;
+        default: hipLaunchKernelGGL((decode_direct_kernel<BLOCK, 4, ONEPASS>), dim3(grid), dim3(nthr), lds, s, p, da); break;
+    }
+    SDH_HIP_CHECK(hipGetLastError());
+    return SDH_OK;
+}
+
+// Returns SDH_OK if launched, 1 if the payload / call does not qualify (caller takes the fused launch), <0 on error.
+int launch_decode_direct(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s) {
+    static const bool off = [] { const char * e = getenv("SDH_DECODE_DIRECT"); return e && atoi(e) == 0; }();       // A/B switch
+    if (off || a.T != 1 || a.exact_order) return 1;
+    const bool is_block = (w.kind == SDH_OP_BASE_BLOCK);
+    if (!is_block && w.kind != SDH_OP_BASE_COO) return 1;
+    if (w.idx_type != SDH_TYPE_I16 || w.val_type != SDH_TYPE_F16) return 1;
+    if (!w.w0_closed_form || !w.d2 || w.pack.off_d1 >= 0 || w.p2) return 1;
+    if (w.L < 256 || w.L > 16384 || (w.L & (w.L - 1)) != 0) return 1;
+    if ((w.n_in % 4) != 0 || (w.n_out % 16) != 0) return 1;
+    if (!w.tall && (w.n_out > w.L || w.pack.off_d3 >= 0)) return 1;    // wide: the blocks' sums are formed before d3 could apply
+    const int64_t xlen = w.tall ? w.L : w.B * w.L;
+    if (w.n_in > xlen) return 1;
+    const size_t lds = (size_t) xlen * 4 + 8 * 64 * 4;
+    if (lds > 150 * 1024) return 1;
+    DeltaParams p = make_delta_params(w, a);
+    if (!p.x_vec_ok) return 1;
+    int G = 1, steps = 0;
+    if (!delta_vector_shape(p, is_block, &G, &steps) || steps < 1 || steps > 4 || G < 8) return 1;
+    p.G = G;
+    if (!w.dir_d2h) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return 1;   // tables are built by an eager call
+        const int rc = direct_ensure(w, s);
+        if (rc != SDH_OK) return rc;
+    }
+    DirectArgs da{};
+    da.p1b = w.dir_p1b; da.d2h = w.dir_d2h;
+    da.d3 = w.pack.off_d3 >= 0 ? w.d3 : nullptr;
+    da.nseg_blk = (int) (w.L / 16);
+    da.nblk = w.tall ? 1 : (int) w.B;
+    da.xlen = (int) xlen;
+    const unsigned nthr = 16u * (unsigned) G;
+    const int nseg = da.nblk * da.nseg_blk;
+    da.base_threads = (int) nthr / 2;
+    const unsigned grid = (unsigned) (w.n_out / 16);
+    // x staged by exactly one pass of 4 x 16 bytes per thread. Longer x per thread (wide payloads with short rows: Mistral
+    // down COO K = 128 is 256 threads for 16384 inputs) measured slower than the fused launch (9.1 against 6.6 us): four
+    // waves fetch the workgroup's 200 KB. Those keep the fused launch.
+    if (xlen != 16 * (int64_t) nthr) return 1;
+    return is_block ? direct_launch_steps<true, true>(steps, p, da, grid, nthr, lds, s)
+                    : direct_launch_steps<false, true>(steps, p, da, grid, nthr, lds, s);
+}
+
+} // namespace sdh
+
+#ifdef SDH_DD_STAMPS
+extern "C" int sdh_debug_direct_stamps(unsigned long long * out, int n_wg) {
+    return (int) hipMemcpyFromSymbol(out, HIP_SYMBOL(sdh::dd_stamps), (size_t) n_wg * 16 * sizeof(unsigned long long));
+}
+#endif

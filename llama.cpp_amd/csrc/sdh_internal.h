@@ -101,6 +101,9 @@ struct DeviceWeight {
     bool fold_perm = false;      // the buckets are in the permuted input order j = inv_b[q] (x is permuted by the pre-pass, the W0 tile is
     short * fold_p16 = nullptr;  // [B][L] the input each permuted column multiplies (index into the row of x), -1 = none
     _Float16 * fold_gp = nullptr;// then a plain XOR-circulant of G_b: copied from fold_gp [B][8][L], fold_gp[b][c][i] = f16(G_b[i ^ c]))
+    // batch-1 decode with the base term formed by the row workgroups themselves (sdh_direct.hip), built on first use
+    float * dir_d2h = nullptr;            // [B][L/16][16] d2 transformed over the upper index bits
+    unsigned short * dir_p1b = nullptr;   // [B][L] 4 * perm1
 };
 
 struct LibState {
@@ -120,6 +123,7 @@ struct LibState {
     uint16_t * gelu_tab = nullptr;      // [65536] device
     float * ffn_ws = nullptr; size_t ffn_ws_bytes = 0;
     int ffn_last_fused = 0;             // the last gate/up evaluation ran as the single gate|up launch
+    int last_decode_kind = 0;           // sdh_debug_last_decode_kind: 1 direct, 2 fused, 3 two kernels
     // measurement hooks (sdh_profile_*): event pairs around the dominant kernel
     bool   prof_on = false;
     static constexpr int PROF_PAIRS = 4096;
@@ -193,6 +197,10 @@ int launch_delta_spmm(const DeviceWeight & w, const DeltaLaunch & a, hipStream_t
 // Batch-1 decode with a base as ONE launch (sdh_decode.hip). Returns SDH_OK if launched, 1 if the
 // payload / call does not qualify (caller runs base + delta kernels instead), <0 on error.
 int launch_decode_fused(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s);
+// One token, closed-form base without d1: every 16-row workgroup forms its rows' base term itself (no hand-off).
+// Returns SDH_OK if launched, 1 if the payload / call does not qualify, <0 on error.
+int launch_decode_direct(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s);
+void direct_free(DeviceWeight & w);
 // 1..MAX_FUSED_TOKENS tokens, gate and up tall base payloads of one shape: h[t][o] = act(gate(x_t)[o]) * up(x_t)[o] in
 // one launch. Returns SDH_OK, 1 if the pair does not qualify, <0 on error. nf_g / nf_u: the two nodes' counters.
 int launch_decode_pair(DeviceWeight & g, DeviceWeight & u, int act, const uint16_t * gelu_tab,

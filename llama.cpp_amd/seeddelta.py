@@ -28,13 +28,14 @@ SDH_TYPE = {np.dtype(np.float32): 0, np.dtype(np.float16): 1, np.dtype(np.int16)
 
 FWD_DEVICE_IO, FWD_HOST_IO, FWD_ZERO_NONFINITE, FWD_EXACT_ORDER, FWD_W0_MFMA, FWD_NO_FUSE, FWD_NO_SPMM = 0x0, 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
 FWD_NO_MFMA = 0x80            # keep the fp32 forms where sdh_forward would choose the folded contraction by itself
+FWD_NO_DIRECT = 0x100         # one token: keep the fused launch (base term with the bits of the FWHT form), not the direct one
 FWD_MFMA_FOLD = 0x40          # prefill as one dense contraction, residual folded into the W0 tile (f16 operands)
 
 # every symbol include/seeddelta_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "sdh_init", "sdh_abi_version", "sdh_last_error", "sdh_device_synchronize", "sdh_library_stream",
     "sdh_weight_create", "sdh_weight_destroy", "sdh_weight_op_kind", "sdh_weight_payload_bytes",
-    "sdh_forward", "sdh_forward_noalloc", "sdh_noalloc_scratch_bytes", "sdh_debug_alloc_calls", "sdh_debug_fold_layout", "sdh_probe_stream_floor", "sdh_nonfinite_count", "sdh_w0_tile", "sdh_ffn_forward", "sdh_ffn_gate_up", "sdh_ffn_last_fused", "sdh_glu",
+    "sdh_forward", "sdh_forward_noalloc", "sdh_noalloc_scratch_bytes", "sdh_debug_alloc_calls", "sdh_debug_fold_layout", "sdh_debug_last_decode_kind", "sdh_probe_stream_floor", "sdh_nonfinite_count", "sdh_w0_tile", "sdh_ffn_forward", "sdh_ffn_gate_up", "sdh_ffn_last_fused", "sdh_glu",
     "sdh_ffn_stack_create", "sdh_ffn_stack_destroy", "sdh_ffn_stack_forward", "sdh_ffn_stack_status", "sdh_ffn_stack_payload_bytes",
     "sdh_profile_enable", "sdh_profile_read", "sdh_profile_span_begin", "sdh_profile_span_end",
     "sdh_dense_create", "sdh_dense_destroy", "sdh_dense_bytes",
@@ -127,6 +128,7 @@ def load_library(path: str = LIB_PATH):
     lib.sdh_noalloc_scratch_bytes.restype = C.c_int64
     lib.sdh_debug_alloc_calls.restype = C.c_int64
     lib.sdh_debug_fold_layout.restype = C.c_int
+    lib.sdh_debug_last_decode_kind.restype = C.c_int
     lib.sdh_debug_fold_layout.argtypes = [C.c_void_p]
     lib.sdh_ffn_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64,
                                     C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
@@ -382,6 +384,11 @@ class FfnStack:
             self.close()
         except Exception:
             pass
+
+
+def last_decode_kind() -> int:
+    """which launch the last one-token forward with a base took: 1 direct, 2 fused, 3 two kernels, 0 none yet"""
+    return int(load_library().sdh_debug_last_decode_kind())
 
 
 def ffn_last_fused() -> bool:

@@ -238,7 +238,7 @@ def test_fused_decode_matches_two_launch_path(hip, cfg):
     xs = make_x(p.n_in, 6, seed=21)
     for i in range(6):
         x = xs[i:i + 1]
-        y_fused = w.forward_host(x)
+        y_fused = w.forward_host(x, hip.FWD_NO_DIRECT)      # the fused launch (by default one token may take the direct one)
         y_two = w.forward_host(x, hip.FWD_NO_FUSE)
         assert np.array_equal(bits(y_fused), bits(y_two)), f"{cfg} call {i}"
         assert w.nonfinite_count() == 0
@@ -251,7 +251,7 @@ def test_fused_decode_matches_two_launch_path(hip, cfg):
     sp = torch.cuda.current_stream().cuda_stream
     for rep in range(50):
         for i in range(6):
-            w.forward_device(xd[i].data_ptr(), p.n_in, 1, yd[i].data_ptr(), p.n_out, stream=sp)
+            w.forward_device(xd[i].data_ptr(), p.n_in, 1, yd[i].data_ptr(), p.n_out, hip.FWD_NO_DIRECT, stream=sp)
     torch.cuda.synchronize()
     y_all = yd.cpu().numpy()
     for i in range(6):
@@ -276,17 +276,17 @@ def test_fused_decode_under_graph_capture(hip, cfg):
     ye = torch.zeros((1, p.n_out), dtype=torch.float32, device="cuda")
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
-        w.forward_device(xd.data_ptr(), p.n_in, 1, yd.data_ptr(), p.n_out, stream=side.cuda_stream)   # census, eager
+        w.forward_device(xd.data_ptr(), p.n_in, 1, yd.data_ptr(), p.n_out, hip.FWD_NO_DIRECT, stream=side.cuda_stream)   # census, eager
         side.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=side):
-            w.forward_device(xd.data_ptr(), p.n_in, 1, yd.data_ptr(), p.n_out,
+            w.forward_device(xd.data_ptr(), p.n_in, 1, yd.data_ptr(), p.n_out, hip.FWD_NO_DIRECT,
                              stream=torch.cuda.current_stream().cuda_stream)
         for i in range(4):
             xd.copy_(torch.from_numpy(xs[i:i + 1]), non_blocking=False)
             g.replay()
             if i == 2:                       # an eager launch of the same weight between two replays
-                w.forward_device(xe.data_ptr(), p.n_in, 1, ye.data_ptr(), p.n_out, stream=side.cuda_stream)
+                w.forward_device(xe.data_ptr(), p.n_in, 1, ye.data_ptr(), p.n_out, hip.FWD_NO_DIRECT, stream=side.cuda_stream)
             side.synchronize()
             assert np.array_equal(bits(yd.cpu().numpy()), bits(want[i])), f"{cfg} replay {i}"
         assert np.array_equal(bits(ye.cpu().numpy()), bits(want[4]))
@@ -302,13 +302,13 @@ def test_fused_decode_under_graph_capture(hip, cfg):
 def test_small_batch_decode_is_one_launch_and_bit_identical(hip, cfg):
     """2..4 tokens (speculative / batched decode): base workgroups per token and one pass over the payload
     for all tokens, in one launch. Per token the arithmetic is the one-token kernel's, so every token's
-    output equals its own batch-1 result bit for bit (a batch never changes a token's result), call
-    after call, with strided token columns as well; against the oracle the fast-path tolerance holds."""
+    output equals its own batch-1 result through the fused launch bit for bit (SDH_FWD_NO_DIRECT: by default one token
+    may take the direct launch, whose base term is summed in another order), call after call, with strided token columns as well; against the oracle the fast-path tolerance holds."""
     torch = pytest.importorskip("torch")
     p = config_payload(cfg)
     w = hip.SeedDeltaWeight(p)
     xs = make_x(p.n_in, 12, seed=77)
-    single = np.concatenate([w.forward_host(xs[t:t + 1]) for t in range(12)], axis=0)
+    single = np.concatenate([w.forward_host(xs[t:t + 1], hip.FWD_NO_DIRECT) for t in range(12)], axis=0)   # the fused one-token launch
     for T in (2, 3, 4):
         for rep in range(3):
             x = xs[rep * T:(rep + 1) * T]
@@ -477,3 +477,71 @@ def test_null_stream_is_the_default_stream(hip):
     for i in range(4):
         assert np.array_equal(bits(outs[i].cpu().numpy()), bits(want[i])), i
     assert hip.library_stream() != 0
+
+
+DIRECT_CFGS = ["cfg3_mistral_down_block32_k1536", "cfg2_gemma4b_gate_coo_k128", "cfg4_mistral_gate_coo_k128",
+               "cfg4_mistral_gate_block16_k128", "cfg1_gemma1b_gate_block16_k64"]
+
+
+@pytest.mark.parametrize("cfg", DIRECT_CFGS)
+def test_direct_decode_one_token(hip, cfg):
+    """One token, closed-form base without d1: by default every 16-row workgroup forms the base term of its own rows
+    (csrc/sdh_direct.hip) instead of waiting for a base workgroup's hand-off. fp32 in another summation order than the
+    FWHT: the fast path's tolerance against the oracle, not the fused launch's bits (a difference in the low bits is
+    what shows the launch ran); call after call with changing inputs, back to back on a stream, and replayed from a
+    HIP graph the results are its own, bit for bit. SDH_FWD_NO_DIRECT keeps the fused launch."""
+    torch = pytest.importorskip("torch")
+    p = config_payload(cfg)
+    w = hip.SeedDeltaWeight(p)
+    xs = (1.5 * make_x(p.n_in, 6, seed=41)).astype(np.float32)
+    ys = []
+    for i in range(6):
+        x = xs[i:i + 1]
+        y = w.forward_host(x)
+        assert hip.last_decode_kind() == 1, "the direct launch did not run"
+        y_ref = O.forward(p, x, nth=8)
+        check_fast(p, x, y, y_ref)
+        y_fused = w.forward_host(x, hip.FWD_NO_DIRECT)
+        assert hip.last_decode_kind() == 2
+        assert np.array_equal(bits(y_fused), bits(w.forward_host(x, hip.FWD_NO_FUSE)))
+        assert not np.array_equal(bits(y), bits(y_fused))
+        assert np.all(np.abs(y.astype(np.float64) - y_fused) <= fast_tolerance(p, x, y_ref))
+        assert w.nonfinite_count() == 0
+        ys.append(y)
+    xd = torch.from_numpy(xs).cuda()
+    yd = torch.zeros((6, p.n_out), dtype=torch.float32, device="cuda")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for rep in range(30):
+            for i in range(6):
+                w.forward_device(xd[i].data_ptr(), p.n_in, 1, yd[i].data_ptr(), p.n_out, stream=side.cuda_stream)
+        side.synchronize()
+        y_all = yd.cpu().numpy()
+        for i in range(6):
+            assert np.array_equal(bits(y_all[i:i + 1]), bits(ys[i]))
+        xg = torch.zeros((1, p.n_in), dtype=torch.float32, device="cuda")
+        yg = torch.zeros((1, p.n_out), dtype=torch.float32, device="cuda")
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            w.forward_device(xg.data_ptr(), p.n_in, 1, yg.data_ptr(), p.n_out, stream=torch.cuda.current_stream().cuda_stream)
+        for i in range(3):
+            xg.copy_(xd[i:i + 1])
+            g.replay()
+            side.synchronize()
+            assert np.array_equal(bits(yg.cpu().numpy()), bits(ys[i])), f"{cfg} replay {i}"
+
+
+@pytest.mark.parametrize("kw", [dict(scheme="coo", K=64, d13_random=True), dict(scheme="block", K=64, block=16, d13_random=True),
+                                dict(scheme="coo", K=64, perm=False), dict(scheme="coo", K=40)])
+@pytest.mark.parametrize("dims", [(2816, 1024), (1024, 2816), (4096, 4096)])
+def test_direct_decode_declines_or_holds(hip, kw, dims):
+    """Payloads the direct launch does not take (d1 present; wide with d3; rows that need the scalar kernel) keep the fused
+    launch's bits; the ones it takes (no permutation = identity, square shapes) hold the fast path's tolerance."""
+    p = make_payload(dims[0], dims[1], base=True, seed=8, **kw)
+    w = hip.SeedDeltaWeight(p)
+    x = (2.0 * make_x(p.n_in, 1, seed=12)).astype(np.float32)
+    y = w.forward_host(x)
+    check_fast(p, x, y, O.forward(p, x, nth=4))
+    if kw.get("d13_random"):
+        assert np.array_equal(bits(y), bits(w.forward_host(x, hip.FWD_NO_DIRECT)))
+    assert w.nonfinite_count() == 0

@@ -40,7 +40,7 @@ def test_noalloc_matches_forward_two_calls_in_a_row(hip, cfg):
     # second call: smaller (3 tokens), on the scratch the first call left behind
     cases = [(700, 1), (3, 2), (1, 3), (130, 4)]
     xs = [make_x(p.n_in, T, seed=seed) for T, seed in cases]
-    wants = [(ref.forward_host(x, hip.FWD_NO_FUSE | hip.FWD_NO_MFMA), ref.forward_host(x, hip.FWD_NO_MFMA)) for x in xs]   # the fp32 forms: the no-alloc call never folds
+    wants = [(ref.forward_host(x, hip.FWD_NO_FUSE | hip.FWD_NO_MFMA), ref.forward_host(x, hip.FWD_NO_MFMA | hip.FWD_NO_DIRECT)) for x in xs]   # the fp32 forms with the FWHT base: the no-alloc call never folds
     xd = [torch.from_numpy(x).cuda() for x in xs]
     yd = [torch.full((x.shape[0], w.n_out), float("nan"), dtype=torch.float32, device="cuda") for x in xs]
     torch.cuda.synchronize()
