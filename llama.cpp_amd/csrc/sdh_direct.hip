@@ -13,10 +13,26 @@
 // i.e. L multiply-adds and L/16 small transforms per base block and workgroup instead of two transforms of L on one CU,
 // and every workgroup reads x (57 KB on cfg3), the permutation (2 bytes per input) and D2h (4 bytes per input) from L2
 // instead of waiting for another CU. The workgroup stages x in LDS once (zero-padded): the permutation gather and the
-// residual's activation gathers both read it there. 16 rows per workgroup, 16 G threads (G lanes per row).
+// residual's activation gathers both read it there. 16 rows per workgroup, 16 G threads (G lanes per row); the first half
+// of the waves forms the base sums (two segments per thread on cfg3), the second half the rows' residual sums.
+//
+// What it costs and what it is bound by (MI355X, launch period in a stream of launches over 32 rotating payloads;
+// tools/gpu/r03_direct_wl.sh, in-kernel timeline tools/direct_stamps.py):
+//   cfg3 (Mistral down, block 32, K = 1536)  7.04 us   fused launch 7.84     Mistral gate COO K = 128   6.05 / 6.44
+//   Mistral gate block16                      5.51 / 6.12                     Gemma-3 4B gate COO        5.32 / 6.10
+// A CU takes in about 25 bytes a clock from L2 / HBM whatever the mix, and a cfg3 workgroup asks for 204 KB (x 57, p1b 32,
+// D2h 64, payload 49 + indices): the last wave's x is stored ~2.5 us after the workgroup starts, the base sums are done
+// 2 us later, the store follows 0.6 us after that; without the base (x + payload only) the launch is 5.3 us. Arithmetic is
+// not the limit (the 16-point transforms, the gathers and the cross-lane sums together: 0.6 us of the base role). Measured
+// and left out: each workgroup walking x and the tables from its own offset (same time: the L2 is not the narrow place),
+// tables requested together with x (+0.3 us: they stand ahead of the row waves' x in the CU's queue), payload requested
+// ahead of x (+0.25 us), one role for all waves (every wait then counts the other role's loads: 8.0 us), 256-thread
+// workgroups for wide payloads with short rows (9.1 against 6.5 us: those keep the fused launch).
 //
 // Arithmetic: fp32 throughout, but not the reference's butterfly order — the result is within the fast path's bound
-// (a few ulp of sum |terms|), not bit-identical to the FWHT forms; SDH_FWD_EXACT_ORDER and SDH_FWD_NO_DIRECT never come here.
+// (measured <= 0.05 of it), not bit-identical to the FWHT forms; a token's result through this launch therefore differs in
+// the low bits from the same token inside a 2-4 token batch. SDH_FWD_NO_DIRECT keeps the fused launch (whose base term has
+// the FWHT form's bits); SDH_FWD_EXACT_ORDER never comes here.
 #include "sdh_internal.h"
 #include "sdh_base_dev.h"
 #include "sdh_delta_dev.h"
@@ -351,8 +367,18 @@ void decode_direct_kernel(const DeltaParams p, const DirectArgs da) {
     DD_T(0);
     float4 xq[4];
     stage_issue<ONEPASS>(p, tid, nthr, xq);
-    __builtin_amdgcn_sched_barrier(0);
     RowRegs<BLOCK, STEPS> rr[2];
+    // The payload is requested once x is stored, like the base role's tables: a CU takes in ~25 bytes a clock from L2 /
+    // HBM whatever the mix (x + tables + payload: 209 KB per workgroup on cfg3 — that, not arithmetic, is what the launch
+    // takes), and the barrier below waits for the LAST wave's x. Requested ahead of x: 7.33 us per launch, behind: 7.08.
+#ifdef SDH_DD_PAYLOAD_EARLY        // dev A/B
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) direct_row_load<BLOCK, STEPS>(p, row_ok[u] ? o[u] : 0, row_ok[u], l, G, rr[u]);
+#endif
+    stage_store<ONEPASS>(p, da, xs, tid, nthr, xq);          // nothing conditional has been issued so far: the waits for x are exact
+#ifndef SDH_DD_PAYLOAD_EARLY
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
 #ifdef SDH_DD_NODELTA              // dev A/B: no payload stream
@@ -361,7 +387,7 @@ void decode_direct_kernel(const DeltaParams p, const DirectArgs da) {
         direct_row_load<BLOCK, STEPS>(p, row_ok[u] ? o[u] : 0, row_ok[u], l, G, rr[u]);
 #endif
     }
-    stage_store<ONEPASS>(p, da, xs, tid, nthr, xq);          // nothing conditional has been issued so far: the waits for x are exact
+#endif
     DD_T(1);
     __syncthreads();
     DD_T(2);
