@@ -138,7 +138,8 @@ def test_stack_call_under_contention_reports_its_own_timeouts(hip):
     with torch.cuda.stream(side):
         for _ in range(12):
             b = a @ a                                                               # ~10 ms each: the GPU is full for the call below
-    yd.fill_(float("nan"))
+    with torch.cuda.stream(s):                                                      # on the call's stream: ordered before it, whatever the other streams hold
+        yd.fill_(float("nan"))
     st.forward_device(0, xd.data_ptr(), yd.data_ptr(), stream=s.cuda_stream)
     nf, timeouts = st.status()
     y = yd.cpu().numpy()
@@ -148,7 +149,8 @@ def test_stack_call_under_contention_reports_its_own_timeouts(hip):
         print(f"\ncontended stack call: {timeouts} hand-off waits timed out, {nf} non-finite node outputs")
     side.synchronize()
     del b
-    yd.fill_(float("nan"))
+    with torch.cuda.stream(s):
+        yd.fill_(float("nan"))
     st.forward_device(0, xd.data_ptr(), yd.data_ptr(), stream=s.cuda_stream)
     assert st.status() == (0, 0)                                                    # per call, not cumulative
     assert np.array_equal(bits(yd.cpu().numpy()), bits(want))

@@ -36,6 +36,6 @@ for c in fetch:FETCH_SIZE write:WRITE_SIZE; do
 done
 hl_f=$(find $R/gpurun_out/pmc_fetch_hl -name "*counter_collection.csv" | head -1); hl_w=$(find $R/gpurun_out/pmc_write_hl -name "*counter_collection.csv" | head -1)
 st_f=$(find $R/gpurun_out/pmc_fetch_stk -name "*counter_collection.csv" | head -1); st_w=$(find $R/gpurun_out/pmc_write_stk -name "*counter_collection.csv" | head -1)
-python3 $R/tools/pmc_traffic.py $hl_f $hl_w decode_fused $R/gpurun_out/${TAG}_traffic_cfg3.json
+python3 $R/tools/pmc_traffic.py $hl_f $hl_w decode_direct $R/gpurun_out/${TAG}_traffic_cfg3.json
 python3 $R/tools/pmc_traffic.py $st_f $st_w ffn_stack_kernel $R/gpurun_out/${TAG}_traffic_stack.json
 find $R/gpurun_out/pmc_fetch_hl $R/gpurun_out/pmc_write_hl $R/gpurun_out/pmc_fetch_stk $R/gpurun_out/pmc_write_stk -name "*.csv" -size +1M -delete
