@@ -73,7 +73,7 @@ std::mutex g_call_mu;   // one evaluation at a time: contexts that share a model
 // class's crossover (80-320 tokens) run as folded f16 contractions on the matrix cores: ~1e-3 relative per output, as any GPU
 // backend's f16 GEMM, instead of the CPU op's fp32 arithmetic.
 int extra_flags() {
-    static const int f = [] { const char * e = std::getenv("SEEDDELTA_HIP_FP32"); return (e && *e && *e != '0') ? SDH_FWD_NO_MFMA : 0; }();
+    static const int f = [] { const char * e = std::getenv("SEEDDELTA_HIP_FP32"); return (e && *e && *e != '0') ? (SDH_FWD_NO_MFMA | SDH_FWD_NO_DIRECT) : 0; }();
     return f;
 }
                         // (hand-off granules, non-finite ring, workspace) and the library's host-I/O staging
