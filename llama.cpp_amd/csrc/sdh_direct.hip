@@ -27,7 +27,9 @@
 // and left out: each workgroup walking x and the tables from its own offset (same time: the L2 is not the narrow place),
 // tables requested together with x (+0.3 us: they stand ahead of the row waves' x in the CU's queue), payload requested
 // ahead of x (+0.25 us), one role for all waves (every wait then counts the other role's loads: 8.0 us), 256-thread
-// workgroups for wide payloads with short rows (9.1 against 6.5 us: those keep the fused launch).
+// workgroups for wide payloads with short rows (9.1 against 6.5 us: those keep the fused launch), and the gate | up pair of a
+// gated FFN block in this form (16 rows of both tensors per workgroup, 896 workgroups of 512 threads on Mistral dims:
+// 16.95 against 16.22 us per layer with the fused pair launch — 80 KB of x and tables per 16 KB of payload).
 //
 // Arithmetic: fp32 throughout, but not the reference's butterfly order — the result is within the fast path's bound
 // (measured <= 0.05 of it), not bit-identical to the FWHT forms; a token's result through this launch therefore differs in
@@ -213,13 +215,93 @@ __device__ unsigned long long dd_stamps[4096 * 2 * 8];
 #define DD_FLUSH(role, cond) do { } while (0)
 #endif
 
-// x -> LDS, zero past n_in. The first pass (4 x 16 bytes per thread) is split in two so that a role can issue its other
-// loads in between: stage_issue first, the role's own loads next, stage_store last. Branch-free (clamped address, select):
-// the compiler's waits stay exact counts. n_in % 4 == 0 and x 16-byte aligned (host).
-template <bool ONEPASS>
-__device__ __forceinline__ void stage_issue(const DeltaParams & p, int tid, int nthr, float4 (&xq)[4]) {
+// One segment of 16 permuted inputs: gather from the LDS copy of x (xb: the block's first byte), transform, multiply-add.
+__device__ __forceinline__ void direct_segment(float (&acc)[16], const DirectSegTabs & t, const char * xb, bool valid) {
+    const unsigned pw[8] = {t.pa.x, t.pa.y, t.pa.z, t.pa.w, t.pb.x, t.pb.y, t.pb.z, t.pb.w};
+    float z[16];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int i = 0; i < 8; ++i) {
+#ifdef SDH_DD_NOGATHER             // dev A/B: no LDS gather (the offsets stand in for the values)
+        z[2 * i]     = __uint_as_float(pw[i] & 0xFFFFu);
+        z[2 * i + 1] = __uint_as_float(pw[i] >> 16);
+#else
+        z[2 * i]     = *reinterpret_cast<const float *>(xb + (pw[i] & 0xFFFFu));
+        z[2 * i + 1] = *reinterpret_cast<const float *>(xb + (pw[i] >> 16));
+#endif
+    }
+#ifndef SDH_DD_NOWHT               // dev A/B: no 16-point transforms
+    wht16(z);
+#endif
+    const float dv[16] = {t.d0.x, t.d0.y, t.d0.z, t.d0.w, t.d1.x, t.d1.y, t.d1.z, t.d1.w,
+                          t.d2.x, t.d2.y, t.d2.z, t.d2.w, t.d3.x, t.d3.y, t.d3.z, t.d3.w};
+    if (valid) {                                             // a trip's second segment may lie past the end (uniform per wave from L = 1024 on)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[k] = __builtin_fmaf(dv[k], z[k], acc[k]);
+    }
+}
+
+// A base wave's 16 sums across its lanes, reduce-scatter: each step halves the values a lane holds and adds the partner's
+// half. Lane bits 5 and 4 by half-register swaps (the swap is the exchange: one swap and one add per pair), bits 1 and 0 by
+// DPP moves; the four lanes that differ in bits 2 and 3 keep separate partial sums (the row waves add them up).
+// red: [waves][4][16].
+__device__ __forceinline__ void direct_scatter_store(float (&acc)[16], float * red, int wave, int lane) {
+#ifndef SDH_DD_NOSCATTER           // dev A/B: no cross-lane reduction
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = swap32_add(acc[i], acc[i + 8]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = swap16_add(acc[i], acc[i + 4]);
+    {
+        const bool hi = (lane & 2) != 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float keep = hi ? acc[i + 2] : acc[i], send = hi ? acc[i] : acc[i + 2];
+            acc[i] = keep + dpp_partner<0x4E>(send);                          // quad_perm [2,3,0,1]
+        }
+    }
+    {
+        const bool hi = (lane & 1) != 0;
+        const float keep = hi ? acc[1] : acc[0], send = hi ? acc[0] : acc[1];
+        acc[0] = keep + dpp_partner<0xB1>(send);                              // quad_perm [1,0,3,2]
+    }
+#endif
+    const int k = (((lane >> 5) & 1) << 3) | (((lane >> 4) & 1) << 2) | (lane & 3);
+    red[(wave * 4 + ((lane >> 2) & 3)) * 16 + k] = acc[0];
+}
+
+// A row wave: the 16 sums from the base waves' partials, then H_16 across the lanes; lane r (mod 16) returns v[16 ph + r].
+// Cross-lane moves by half-register swaps and DPP only: no LDS round trip stands between the barrier and the store.
+__device__ __forceinline__ float direct_final(const float * red, int nbw, int lane) {
+    const int kk = lane & 15;
+    float sv = 0.0f;
+    float part[8];                                           // all reads in flight together (at most 8 base waves x 4 partials / 4 lane groups)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int e = (lane >> 4) + 4 * q;
+        part[q] = red[(e < nbw * 4 ? e : 0) * 16 + kk];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sv += ((lane >> 4) + 4 * q < nbw * 4) ? part[q] : 0.0f;
+    sv = swap16_add(sv, sv);
+    sv = swap32_add(sv, sv);                                 // every 16-lane row now holds the 16 sums
+    float partner;
+    partner = dpp_partner<0xB1>(sv);         sv = (lane & 1) ? partner - sv : partner + sv;
+    partner = dpp_partner<0x4E>(sv);         sv = (lane & 2) ? partner - sv : partner + sv;
+    partner = lane_xor_partner(sv, 4, lane); sv = (lane & 4) ? partner - sv : partner + sv;
+    partner = lane_xor_partner(sv, 8, lane); sv = (lane & 8) ? partner - sv : partner + sv;
+    return sv;
+}
+__device__ __forceinline__ float direct_pick(float sv, int r, int G) {      // v of row r (0..15) for the lanes of that row
+    if (G == 64) return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sv), r));     // one row per slot: uniform
+    return __shfl(sv, r, 64);
+}
+
+// x -> LDS, zero past n_in: NU x 16 bytes per thread (the host launches only when xlen == 4 * NU * nthr), split in two so
+// that a role can issue its other loads in between: stage_issue first, stage_store when x is needed. Branch-free (clamped
+// address, select): the compiler's waits stay exact counts. n_in % 4 == 0 and x 16-byte aligned (host).
+template <int NU>
+__device__ __forceinline__ void stage_issue(const DeltaParams & p, int tid, int nthr, float4 (&xq)[NU]) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
         const int i = (tid + u * nthr) * 4;
 #ifndef SDH_DD_NOX                 // dev A/B (tools/build_variants.sh; results wrong on purpose): LDS zero-filled, x not read
         xq[u] = *reinterpret_cast<const float4 *>(p.x + (i < p.n_in ? i : 0));
@@ -228,22 +310,12 @@ __device__ __forceinline__ void stage_issue(const DeltaParams & p, int tid, int 
 #endif
     }
 }
-template <bool ONEPASS>
-__device__ __forceinline__ void stage_store(const DeltaParams & p, const DirectArgs & da, float * xs, int tid, int nthr, const float4 (&xq)[4]) {
+template <int NU>
+__device__ __forceinline__ void stage_store(const DeltaParams & p, float * xs, int tid, int nthr, const float4 (&xq)[NU]) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NU; ++u) {
         const int i = (tid + u * nthr) * 4;
-        const float4 q = i < p.n_in ? xq[u] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (ONEPASS || i < da.xlen) *reinterpret_cast<float4 *>(xs + i) = q;     // ONEPASS: xlen == 16 * nthr exactly (host)
-    }
-    if constexpr (!ONEPASS) {
-        for (int i = (tid + 4 * nthr) * 4; i < da.xlen; i += nthr * 4) {  // narrow workgroups, long x: the rest
-            float4 q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#ifndef SDH_DD_NOX
-            if (i < p.n_in) q = *reinterpret_cast<const float4 *>(p.x + i);
-#endif
-            *reinterpret_cast<float4 *>(xs + i) = q;
-        }
+        *reinterpret_cast<float4 *>(xs + i) = i < p.n_in ? xq[u] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
 }
 
@@ -251,7 +323,7 @@ __device__ __forceinline__ void stage_store(const DeltaParams & p, const DirectA
 // the rows' residual sums, two 64-lane row slots per wave: each role's loads are its own (a wave's loads return in
 // order and its waits count them in order: a wave that had the payload stream ahead of x or the tables in its queue waited
 // for HBM before it could start). Order of issue in both roles: x first.
-template <bool BLOCK, int STEPS, bool ONEPASS>
+template <bool BLOCK, int STEPS, int NU>
 __global__ __launch_bounds__(1024)
 void decode_direct_kernel(const DeltaParams p, const DirectArgs da) {
     extern __shared__ __align__(16) float xs[];              // [xlen] activations, then [8 waves][4][16] partial base sums
@@ -269,12 +341,12 @@ void decode_direct_kernel(const DeltaParams p, const DirectArgs da) {
         const int bt = nbw * 64;
         DD_DECL;
         DD_T(0);
-        float4 xq[4];
-        stage_issue<ONEPASS>(p, tid, nthr, xq);
+        float4 xq[NU];
+        stage_issue<NU>(p, tid, nthr, xq);
         // The CU's vector-memory front end takes the waves' requests in order, 64 bytes a clock: tables requested here
         // (96 KB per workgroup) would stand ahead of the x requests of the row waves, which start a little later, and the
         // barrier below waits for those. So: x first, stored, and only then the tables (in flight across the barrier).
-        stage_store<ONEPASS>(p, da, xs, tid, nthr, xq);
+        stage_store<NU>(p, xs, tid, nthr, xq);
         __builtin_amdgcn_sched_barrier(0);
         DirectSegTabs tb0, tb1;
         direct_tabs_load(tb0, da, L, b0, ph, tid, nseg);
@@ -286,65 +358,19 @@ void decode_direct_kernel(const DeltaParams p, const DirectArgs da) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
 #ifndef SDH_DD_NOBASE              // dev A/B: no base sums
-        auto segment = [&](const DirectSegTabs & t, int sg, bool valid) {
-            const int bb = sg / da.nseg_blk;
-            const char * xb = reinterpret_cast<const char *>(xs) + (p.tall ? 0 : (size_t) bb * L * 4);
-            const unsigned pw[8] = {t.pa.x, t.pa.y, t.pa.z, t.pa.w, t.pb.x, t.pb.y, t.pb.z, t.pb.w};
-            float z[16];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-#ifdef SDH_DD_NOGATHER             // dev A/B: no LDS gather (the offsets stand in for the values)
-                z[2 * i]     = __uint_as_float(pw[i] & 0xFFFFu);
-                z[2 * i + 1] = __uint_as_float(pw[i] >> 16);
-#else
-                z[2 * i]     = *reinterpret_cast<const float *>(xb + (pw[i] & 0xFFFFu));
-                z[2 * i + 1] = *reinterpret_cast<const float *>(xb + (pw[i] >> 16));
-#endif
-            }
-#ifndef SDH_DD_NOWHT               // dev A/B: no 16-point transforms
-            wht16(z);
-#endif
-            const float dv[16] = {t.d0.x, t.d0.y, t.d0.z, t.d0.w, t.d1.x, t.d1.y, t.d1.z, t.d1.w,
-                                  t.d2.x, t.d2.y, t.d2.z, t.d2.w, t.d3.x, t.d3.y, t.d3.z, t.d3.w};
-            if (valid) {                                     // a trip's second segment may lie past the end (uniform per wave from L = 1024 on)
-#pragma unroll
-                for (int k = 0; k < 16; ++k) acc[k] = __builtin_fmaf(dv[k], z[k], acc[k]);
-            }
-        };
         for (int sg = tid; sg < nseg; sg += 2 * bt) {
             if (sg != tid) {                                 // later trips (narrow workgroups): loaded here, latency not hidden
                 direct_tabs_load(tb0, da, L, b0, ph, sg, nseg);
                 direct_tabs_load(tb1, da, L, b0, ph, sg + bt, nseg);
             }
-            segment(tb0, sg, true);
-            segment(tb1, sg + bt < nseg ? sg + bt : 0, sg + bt < nseg);
+            const bool two = sg + bt < nseg;
+            const char * xc = reinterpret_cast<const char *>(xs);
+            direct_segment(acc, tb0, xc + (p.tall ? 0 : (size_t) (sg / da.nseg_blk) * L * 4), true);
+            direct_segment(acc, tb1, xc + (p.tall || !two ? 0 : (size_t) ((sg + bt) / da.nseg_blk) * L * 4), two);
         }
 #endif
         DD_T(3);
-        // across the lanes, reduce-scatter: each step halves the values a lane holds and adds the partner's half. Lane bits 5
-        // and 4 by half-register swaps (the swap is the exchange: one swap and one add per pair), bits 1 and 0 by DPP moves;
-        // the four lanes that differ in bits 2 and 3 keep separate partial sums (the row waves add them up).
-#ifndef SDH_DD_NOSCATTER           // dev A/B: no cross-lane reduction
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = swap32_add(acc[i], acc[i + 8]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = swap16_add(acc[i], acc[i + 4]);
-        {
-            const bool hi = (lane & 2) != 0;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const float keep = hi ? acc[i + 2] : acc[i], send = hi ? acc[i] : acc[i + 2];
-                acc[i] = keep + dpp_partner<0x4E>(send);                          // quad_perm [2,3,0,1]
-            }
-        }
-        {
-            const bool hi = (lane & 1) != 0;
-            const float keep = hi ? acc[1] : acc[0], send = hi ? acc[0] : acc[1];
-            acc[0] = keep + dpp_partner<0xB1>(send);                              // quad_perm [1,0,3,2]
-        }
-#endif
-        const int k = (((lane >> 5) & 1) << 3) | (((lane >> 4) & 1) << 2) | (lane & 3);
-        red[(wave * 4 + ((lane >> 2) & 3)) * 16 + k] = acc[0];
+        direct_scatter_store(acc, red, wave, lane);
         DD_T(4);
         __syncthreads();
         DD_T(5);
@@ -365,8 +391,8 @@ void decode_direct_kernel(const DeltaParams p, const DirectArgs da) {
     }
     DD_DECL;
     DD_T(0);
-    float4 xq[4];
-    stage_issue<ONEPASS>(p, tid, nthr, xq);
+    float4 xq[NU];
+    stage_issue<NU>(p, tid, nthr, xq);
     RowRegs<BLOCK, STEPS> rr[2];
     // The payload is requested once x is stored, like the base role's tables: a CU takes in ~25 bytes a clock from L2 /
     // HBM whatever the mix (x + tables + payload: 209 KB per workgroup on cfg3 — that, not arithmetic, is what the launch
@@ -376,7 +402,7 @@ void decode_direct_kernel(const DeltaParams p, const DirectArgs da) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) direct_row_load<BLOCK, STEPS>(p, row_ok[u] ? o[u] : 0, row_ok[u], l, G, rr[u]);
 #endif
-    stage_store<ONEPASS>(p, da, xs, tid, nthr, xq);          // nothing conditional has been issued so far: the waits for x are exact
+    stage_store<NU>(p, xs, tid, nthr, xq);          // nothing conditional has been issued so far: the waits for x are exact
 #ifndef SDH_DD_PAYLOAD_EARLY
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -410,34 +436,10 @@ void decode_direct_kernel(const DeltaParams p, const DirectArgs da) {
     DD_T(3);
     __syncthreads();
     DD_T(4);
-    // the 16 sums, then H_16 across the lanes: lane r (mod 16) ends with v[16 ph + r]. Cross-lane moves by half-register
-    // swaps and DPP only: no LDS round trip stands between the barrier and the store.
-    const int kk = lane & 15;
-    float sv = 0.0f;
-    {
-        float part[8];                                       // all reads in flight together (at most 8 base waves x 4 partials / 4 lane groups)
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int e = (lane >> 4) + 4 * q;
-            part[q] = red[(e < nbw * 4 ? e : 0) * 16 + kk];
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) sv += ((lane >> 4) + 4 * q < nbw * 4) ? part[q] : 0.0f;
-    }
-    sv = swap16_add(sv, sv);
-    sv = swap32_add(sv, sv);                                 // every 16-lane row now holds the 16 sums
-    {
-        float partner;
-        partner = dpp_partner<0xB1>(sv);         sv = (lane & 1) ? partner - sv : partner + sv;
-        partner = dpp_partner<0x4E>(sv);         sv = (lane & 2) ? partner - sv : partner + sv;
-        partner = lane_xor_partner(sv, 4, lane); sv = (lane & 4) ? partner - sv : partner + sv;
-        partner = lane_xor_partner(sv, 8, lane); sv = (lane & 8) ? partner - sv : partner + sv;
-    }
+    const float sv = direct_final(red, nbw, lane);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        float vrow;
-        if (G == 64) vrow = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sv), rloc[u] & 15));   // one row per slot: uniform
-        else         vrow = __shfl(sv, rloc[u] & 15, 64);
+        const float vrow = direct_pick(sv, rloc[u] & 15, G);
         if (leader[u]) store_output(p, o[u], 0, vrow * s3[u] + dsum[u], scale[u]);
     }
     DD_T(5);
@@ -462,21 +464,21 @@ void direct_free(DeviceWeight & w) {
     w.dir_d2h = nullptr; w.dir_p1b = nullptr;
 }
 
-template <bool BLOCK, bool ONEPASS>
+template <bool BLOCK, int NU>
 static int direct_launch_steps(int steps, const DeltaParams & p, const DirectArgs & da, unsigned grid, unsigned nthr, size_t lds, hipStream_t s) {
     static const bool attr_ok = [] {
         bool ok = true;
         auto set = [&](const void * k) { ok &= hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; };
-        set((const void *) decode_direct_kernel<BLOCK, 1, ONEPASS>); set((const void *) decode_direct_kernel<BLOCK, 2, ONEPASS>);
-        set((const void *) decode_direct_kernel<BLOCK, 3, ONEPASS>); set((const void *) decode_direct_kernel<BLOCK, 4, ONEPASS>);
+        set((const void *) decode_direct_kernel<BLOCK, 1, NU>); set((const void *) decode_direct_kernel<BLOCK, 2, NU>);
+        set((const void *) decode_direct_kernel<BLOCK, 3, NU>); set((const void *) decode_direct_kernel<BLOCK, 4, NU>);
         return ok;
     }();
     if (!attr_ok) return 1;
     switch (steps) {
-        case 1: hipLaunchKernelGGL((decode_direct_kernel<BLOCK, 1, ONEPASS>), dim3(grid), dim3(nthr), lds, s, p, da); break;
-        case 2: hipLaunchKernelGGL((decode_direct_kernel<BLOCK, 2, ONEPASS>), dim3(grid), dim3(nthr), lds, s, p, da); break;
-        case 3: hipLaunchKernelGGL((decode_direct_kernel<BLOCK, 3, ONEPASS>), dim3(grid), dim3(nthr), lds, s, p, da); break;
-        default: hipLaunchKernelGGL((decode_direct_kernel<BLOCK, 4, ONEPASS>), dim3(grid), dim3(nthr), lds, s, p, da); break;
+        case 1: hipLaunchKernelGGL((decode_direct_kernel<BLOCK, 1, NU>), dim3(grid), dim3(nthr), lds, s, p, da); break;
+        case 2: hipLaunchKernelGGL((decode_direct_kernel<BLOCK, 2, NU>), dim3(grid), dim3(nthr), lds, s, p, da); break;
+        case 3: hipLaunchKernelGGL((decode_direct_kernel<BLOCK, 3, NU>), dim3(grid), dim3(nthr), lds, s, p, da); break;
+        default: hipLaunchKernelGGL((decode_direct_kernel<BLOCK, 4, NU>), dim3(grid), dim3(nthr), lds, s, p, da); break;
     }
     SDH_HIP_CHECK(hipGetLastError());
     return SDH_OK;
@@ -522,8 +524,8 @@ int launch_decode_direct(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s)
     // down COO K = 128 is 256 threads for 16384 inputs) measured slower than the fused launch (9.1 against 6.6 us): four
     // waves fetch the workgroup's 200 KB. Those keep the fused launch.
     if (xlen != 16 * (int64_t) nthr) return 1;
-    return is_block ? direct_launch_steps<true, true>(steps, p, da, grid, nthr, lds, s)
-                    : direct_launch_steps<false, true>(steps, p, da, grid, nthr, lds, s);
+    return is_block ? direct_launch_steps<true, 4>(steps, p, da, grid, nthr, lds, s)
+                    : direct_launch_steps<false, 4>(steps, p, da, grid, nthr, lds, s);
 }
 
 } // namespace sdh

@@ -25,13 +25,15 @@ def make_layers(hip, n_layers, n_embd, n_ff, scheme, K, block=16, seed=100, d13_
 
 
 def chain_node_by_node(hip, torch, ws, x, act):
-    """the same layers through sdh_ffn_forward, one call per layer, device buffers"""
+    """the same layers through sdh_ffn_forward, one call per layer, device buffers. SDH_FWD_NO_DIRECT: the stack kernel's base
+    terms come from base workgroups running the FWHT, as in the fused launches; the direct one-token launches that
+    sdh_ffn_forward takes by default sum the base term in another order (same bound, other low bits)."""
     n_embd = x.shape[1]
     a = torch.from_numpy(x).cuda()
     b = torch.empty_like(a)
     outs = []
     for wg, wu, wd in ws:
-        hip.ffn_forward_device(wg, wu, wd, act, a.data_ptr(), n_embd, 1, b.data_ptr(), n_embd, 0, 0)
+        hip.ffn_forward_device(wg, wu, wd, act, a.data_ptr(), n_embd, 1, b.data_ptr(), n_embd, hip.FWD_NO_DIRECT, 0)
         torch.cuda.synchronize()
         outs.append(b.cpu().numpy().copy())
         a, b = b, a
