@@ -2,7 +2,7 @@
 random shapes, schemes, dtypes, token counts and flag sets for a time budget; stops at the first mismatch and
 prints the case so that it can be turned into a test. Bars are those of tests/test_gpu_forward.py: EXACT_ORDER and
 the tiled SpMM path (T >= 6, no NO_SPMM) bit-identical to the oracle, the other fast paths within fast_tolerance,
-W0_MFMA within its f16 bound, the folded contraction (SDH_FWD_MFMA_FOLD, and the default / NO_FUSE dispatch where the
+W0_MFMA within its f16 bound, the direct one-token launch (counted as default_direct) within fast_tolerance, the folded contraction (SDH_FWD_MFMA_FOLD, and the default / NO_FUSE dispatch where the
 token count is above the payload class's crossover) within tests/test_gpu_prefill_full.py's fold_bound.
     python3 tools/fuzz_forward.py [seconds] [seed]"""
 import os
@@ -56,10 +56,23 @@ def main():
         block = int(rng.choice([8, 12, 16, 32]))
         K = int(rng.choice([1, 8, 20, 32, 64, 96, 128, 256, 384, 512, 1024, 1536]))
         base = bool(rng.random() < 0.7)
-        T = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 17, 40, 130, 170, 260, 300, 420]))
+        T = int(rng.choice([1, 1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 17, 40, 130, 170, 260, 300, 420]))
+        direct_case = None
+        if T == 1 and rng.random() < 0.6:                  # shapes the direct one-token launch takes: staged x = 256 * lanes per row
+            direct_case = int(rng.integers(4))
+            r8 = lambda lo, hi: int(rng.integers(lo // 8 + 1, hi // 8 + 1)) * 8
+            r16 = lambda lo, hi: int(rng.integers(lo // 16 + 1, hi // 16 + 1)) * 16
+            if direct_case == 0:   n_in, n_out, K = r8(1024, 2048), r16(2048, 6000), 64                             # tall, 8 lanes per row
+            elif direct_case == 1: n_in, n_out, K = r8(2048, 4096), r16(4096, 9000), int(rng.choice([96, 128]))     # tall, 16 lanes
+            elif direct_case == 2: n_in, n_out, K = r8(6144, 8192), r16(1024, 2048), 256                            # wide, 32 lanes, 4 blocks
+            else:                  n_in, n_out, K = r8(14336, 16384), r16(1024, 2048), int(rng.choice([384, 512, 1024, 1536]))   # wide, 64 lanes, 8 blocks
+            block = int(rng.choice([8, 16, 32]))
+            base = True
         kw = dict(scheme=scheme, K=K, block=block, base=base, row_scale=bool(rng.random() < 0.8), d13_random=bool(base and rng.random() < 0.5),
                   seed=int(rng.integers(1 << 30)))
-        if rng.random() < 0.25:
+        if direct_case is not None:
+            kw["d13_random"] = bool(rng.random() < 0.15)
+        elif rng.random() < 0.25:
             kw.update(idx_dtype=np.int32 if rng.random() < 0.5 else np.int16, val_dtype=np.float32 if rng.random() < 0.5 else np.float16)
         if n_in > 32767:
             kw["idx_dtype"] = np.int32
@@ -82,6 +95,8 @@ def main():
         for name, fl in flagsets:
             y = w.forward_host(x, fl)
             folded = base and T >= 5 and name in ("default", "no_fuse", "fold") and w.fold_layout() != 0
+            if base and T == 1 and name == "default" and hip.last_decode_kind() == 1:
+                name = "default_direct"
             exact = not folded and (name == "exact" or (name in ("default", "no_fuse") and T >= 6))
             if folded:
                 name = name if name == "fold" else name + "_folded"
