@@ -29,7 +29,10 @@
 // ahead of x (+0.25 us), one role for all waves (every wait then counts the other role's loads: 8.0 us), 256-thread
 // workgroups for wide payloads with short rows (9.1 against 6.5 us: those keep the fused launch), and the gate | up pair of a
 // gated FFN block in this form (16 rows of both tensors per workgroup, 896 workgroups of 512 threads on Mistral dims:
-// 16.95 against 16.22 us per layer with the fused pair launch — 80 KB of x and tables per 16 KB of payload).
+// 16.95 against 16.22 us per layer with the fused pair launch — 80 KB of x and tables per 16 KB of payload), and 1024-thread
+// workgroups of 64 rows for tall payloads with short rows (x, permutation and transforms shared by four row groups, 88
+// instead of 4 x 48 KB per 64 rows: Mistral gate 6.24 against 6.05 us, Gemma-3 4B gate 6.12 against 5.31 — four small
+// workgroups per CU at different points of their chains overlap better than one large one).
 //
 // Arithmetic: fp32 throughout, but not the reference's butterfly order — the result is within the fast path's bound
 // (measured <= 0.05 of it), not bit-identical to the FWHT forms; a token's result through this launch therefore differs in
