@@ -32,7 +32,10 @@
 // 16.95 against 16.22 us per layer with the fused pair launch — 80 KB of x and tables per 16 KB of payload), and 1024-thread
 // workgroups of 64 rows for tall payloads with short rows (x, permutation and transforms shared by four row groups, 88
 // instead of 4 x 48 KB per 64 rows: Mistral gate 6.24 against 6.05 us, Gemma-3 4B gate 6.12 against 5.31 — four small
-// workgroups per CU at different points of their chains overlap better than one large one).
+// workgroups per CU at different points of their chains overlap better than one large one), and the same launch for 2-4
+// tokens in passes of two (tables and payload kept in registers, x of two tokens in LDS: every token bit-identical to its
+// one-token result, but 128 VGPRs do not hold a role's tables or payload plus two tokens' staging — with as few as 12
+// spilled registers the launch took 17-44 us against 7-15 us for the fused multi-token launches).
 //
 // Arithmetic: fp32 throughout, but not the reference's butterfly order — the result is within the fast path's bound
 // (measured <= 0.05 of it), not bit-identical to the FWHT forms; a token's result through this launch therefore differs in
