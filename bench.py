@@ -36,6 +36,7 @@ for _p in (ROOT, os.path.join(ROOT, "oracle")):
 
 import numpy as np  # noqa: E402
 
+CLOCK_SETTLE_MS = 60.0        # untimed launches before the W warm-up steps of the headline leg (clock ramp)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 achievable)
 
 
@@ -669,7 +670,13 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
-    run_rotation(sp)                            # one-time set-up (census) is not a warm-up step
+    run_rotation(sp)                            # one-time set-up (census, first-use tables) is not a warm-up step
+    # the GPU's clocks take ~20 ms of load to settle (the same command read 7.8 us per launch from a cold
+    # start with --steps 20 and 7.1 us after 50 ms of launches): an untimed settling run of fixed length, whatever W is
+    t_settle = time.perf_counter()
+    while (time.perf_counter() - t_settle) * 1e3 < CLOCK_SETTLE_MS:
+        loop(8)
+        torch.cuda.synchronize()
     loop(warm)
     torch.cuda.synchronize()
     barrier()
@@ -789,7 +796,7 @@ def main():
             "config": {"workload": args.workload, "tokens_per_step": NP * T, "launches_per_step": NP,
                        "step": "one rotation over the distinct payloads", "tokens_per_launch": T,
                        "n_in": n_in, "n_out": n_out, "distinct_payloads": NP, "launch": args.launch,
-                       "parallelism": "replicas only" if world > 1 else "single GPU"},
+                       "clock_settle_ms": CLOCK_SETTLE_MS, "parallelism": "replicas only" if world > 1 else "single GPU"},
             "roofline": roof, "cpu_baseline": cpu,
         }
         detail = dict(line)
