@@ -367,8 +367,8 @@ def run_ffn(args, dev):
             def block_p():
                 for wg, wu, wd in use:
                     seeddelta.ffn_forward_device(wg, wu, wd, seeddelta.ACT_SILU, xT.data_ptr(), n_embd, T, yT.data_ptr(), n_embd, fl, sp)
-            ev_p, _ = timed_on_stream(block_p, 6, st, seeddelta, warm=30 if name == "fp32" else 6)     # (the first variant also brings the clocks up)
-            prefill_layer[name] = ev_p / (6 * len(use))
+            ev_p, _ = timed_on_stream(block_p, 24, st, seeddelta, warm=30 if name == "fp32" else 24)    # (the first variant also brings the clocks up;
+            prefill_layer[name] = ev_p / (24 * len(use))                                                 # 24 + 24 blocks of four layers: ~25 ms per variant, settled clocks)
         prefill_layer = {"tokens": T, "ms_per_layer": prefill_layer,
                          "tokens_per_s_fold": T / prefill_layer["mfma_fold"] * 1e3,
                          "mfma_frac_fold": 2.0 * 3 * n_embd * n_ff * T / (prefill_layer["mfma_fold"] * 1e-3) / (MFMA_F16_PEAK_TFLOPS * 1e12)}

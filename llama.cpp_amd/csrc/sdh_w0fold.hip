@@ -197,8 +197,12 @@ void fold_gp_kernel(const float * __restrict__ G, _Float16 * __restrict__ gp, in
 constexpr int FZ_T = SDH_FZ_T, FZ_NTH = SDH_FZ_NTH;
 template <bool TALL>
 __global__ __launch_bounds__(FZ_NTH)
-void fold_z16_kernel(const float * __restrict__ x, int64_t ldx, int64_t T, int n_in, int L, int B, const short * __restrict__ p16,
-                     _Float16 * __restrict__ z, int kz, int64_t zcopy) {
+void fold_z16_kernel(const float * __restrict__ x, int64_t ldx, int64_t T, int n_in, int L, int B, const short * __restrict__ p16a,
+                     _Float16 * __restrict__ za, int kz, int64_t zcopy,
+                     const short * __restrict__ p16b = nullptr, _Float16 * __restrict__ zb = nullptr) {
+    // blockIdx.z == 1: the second tensor of a pair that shares x and the shape (gate | up of a gated FFN: one launch for both images)
+    const short * __restrict__ p16 = blockIdx.z ? p16b : p16a;
+    _Float16 * __restrict__ z = blockIdx.z ? zb : za;
     extern __shared__ __align__(16) unsigned char fz_smem[];
     _Float16 * xr = (_Float16 *) fz_smem;                          // [FZ_T][n_in]
     const int64_t t0 = FZ_T * (int64_t) blockIdx.x;
@@ -1060,8 +1064,15 @@ int launch_w0_fold_pair(DeviceWeight & g, DeviceWeight & u, const float * x, int
     _Float16 * zg = (_Float16 *) g.ws, * zu = (_Float16 *) u.ws;
     const size_t zl = ((size_t) g.n_in * 2 * FZ_T + 15) & ~(size_t) 15;
     const dim3 zgrid((unsigned) (T_pad / FZ_T), 2);
-    hipLaunchKernelGGL(fold_z16_kernel<true>, zgrid, dim3(FZ_NTH), zl, s, x, ldx, T, (int) g.n_in, (int) g.L, (int) g.B, g.fold_p16, zg, (int) kz, zcopy);
-    hipLaunchKernelGGL(fold_z16_kernel<true>, zgrid, dim3(FZ_NTH), zl, s, x, ldx, T, (int) u.n_in, (int) u.L, (int) u.B, u.fold_p16, zu, (int) kz, zcopy);
+    static const bool one_prepass = getenv("SDH_FOLD_TWO_PREPASSES") == nullptr;       // A/B switch
+    if (one_prepass) {
+        const dim3 zgrid2(zgrid.x, zgrid.y, 2);
+        hipLaunchKernelGGL(fold_z16_kernel<true>, zgrid2, dim3(FZ_NTH), zl, s, x, ldx, T, (int) g.n_in, (int) g.L, (int) g.B, g.fold_p16, zg, (int) kz, zcopy,
+                           u.fold_p16, zu);
+    } else {
+        hipLaunchKernelGGL(fold_z16_kernel<true>, zgrid, dim3(FZ_NTH), zl, s, x, ldx, T, (int) g.n_in, (int) g.L, (int) g.B, g.fold_p16, zg, (int) kz, zcopy);
+        hipLaunchKernelGGL(fold_z16_kernel<true>, zgrid, dim3(FZ_NTH), zl, s, x, ldx, T, (int) u.n_in, (int) u.L, (int) u.B, u.fold_p16, zu, (int) kz, zcopy);
+    }
     SDH_HIP_CHECK(hipGetLastError());
     const dim3 grid((unsigned) ((g.n_out + FD_R - 1) / FD_R), (unsigned) (T_pad / FD_N), 1);
     if (grid.y > 65535) { set_error("w0 fold: token chunk too large"); return SDH_ERR_UNSUPPORTED; }
