@@ -301,7 +301,7 @@ __device__ __forceinline__ float direct_pick(float sv, int r, int G) {      // v
     return __shfl(sv, r, 64);
 }
 
-// x -> LDS, zero past n_in: NU x 16 bytes per thread (the host launches only when xlen == 4 * NU * nthr), split in two so
+// x -> LDS, zero past n_in: NU x 16 bytes per thread (the host launches only when xlen <= 4 * NU * nthr), split in two so
 // that a role can issue its other loads in between: stage_issue first, stage_store when x is needed. Branch-free (clamped
 // address, select): the compiler's waits stay exact counts. n_in % 4 == 0 and x 16-byte aligned (host).
 template <int NU>
@@ -317,11 +317,11 @@ __device__ __forceinline__ void stage_issue(const DeltaParams & p, int tid, int 
     }
 }
 template <int NU>
-__device__ __forceinline__ void stage_store(const DeltaParams & p, float * xs, int tid, int nthr, const float4 (&xq)[NU]) {
+__device__ __forceinline__ void stage_store(const DeltaParams & p, float * xs, int tid, int nthr, int xlen, const float4 (&xq)[NU]) {
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         const int i = (tid + u * nthr) * 4;
-        *reinterpret_cast<float4 *>(xs + i) = i < p.n_in ? xq[u] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (i < xlen) *reinterpret_cast<float4 *>(xs + i) = i < p.n_in ? xq[u] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // xlen < 4 NU nthr: short x
     }
 }
 
@@ -352,7 +352,7 @@ void decode_direct_kernel(const DeltaParams p, const DirectArgs da) {
         // The CU's vector-memory front end takes the waves' requests in order, 64 bytes a clock: tables requested here
         // (96 KB per workgroup) would stand ahead of the x requests of the row waves, which start a little later, and the
         // barrier below waits for those. So: x first, stored, and only then the tables (in flight across the barrier).
-        stage_store<NU>(p, xs, tid, nthr, xq);
+        stage_store<NU>(p, xs, tid, nthr, da.xlen, xq);
         __builtin_amdgcn_sched_barrier(0);
         DirectSegTabs tb0, tb1;
         direct_tabs_load(tb0, da, L, b0, ph, tid, nseg);
@@ -408,7 +408,7 @@ void decode_direct_kernel(const DeltaParams p, const DirectArgs da) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) direct_row_load<BLOCK, STEPS>(p, row_ok[u] ? o[u] : 0, row_ok[u], l, G, rr[u]);
 #endif
-    stage_store<NU>(p, xs, tid, nthr, xq);          // nothing conditional has been issued so far: the waits for x are exact
+    stage_store<NU>(p, xs, tid, nthr, da.xlen, xq);          // nothing conditional has been issued so far: the waits for x are exact
 #ifndef SDH_DD_PAYLOAD_EARLY
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -526,10 +526,10 @@ int launch_decode_direct(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s)
     const int nseg = da.nblk * da.nseg_blk;
     da.base_threads = (int) nthr / 2;
     const unsigned grid = (unsigned) (w.n_out / 16);
-    // x staged by exactly one pass of 4 x 16 bytes per thread. Longer x per thread (wide payloads with short rows: Mistral
+    // x staged by one pass of at most 4 x 16 bytes per thread. Longer x per thread (wide payloads with short rows: Mistral
     // down COO K = 128 is 256 threads for 16384 inputs) measured slower than the fused launch (9.1 against 6.6 us): four
     // waves fetch the workgroup's 200 KB. Those keep the fused launch.
-    if (xlen != 16 * (int64_t) nthr) return 1;
+    if (xlen > 16 * (int64_t) nthr) return 1;
     return is_block ? direct_launch_steps<true, 4>(steps, p, da, grid, nthr, lds, s)
                     : direct_launch_steps<false, 4>(steps, p, da, grid, nthr, lds, s);
 }
