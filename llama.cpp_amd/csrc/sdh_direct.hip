@@ -27,7 +27,9 @@
 // and left out: each workgroup walking x and the tables from its own offset (same time: the L2 is not the narrow place),
 // tables requested together with x (+0.3 us: they stand ahead of the row waves' x in the CU's queue), payload requested
 // ahead of x (+0.25 us), one role for all waves (every wait then counts the other role's loads: 8.0 us), 256-thread
-// workgroups for wide payloads with short rows (9.1 against 6.5 us: those keep the fused launch), and the gate | up pair of a
+// workgroups for wide payloads with short rows (9.1 against 6.5 us: four waves fetch the workgroup's 200 KB — such payloads
+// run with 64 lanes per row instead, most of them idle, so that 1024 threads stage x: Mistral down COO K = 128 5.85 against
+// 6.16 us, block16 5.51 / 6.22, Gemma-3 4B down 5.33 / 6.06), and the gate | up pair of a
 // gated FFN block in this form (16 rows of both tensors per workgroup, 896 workgroups of 512 threads on Mistral dims:
 // 16.95 against 16.22 us per layer with the fused pair launch — 80 KB of x and tables per 16 KB of payload), and 1024-thread
 // workgroups of 64 rows for tall payloads with short rows (x, permutation and transforms shared by four row groups, 88
@@ -522,13 +524,16 @@ int launch_decode_direct(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s)
     da.nseg_blk = (int) (w.L / 16);
     da.nblk = w.tall ? 1 : (int) w.B;
     da.xlen = (int) xlen;
+    // wide payloads with short rows: a long x and few lanes per row. One row per 64-lane slot instead (lanes past the row's
+    // end idle), so that 1024 threads stage x
+    static const bool widen = getenv("SDH_DIRECT_NO_WIDEN") == nullptr;                 // A/B switch
+    if (widen && !w.tall && xlen > 256 * (int64_t) G && xlen <= 16384) { G = 64; steps = (p.Ktot + 511) / 512; p.G = G; }
     const unsigned nthr = 16u * (unsigned) G;
     const int nseg = da.nblk * da.nseg_blk;
     da.base_threads = (int) nthr / 2;
     const unsigned grid = (unsigned) (w.n_out / 16);
-    // x staged by one pass of at most 4 x 16 bytes per thread. Longer x per thread (wide payloads with short rows: Mistral
-    // down COO K = 128 is 256 threads for 16384 inputs) measured slower than the fused launch (9.1 against 6.6 us): four
-    // waves fetch the workgroup's 200 KB. Those keep the fused launch.
+    // x staged by one pass of at most 4 x 16 bytes per thread (wide payloads with short rows were widened to 64 lanes per row
+    // above for this; what still does not fit — more than 16384 staged inputs — keeps the fused launch)
     if (xlen > 16 * (int64_t) nthr) return 1;
     return is_block ? direct_launch_steps<true, 4>(steps, p, da, grid, nthr, lds, s)
                     : direct_launch_steps<false, 4>(steps, p, da, grid, nthr, lds, s);
