@@ -510,7 +510,7 @@ int launch_decode_direct(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s)
     DeltaParams p = make_delta_params(w, a);
     if (!p.x_vec_ok) return 1;
     int G = 1, steps = 0;
-    if (!delta_vector_shape(p, is_block, &G, &steps) || steps < 1 || steps > 4 || G < 8) return 1;
+    if (!delta_vector_shape(p, is_block, &G, &steps) || steps < 1 || steps > 4) return 1;
     p.G = G;
     if (!w.dir_d2h) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -524,10 +524,15 @@ int launch_decode_direct(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s)
     da.nseg_blk = (int) (w.L / 16);
     da.nblk = w.tall ? 1 : (int) w.B;
     da.xlen = (int) xlen;
-    // wide payloads with short rows: a long x and few lanes per row. One row per 64-lane slot instead (lanes past the row's
-    // end idle), so that 1024 threads stage x
+    // short rows and a long x (wide payloads above all): more lanes per row than the row needs (lanes past its end idle), so
+    // that the workgroup has 16 threads per 256 staged inputs
     static const bool widen = getenv("SDH_DIRECT_NO_WIDEN") == nullptr;                 // A/B switch
-    if (widen && !w.tall && xlen > 256 * (int64_t) G && xlen <= 16384) { G = 64; steps = (p.Ktot + 511) / 512; p.G = G; }
+    if (widen && xlen <= 16384) {
+        while (G < 64 && (256 * (int64_t) G < xlen || G < 8)) G <<= 1;
+        steps = (p.Ktot + 8 * G - 1) / (8 * G);
+        p.G = G;
+    }
+    if (G < 8) return 1;                                     // a workgroup is at least one base wave and one row wave
     const unsigned nthr = 16u * (unsigned) G;
     const int nseg = da.nblk * da.nseg_blk;
     da.base_threads = (int) nthr / 2;
