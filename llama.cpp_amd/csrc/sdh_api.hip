@@ -397,7 +397,11 @@ static int sdh_weight_create_impl(const sdh_weight_desc * desc, sdh_weight ** ou
         pd.off_p2 = region(present(p2));
         pd.blk_stride = off;
         if (off > 0) {
-            std::vector<uint8_t> slab((size_t) off * (size_t) B, 0);
+            // behind the parameters: room for the direct one-token launch's tables (sdh_direct.hip: B L floats and B L 16-bit
+            // offsets, filled on the device below): no allocation of their own.
+            const size_t par_bytes = ((size_t) off * (size_t) B + 255) / 256 * 256;
+            const bool tab_room = L >= 256 && L <= 16384 && (L & (L - 1)) == 0;
+            std::vector<uint8_t> slab(par_bytes + (tab_room ? (size_t) L * (size_t) B * 6 : 0), 0);
             auto put_f = [&](int o, const sdh_tensor & src, const std::vector<float> & f32) {
                 if (o < 0) return;
                 for (int64_t b = 0; b < B; ++b) {
@@ -424,6 +428,7 @@ static int sdh_weight_create_impl(const sdh_weight_desc * desc, sdh_weight ** ou
             put_i(pd.off_p2, hp2);
             if ((rc = upload(slab, &w->pack_dev)) != SDH_OK) return fail(rc);
             pd.pack = w->pack_dev;
+            if (tab_room) w->dir_space = w->pack_dev + par_bytes;
         }
         // hand-off buffer of the fused decode kernel: [B][L] granules {value, epoch} (tag 0 = never
         // written; epochs start at 1)
@@ -433,6 +438,12 @@ static int sdh_weight_create_impl(const sdh_weight_desc * desc, sdh_weight ** ou
             if (e == hipSuccess) e = hipMemset(w->handoff, 0, gb);
             if (e != hipSuccess) { set_error("hand-off alloc failed: %s", hipGetErrorString(e)); return fail(SDH_ERR_HIP); }
         }
+    }
+    if (w->kind == SDH_OP_BASE_COO || w->kind == SDH_OP_BASE_BLOCK) {   // tables of the direct one-token launch (payloads that qualify)
+        LibState & ls = lib();
+        int rc = direct_build_tables(*w, ls.stream);
+        if (rc == SDH_OK && hipStreamSynchronize(ls.stream) != hipSuccess) { set_error("direct decode: table kernels failed"); rc = SDH_ERR_HIP; }
+        if (rc != SDH_OK) return fail(rc);
     }
     {
         hipError_t e = hipMalloc((void **) &w->nf_ring, DeviceWeight::NF_SLOTS * sizeof(int));

@@ -318,12 +318,12 @@ __device__ __forceinline__ void stage_issue(const DeltaParams & p, int tid, int 
 #endif
     }
 }
-template <int NU>
+template <int NU, bool FULL>                                 // FULL: xlen == 4 NU nthr — the stores are unconditional and the waits before them exact
 __device__ __forceinline__ void stage_store(const DeltaParams & p, float * xs, int tid, int nthr, int xlen, const float4 (&xq)[NU]) {
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         const int i = (tid + u * nthr) * 4;
-        if (i < xlen) *reinterpret_cast<float4 *>(xs + i) = i < p.n_in ? xq[u] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // xlen < 4 NU nthr: short x
+        if (FULL || i < xlen) *reinterpret_cast<float4 *>(xs + i) = i < p.n_in ? xq[u] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
 }
 
@@ -331,7 +331,7 @@ __device__ __forceinline__ void stage_store(const DeltaParams & p, float * xs, i
 // the rows' residual sums, two 64-lane row slots per wave: each role's loads are its own (a wave's loads return in
 // order and its waits count them in order: a wave that had the payload stream ahead of x or the tables in its queue waited
 // for HBM before it could start). Order of issue in both roles: x first.
-template <bool BLOCK, int STEPS, int NU>
+template <bool BLOCK, int STEPS, int NU, bool FULL>
 __global__ __launch_bounds__(1024)
 void decode_direct_kernel(const DeltaParams p, const DirectArgs da) {
     extern __shared__ __align__(16) float xs[];              // [xlen] activations, then [8 waves][4][16] partial base sums
@@ -354,7 +354,7 @@ void decode_direct_kernel(const DeltaParams p, const DirectArgs da) {
         // The CU's vector-memory front end takes the waves' requests in order, 64 bytes a clock: tables requested here
         // (96 KB per workgroup) would stand ahead of the x requests of the row waves, which start a little later, and the
         // barrier below waits for those. So: x first, stored, and only then the tables (in flight across the barrier).
-        stage_store<NU>(p, xs, tid, nthr, da.xlen, xq);
+        stage_store<NU, FULL>(p, xs, tid, nthr, da.xlen, xq);
         __builtin_amdgcn_sched_barrier(0);
         DirectSegTabs tb0, tb1;
         direct_tabs_load(tb0, da, L, b0, ph, tid, nseg);
@@ -410,7 +410,7 @@ void decode_direct_kernel(const DeltaParams p, const DirectArgs da) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) direct_row_load<BLOCK, STEPS>(p, row_ok[u] ? o[u] : 0, row_ok[u], l, G, rr[u]);
 #endif
-    stage_store<NU>(p, xs, tid, nthr, da.xlen, xq);          // nothing conditional has been issued so far: the waits for x are exact
+    stage_store<NU, FULL>(p, xs, tid, nthr, da.xlen, xq);          // nothing conditional has been issued so far: the waits for x are exact
 #ifndef SDH_DD_PAYLOAD_EARLY
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -455,38 +455,50 @@ void decode_direct_kernel(const DeltaParams p, const DirectArgs da) {
 }
 
 // ---- host ---------------------------------------------------------------------------------------------------------------
-static int direct_ensure(DeviceWeight & w, hipStream_t s) {
-    if (w.dir_d2h) return SDH_OK;
+// The static part of what launch_decode_direct asks of a payload.
+static bool direct_weight_ok(const DeviceWeight & w) {
+    if (w.kind != SDH_OP_BASE_BLOCK && w.kind != SDH_OP_BASE_COO) return false;
+    if (w.idx_type != SDH_TYPE_I16 || w.val_type != SDH_TYPE_F16) return false;
+    if (!w.w0_closed_form || !w.d2 || w.pack.off_d1 >= 0 || w.p2) return false;
+    if (w.L < 256 || w.L > 16384 || (w.L & (w.L - 1)) != 0) return false;
+    if ((w.n_in % 4) != 0 || (w.n_out % 16) != 0) return false;
+    if (!w.tall && (w.n_out > w.L || w.pack.off_d3 >= 0)) return false;      // wide: the blocks' sums are formed before d3 could apply
+    const int64_t xlen = w.tall ? w.L : w.B * w.L;
+    return w.n_in <= xlen && (size_t) xlen * 4 + 8 * 64 * 4 <= 150 * 1024;
+}
+
+// Tables of the direct launch, built when the weight is created (sdh_weight_create) by two small kernels on `s`, into room
+// that sdh_weight_create left behind the packed base parameters (D2h, then the 16-bit offsets): no allocation of their own,
+// and none at the first forward — a forward that allocates cannot be recorded into a graph.
+int direct_build_tables(DeviceWeight & w, hipStream_t s) {
+    static const bool off = [] { const char * e = getenv("SDH_DECODE_DIRECT"); return e && atoi(e) == 0; }();
+    if (off || w.dir_d2h || !w.dir_space || !direct_weight_ok(w)) return SDH_OK;
     const size_t n = (size_t) w.B * (size_t) w.L;
-    float * d2h = nullptr; unsigned short * p1b = nullptr;
-    SDH_HIP_CHECK(hipMalloc((void **) &d2h, n * sizeof(float)));
-    if (hipMalloc((void **) &p1b, n * sizeof(unsigned short)) != hipSuccess) { (void) hipFree(d2h); set_error("direct decode: out of device memory"); return SDH_ERR_HIP; }
+    float * d2h = reinterpret_cast<float *>(w.dir_space);
+    unsigned short * p1b = reinterpret_cast<unsigned short *>(d2h + n);
     hipLaunchKernelGGL(direct_d2h_kernel, dim3((unsigned) ((w.L + 255) / 256), (unsigned) w.B), dim3(256), 0, s, w.d2, d2h, (int) w.L);
     hipLaunchKernelGGL(direct_p1b_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, w.p1, p1b, (int) n, (int) w.L);
-    if (hipGetLastError() != hipSuccess) { (void) hipFree(d2h); (void) hipFree(p1b); set_error("direct decode: table kernels failed"); return SDH_ERR_HIP; }
+    if (hipGetLastError() != hipSuccess) { set_error("direct decode: table kernels failed"); return SDH_ERR_HIP; }
     w.dir_d2h = d2h; w.dir_p1b = p1b;
     return SDH_OK;
 }
-void direct_free(DeviceWeight & w) {
-    (void) hipFree(w.dir_d2h); (void) hipFree(w.dir_p1b);
-    w.dir_d2h = nullptr; w.dir_p1b = nullptr;
-}
+void direct_free(DeviceWeight & w) { w.dir_d2h = nullptr; w.dir_p1b = nullptr; w.dir_space = nullptr; }   // the tables live inside pack_dev
 
-template <bool BLOCK, int NU>
+template <bool BLOCK, int NU, bool FULL>
 static int direct_launch_steps(int steps, const DeltaParams & p, const DirectArgs & da, unsigned grid, unsigned nthr, size_t lds, hipStream_t s) {
     static const bool attr_ok = [] {
         bool ok = true;
         auto set = [&](const void * k) { ok &= hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; };
-        set((const void *) decode_direct_kernel<BLOCK, 1, NU>); set((const void *) decode_direct_kernel<BLOCK, 2, NU>);
-        set((const void *) decode_direct_kernel<BLOCK, 3, NU>); set((const void *) decode_direct_kernel<BLOCK, 4, NU>);
+        set((const void *) decode_direct_kernel<BLOCK, 1, NU, FULL>); set((const void *) decode_direct_kernel<BLOCK, 2, NU, FULL>);
+        set((const void *) decode_direct_kernel<BLOCK, 3, NU, FULL>); set((const void *) decode_direct_kernel<BLOCK, 4, NU, FULL>);
         return ok;
     }();
     if (!attr_ok) return 1;
     switch (steps) {
-        case 1: hipLaunchKernelGGL((decode_direct_kernel<BLOCK, 1, NU>), dim3(grid), dim3(nthr), lds, s, p, da); break;
-        case 2: hipLaunchKernelGGL((decode_direct_kernel<BLOCK, 2, NU>), dim3(grid), dim3(nthr), lds, s, p, da); break;
-        case 3: hipLaunchKernelGGL((decode_direct_kernel<BLOCK, 3, NU>), dim3(grid), dim3(nthr), lds, s, p, da); break;
-        default: hipLaunchKernelGGL((decode_direct_kernel<BLOCK, 4, NU>), dim3(grid), dim3(nthr), lds, s, p, da); break;
+        case 1: hipLaunchKernelGGL((decode_direct_kernel<BLOCK, 1, NU, FULL>), dim3(grid), dim3(nthr), lds, s, p, da); break;
+        case 2: hipLaunchKernelGGL((decode_direct_kernel<BLOCK, 2, NU, FULL>), dim3(grid), dim3(nthr), lds, s, p, da); break;
+        case 3: hipLaunchKernelGGL((decode_direct_kernel<BLOCK, 3, NU, FULL>), dim3(grid), dim3(nthr), lds, s, p, da); break;
+        default: hipLaunchKernelGGL((decode_direct_kernel<BLOCK, 4, NU, FULL>), dim3(grid), dim3(nthr), lds, s, p, da); break;
     }
     SDH_HIP_CHECK(hipGetLastError());
     return SDH_OK;
@@ -496,28 +508,15 @@ static int direct_launch_steps(int steps, const DeltaParams & p, const DirectArg
 int launch_decode_direct(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s) {
     static const bool off = [] { const char * e = getenv("SDH_DECODE_DIRECT"); return e && atoi(e) == 0; }();       // A/B switch
     if (off || a.T != 1 || a.exact_order) return 1;
+    if (!w.dir_d2h) return 1;                                // no tables: the payload does not qualify (direct_build_tables)
     const bool is_block = (w.kind == SDH_OP_BASE_BLOCK);
-    if (!is_block && w.kind != SDH_OP_BASE_COO) return 1;
-    if (w.idx_type != SDH_TYPE_I16 || w.val_type != SDH_TYPE_F16) return 1;
-    if (!w.w0_closed_form || !w.d2 || w.pack.off_d1 >= 0 || w.p2) return 1;
-    if (w.L < 256 || w.L > 16384 || (w.L & (w.L - 1)) != 0) return 1;
-    if ((w.n_in % 4) != 0 || (w.n_out % 16) != 0) return 1;
-    if (!w.tall && (w.n_out > w.L || w.pack.off_d3 >= 0)) return 1;    // wide: the blocks' sums are formed before d3 could apply
     const int64_t xlen = w.tall ? w.L : w.B * w.L;
-    if (w.n_in > xlen) return 1;
     const size_t lds = (size_t) xlen * 4 + 8 * 64 * 4;
-    if (lds > 150 * 1024) return 1;
     DeltaParams p = make_delta_params(w, a);
     if (!p.x_vec_ok) return 1;
     int G = 1, steps = 0;
     if (!delta_vector_shape(p, is_block, &G, &steps) || steps < 1 || steps > 4) return 1;
     p.G = G;
-    if (!w.dir_d2h) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return 1;   // tables are built by an eager call
-        const int rc = direct_ensure(w, s);
-        if (rc != SDH_OK) return rc;
-    }
     DirectArgs da{};
     da.p1b = w.dir_p1b; da.d2h = w.dir_d2h;
     da.d3 = w.pack.off_d3 >= 0 ? w.d3 : nullptr;
@@ -540,8 +539,11 @@ int launch_decode_direct(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s)
     // x staged by one pass of at most 4 x 16 bytes per thread (wide payloads with short rows were widened to 64 lanes per row
     // above for this; what still does not fit — more than 16384 staged inputs — keeps the fused launch)
     if (xlen > 16 * (int64_t) nthr) return 1;
-    return is_block ? direct_launch_steps<true, 4>(steps, p, da, grid, nthr, lds, s)
-                    : direct_launch_steps<false, 4>(steps, p, da, grid, nthr, lds, s);
+    if (xlen == 16 * (int64_t) nthr)
+        return is_block ? direct_launch_steps<true, 4, true>(steps, p, da, grid, nthr, lds, s)
+                        : direct_launch_steps<false, 4, true>(steps, p, da, grid, nthr, lds, s);
+    return is_block ? direct_launch_steps<true, 4, false>(steps, p, da, grid, nthr, lds, s)
+                    : direct_launch_steps<false, 4, false>(steps, p, da, grid, nthr, lds, s);
 }
 
 } // namespace sdh

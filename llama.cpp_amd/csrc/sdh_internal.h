@@ -101,7 +101,8 @@ struct DeviceWeight {
     bool fold_perm = false;      // the buckets are in the permuted input order j = inv_b[q] (x is permuted by the pre-pass, the W0 tile is
     short * fold_p16 = nullptr;  // [B][L] the input each permuted column multiplies (index into the row of x), -1 = none
     _Float16 * fold_gp = nullptr;// then a plain XOR-circulant of G_b: copied from fold_gp [B][8][L], fold_gp[b][c][i] = f16(G_b[i ^ c]))
-    // batch-1 decode with the base term formed by the row workgroups themselves (sdh_direct.hip), built on first use
+    // batch-1 decode with the base term formed by the row workgroups themselves (sdh_direct.hip), built at creation (one allocation)
+    uint8_t * dir_space = nullptr;        // room for the two tables behind the packed base parameters (inside pack_dev), or null
     float * dir_d2h = nullptr;            // [B][L/16][16] d2 transformed over the upper index bits
     unsigned short * dir_p1b = nullptr;   // [B][L] 4 * perm1
 };
@@ -200,6 +201,7 @@ int launch_decode_fused(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s);
 // One token, closed-form base without d1: every 16-row workgroup forms its rows' base term itself (no hand-off).
 // Returns SDH_OK if launched, 1 if the payload / call does not qualify, <0 on error.
 int launch_decode_direct(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s);
+int  direct_build_tables(DeviceWeight & w, hipStream_t s);   // at weight creation; a payload without tables never takes the direct launch
 void direct_free(DeviceWeight & w);
 // 1..MAX_FUSED_TOKENS tokens, gate and up tall base payloads of one shape: h[t][o] = act(gate(x_t)[o]) * up(x_t)[o] in
 // one launch. Returns SDH_OK, 1 if the pair does not qualify, <0 on error. nf_g / nf_u: the two nodes' counters.
