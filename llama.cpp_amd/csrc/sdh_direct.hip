@@ -8,7 +8,7 @@
 //   H_L = (H_{L/16} (x) I_16) (I (x) H_16), index i = 16 ih + il, so for the 16 rows p = 16 ph + r of one workgroup
 //   v[16 ph + r] = sum_k (-1)^<r,k>  sum_jh D2h[ph ^ jh][k] * Zt[jh][k]
 //   Zt[jh][.]  = H_16 (z[16 jh .. 16 jh + 15])                             one 16-point transform per 16 inputs, in registers
-//   D2h[s][k]  = sum_t (-1)^<s,t> d2[16 t + k]                             a table built once per weight (the H_{L/16} part)
+//   D2h[s][k]  = sum_t (-1)^<s,t> d2[16 t + k]                             a table built when the weight is created (the H_{L/16} part)
 //
 // i.e. L multiply-adds and L/16 small transforms per base block and workgroup instead of two transforms of L on one CU,
 // and every workgroup reads x (57 KB on cfg3), the permutation (2 bytes per input) and D2h (4 bytes per input) from L2
@@ -17,27 +17,30 @@
 // of the waves forms the base sums (two segments per thread on cfg3), the second half the rows' residual sums.
 //
 // What it costs and what it is bound by (MI355X, launch period in a stream of launches over 32 rotating payloads;
-// tools/gpu/r03_direct_wl.sh, in-kernel timeline tools/direct_stamps.py):
-//   cfg3 (Mistral down, block 32, K = 1536)  7.04 us   fused launch 7.84     Mistral gate COO K = 128   6.05 / 6.44
-//   Mistral gate block16                      5.51 / 6.12                     Gemma-3 4B gate COO        5.32 / 6.10
+// tools/gpu/r03_direct_wl.sh, tools/direct_time.py, in-kernel timeline tools/direct_stamps.py,
+// profiles/r03_q_direct_timeline_ablation.txt), direct / fused launch, us:
+//   cfg3 (Mistral down, block 32, K = 1536)  7.04 / 7.84      Mistral gate COO K = 128   6.05 / 6.44      gate block16  5.51 / 6.12
+//   Mistral down COO K = 128                  5.85 / 6.16      Mistral down block16       5.51 / 6.22      Gemma-3 4B gate / down  5.32 / 6.10, 5.33 / 6.06
 // A CU takes in about 25 bytes a clock from L2 / HBM whatever the mix, and a cfg3 workgroup asks for 204 KB (x 57, p1b 32,
 // D2h 64, payload 49 + indices): the last wave's x is stored ~2.5 us after the workgroup starts, the base sums are done
-// 2 us later, the store follows 0.6 us after that; without the base (x + payload only) the launch is 5.3 us. Arithmetic is
-// not the limit (the 16-point transforms, the gathers and the cross-lane sums together: 0.6 us of the base role). Measured
-// and left out: each workgroup walking x and the tables from its own offset (same time: the L2 is not the narrow place),
-// tables requested together with x (+0.3 us: they stand ahead of the row waves' x in the CU's queue), payload requested
-// ahead of x (+0.25 us), one role for all waves (every wait then counts the other role's loads: 8.0 us), 256-thread
-// workgroups for wide payloads with short rows (9.1 against 6.5 us: four waves fetch the workgroup's 200 KB — such payloads
-// run with 64 lanes per row instead, most of them idle, so that 1024 threads stage x: Mistral down COO K = 128 5.85 against
-// 6.16 us, block16 5.51 / 6.22, Gemma-3 4B down 5.33 / 6.06), and the gate | up pair of a
-// gated FFN block in this form (16 rows of both tensors per workgroup, 896 workgroups of 512 threads on Mistral dims:
-// 16.95 against 16.22 us per layer with the fused pair launch — 80 KB of x and tables per 16 KB of payload), and 1024-thread
-// workgroups of 64 rows for tall payloads with short rows (x, permutation and transforms shared by four row groups, 88
-// instead of 4 x 48 KB per 64 rows: Mistral gate 6.24 against 6.05 us, Gemma-3 4B gate 6.12 against 5.31 — four small
-// workgroups per CU at different points of their chains overlap better than one large one), and the same launch for 2-4
-// tokens in passes of two (tables and payload kept in registers, x of two tokens in LDS: every token bit-identical to its
-// one-token result, but 128 VGPRs do not hold a role's tables or payload plus two tokens' staging — with as few as 12
-// spilled registers the launch took 17-44 us against 7-15 us for the fused multi-token launches).
+// 1-2 us later, the store follows 0.6 us after that; without the base (x + payload only) the launch is 5.3-5.6 us.
+// Arithmetic is not the limit (the 16-point transforms, the gathers and the cross-lane sums: 0.6 us of the base role).
+//
+// Short rows and a long x (16 lanes per row would mean 256 threads for 16,384 staged inputs: 9.1 against 6.5 us, four waves
+// fetching the workgroup's 200 KB) run with more lanes per row than the row needs — 16 threads per 256 staged inputs, the
+// lanes past the row's end idle.
+//
+// Measured and left out: each workgroup walking x and the tables from its own offset (same time: the L2 is not the
+// narrow place); tables requested together with x (+0.3 us: they stand ahead of the row waves' x in the CU's queue);
+// payload requested ahead of x, or a fixed short time after it (+0.1-0.3 us); the base term picked up before the rows'
+// sums (+0.15 us); one role for all waves (every wait then counts the other role's loads: 8.0 us); the gate | up pair of a
+// gated FFN block in this form (16 rows of both tensors per workgroup: 16.95 against 16.22 us per layer with the fused pair
+// launch — 80 KB of x and tables per 16 KB of payload and workgroup); 1024-thread workgroups of 64 rows for tall payloads
+// (x, permutation and transforms shared by four row groups, 88 instead of 4 x 48 KB per 64 rows: Mistral gate 6.24
+// against 6.05 us — four small workgroups per CU at different points of their chains overlap better than one large one);
+// the same launch for 2-4 tokens in passes of two (every token bit-identical to its one-token result, but 128 VGPRs do
+// not hold a role's tables or payload plus two tokens' staging: with as few as 12 spilled registers 17-44 us against
+// 7-15 us for the fused multi-token launches).
 //
 // Arithmetic: fp32 throughout, but not the reference's butterfly order — the result is within the fast path's bound
 // (measured <= 0.05 of it), not bit-identical to the FWHT forms; a token's result through this launch therefore differs in
@@ -58,7 +61,6 @@ struct DirectArgs {
     int nseg_blk;                 // L / 16
     int nblk;                     // base blocks a row sums over: wide B, tall 1
     int xlen;                     // floats of x staged in LDS, zero past n_in: wide B * L, tall L
-    int base_threads;             // threads that form the base sums (a multiple of 64)
 };
 
 // D2h[b][s][k] = sum_t (-1)^popcount(s & t) d2[b][16 t + k], accumulated in double
@@ -176,19 +178,6 @@ __device__ __forceinline__ void wht16(float (&z)[16]) {
                 z[r | rb] = d.x; z[(r | rb) + 1] = d.y;
             }
         }
-    }
-}
-
-// One stage of the cross-lane reduce-scatter on lane bit K: N values per lane become N / 2, each the sum of the two
-// lanes' values of one half (the lane whose bit is clear keeps the lower half).
-template <int K, int N>
-__device__ __forceinline__ void scatter_stage(float (&a)[16], int lane) {
-    const bool hi = (lane >> K) & 1;
-#pragma unroll
-    for (int i = 0; i < N / 2; ++i) {
-        const float keep = hi ? a[i + N / 2] : a[i];
-        const float send = hi ? a[i] : a[i + N / 2];
-        a[i] = keep + base_lane_xor<K>(send);
     }
 }
 
@@ -533,8 +522,6 @@ int launch_decode_direct(DeviceWeight & w, const DeltaLaunch & a, hipStream_t s)
     }
     if (G < 8) return 1;                                     // a workgroup is at least one base wave and one row wave
     const unsigned nthr = 16u * (unsigned) G;
-    const int nseg = da.nblk * da.nseg_blk;
-    da.base_threads = (int) nthr / 2;
     const unsigned grid = (unsigned) (w.n_out / 16);
     // x staged by one pass of at most 4 x 16 bytes per thread (wide payloads with short rows were widened to 64 lanes per row
     // above for this; what still does not fit — more than 16384 staged inputs — keeps the fused launch)
