@@ -545,3 +545,30 @@ def test_direct_decode_declines_or_holds(hip, kw, dims):
     if kw.get("d13_random"):
         assert np.array_equal(bits(y), bits(w.forward_host(x, hip.FWD_NO_DIRECT)))
     assert w.nonfinite_count() == 0
+
+
+def test_direct_decode_captured_without_a_warm_up_call(hip):
+    """The direct launch needs nothing from an earlier eager call (its tables are built by sdh_weight_create, it has no
+    residency census): the very first call on a fresh handle can be recorded into a HIP graph, and replays give the
+    eager result of the same launch."""
+    torch = pytest.importorskip("torch")
+    p = config_payload("cfg4_mistral_gate_coo_k128")
+    w = hip.SeedDeltaWeight(p)
+    xs = make_x(p.n_in, 3, seed=55)
+    xg = torch.zeros((1, p.n_in), dtype=torch.float32, device="cuda")
+    yg = torch.full((1, p.n_out), float("nan"), dtype=torch.float32, device="cuda")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            w.forward_device(xg.data_ptr(), p.n_in, 1, yg.data_ptr(), p.n_out, stream=torch.cuda.current_stream().cuda_stream)
+        assert hip.last_decode_kind() == 1
+        outs = []
+        for i in range(3):
+            xg.copy_(torch.from_numpy(xs[i:i + 1]))
+            g.replay()
+            side.synchronize()
+            outs.append(yg.cpu().numpy().copy())
+    for i in range(3):
+        assert np.array_equal(bits(outs[i]), bits(w.forward_host(xs[i:i + 1])))
+        check_fast(p, xs[i:i + 1], outs[i], O.forward(p, xs[i:i + 1], nth=8))
