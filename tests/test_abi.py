@@ -98,3 +98,20 @@ def test_shim_library_defines_the_reference_constructors():
     undefined = subprocess.run(["nm", "-D", "--undefined-only", O.SHIM_SO], capture_output=True, text=True).stdout
     for name in ("sdh_init", "sdh_weight_create", "sdh_forward", "sdh_nonfinite_count"):
         assert name in undefined, name
+
+
+def test_python_flag_constants_match_the_header():
+    """Every SDH_FWD_* flag of include/seeddelta_hip.h that the Python layer names has the header's value."""
+    import re
+    import llama_cpp_amd.seeddelta as sd
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "include", "seeddelta_hip.h")).read()
+    flags = {m.group(1): int(m.group(2), 16) for m in re.finditer(r"#define\s+SDH_(FWD_[A-Z_0-9]+)\s+(0x[0-9A-Fa-f]+)", text)}
+    assert flags["FWD_NO_DIRECT"] == 0x100 and flags["FWD_MFMA_FOLD"] == 0x40
+    checked = 0
+    for name, value in flags.items():
+        if hasattr(sd, name):
+            assert getattr(sd, name) == value, name
+            checked += 1
+    assert checked >= 8
+    assert len(set(flags.values()) - {0}) == len([v for v in flags.values() if v != 0])      # no two flags share a bit pattern
